@@ -1,0 +1,108 @@
+"""ctypes binding of libgfla_hip.so (the C ABI declared in include/gfla_hip.h).
+
+The library is the only implementation of the ops: there is no Python/torch fallback.  If it
+is missing or fails to load, importing an op raises; if a call returns a non-zero status, a
+RuntimeError is raised (the reference swallows native errors, block_extractor_cuda.cc:11).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgfla_hip.so")
+_lib = None
+
+_i64, _int, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+
+# entry point -> argument types (pointers first, then sizes), mirroring include/gfla_hip.h
+_SIGNATURES = {
+    "gfla_block_extractor_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _ptr],
+    "gfla_block_extractor_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _ptr],
+    "gfla_local_attn_reshape_fwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
+    "gfla_local_attn_reshape_bwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
+    "gfla_resample2d_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_resample2d_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _int, _ptr],
+    "gfla_local_attn_aggregate_fwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_local_attn_aggregate_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
+}
+_FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_resample2d_bwd", "gfla_local_attn_aggregate_bwd"}
+
+
+def exported_symbols():
+    """Every symbol include/gfla_hip.h declares."""
+    names = ["gfla_abi_version", "gfla_status_string", "gfla_set_tuning"]
+    for base in _SIGNATURES:
+        for sfx in ("f32", "f64", "bf16"):
+            if sfx == "bf16" and base in _FWD_ONLY_BF16:
+                continue
+            names.append("%s_%s" % (base, sfx))
+    return names
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libgfla_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libgfla_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C global_flow_local_attention_amd/csrc`. There is no fallback path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        handle.gfla_status_string.restype = ctypes.c_char_p
+        handle.gfla_status_string.argtypes = [_int]
+        handle.gfla_set_tuning.argtypes = [_int, _int]
+        for base, args in _SIGNATURES.items():
+            for sfx in ("f32", "f64", "bf16"):
+                if sfx == "bf16" and base in _FWD_ONLY_BF16:
+                    continue
+                fn = getattr(handle, "%s_%s" % (base, sfx))
+                fn.argtypes = args
+                fn.restype = _int
+        _lib = handle
+    return _lib
+
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+
+
+def suffix(t, what):
+    try:
+        return _SUFFIX[t.dtype]
+    except KeyError:
+        raise TypeError("%s: unsupported dtype %s (float32, float64, bfloat16 forward)" % (what, t.dtype))
+
+
+def require_gpu(*tensors):
+    """The reference raises NotImplementedError for non-CUDA tensors (block_extractor.py:23-24)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NotImplementedError("GFLA ops run on the GPU only (got a %s tensor); there is no CPU path"
+                                      % t.device.type)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def call(name, ref_tensor, *args):
+    """Invoke `name` on the current stream of ref_tensor's device; raise on non-zero status."""
+    fn = getattr(lib(), name)
+    with torch.cuda.device(ref_tensor.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(ref_tensor.device).cuda_stream)
+        status = fn(*args, stream)
+    if status != 0:
+        raise RuntimeError("%s failed: %s (status %d)" % (name, lib().gfla_status_string(status).decode(), status))
+
+
+def set_tuning(key, value):
+    return lib().gfla_set_tuning(int(key), int(value))

@@ -1,0 +1,327 @@
+// block_extractor for gfx950: k x k bilinear patch gather around (x,y)+flow, and its gradient.
+//
+// Semantics follow the reference kernels (block_extractor_kernel.cu:20-85 forward, :89-170
+// backward): flow channel 0 = x, channel 1 = y, in source pixels; taps are clamped to the
+// source plane, weights come from the UN-clamped fractional part; (flow + offset) + index is
+// evaluated in that order in the arithmetic type.  The decomposition onto the machine is new:
+//
+//  forward   one lane owns V consecutive output x of one output row (one 16-byte store) and
+//            walks a chunk of channels with the SAME four tap offsets and weights, so the
+//            per-pixel index/weight arithmetic is paid once per chunk, the dominant HBM stream
+//            (the k^2-times-amplified output) is written in full 128-byte lines, and the
+//            4-tap reads of the small source plane are served by L1/L2.
+//  backward  one lane owns one flow pixel and a chunk of channels: d/dflow is reduced in
+//            registers over the k^2 taps and the channel chunk (1 atomic per lane per component
+//            instead of C*k^2 colliding atomics per address), grad_source is scattered with
+//            relaxed device-scope float atomics.
+#include "gfla_common.h"
+
+namespace gfla {
+
+// ----------------------------------------------------------------------------------------
+// forward: thread <-> (b, channel chunk, output row y, V consecutive x)
+// ----------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void be_fwd_rows_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs,
+    int Ws, int Hf, int Wf, int k, int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  const int Wo = k * Wf, Ho = k * Hf, WG = Wo / V;
+  const int sp_blk = blockIdx.x % sp_blocks;
+  const int bc = blockIdx.x / sp_blocks;
+  const int sp = sp_blk * kBlock + threadIdx.x;
+  if (sp >= Ho * WG) return;
+  const int b = bc / ncg, cg = bc - b * ncg;
+  const int c0 = cg * cpt;
+  const int c1 = min(C, c0 + cpt);
+  const int y = sp / WG;
+  const int x0 = (sp - y * WG) * V;
+  const int yf = y / k;
+  const int oy = (y - yf * k) - k / 2;
+
+  int off[V][4];
+  A w[V][4];
+  const T *flow_x = flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf;
+  const T *flow_y = flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const int x = x0 + e;
+    const int xf = x / k;
+    const int ox = (x - xf * k) - k / 2;
+    // block_extractor_kernel.cu:62-67
+    const A fy = Num<T>::ld(flow_y + xf) + (A)oy;
+    const A fx = Num<T>::ld(flow_x + xf) + (A)ox;
+    const A dy = fy + (A)yf;
+    const A dx = fx + (A)xf;
+    const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+    // :69-76
+    const int xL = clampi((int)fdx, 0, Ws - 1);
+    const int xR = clampi((int)(fdx + 1), 0, Ws - 1);
+    const int yT = clampi((int)fdy, 0, Hs - 1);
+    const int yB = clampi((int)(fdy + 1), 0, Hs - 1);
+    const A xL_P = 1 - (dx - fdx), xR_P = dx - fdx;
+    const A yT_P = 1 - (dy - fdy), yB_P = dy - fdy;
+    off[e][0] = yT * Ws + xL;
+    off[e][1] = yT * Ws + xR;
+    off[e][2] = yB * Ws + xL;
+    off[e][3] = yB * Ws + xR;
+    w[e][0] = xL_P * yT_P;
+    w[e][1] = xR_P * yT_P;
+    w[e][2] = xL_P * yB_P;
+    w[e][3] = xR_P * yB_P;
+  }
+
+  const int64_t plane_sz = (int64_t)Hs * Ws;
+  const int64_t oplane_sz = (int64_t)Ho * Wo;
+  const T *plane = src + ((int64_t)b * C + c0) * plane_sz;
+  T *orow = out + ((int64_t)b * C + c0) * oplane_sz + (int64_t)y * Wo + x0;
+  for (int c = c0; c < c1; ++c) {
+    Pack<T, V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      // :78-84, same order of accumulation
+      A s = w[e][0] * Num<T>::ld(plane + off[e][0]);
+      s += w[e][1] * Num<T>::ld(plane + off[e][1]);
+      s += w[e][2] * Num<T>::ld(plane + off[e][2]);
+      s += w[e][3] * Num<T>::ld(plane + off[e][3]);
+      r.v[e] = Num<T>::from(s);
+    }
+    *reinterpret_cast<Pack<T, V> *>(orow) = r;
+    plane += plane_sz;
+    orow += oplane_sz;
+  }
+}
+
+template <typename T, int V>
+static int launch_fwd_rows(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs,
+                           int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t stream) {
+  const int64_t Ho = k * Hf, Wo = k * Wf;
+  const int64_t sp = Ho * (Wo / V);
+  const int64_t sp_blocks = ceil_div(sp, kBlock);
+  int cpt = tuning(1) > 0 ? tuning(1) : pick_channels_per_thread(sp_blocks * kBlock, C, B, 16);
+  if (cpt > C) cpt = (int)C;
+  const int64_t ncg = ceil_div(C, cpt);
+  const int64_t blocks = sp_blocks * ncg * B;
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((be_fwd_rows_kernel<T, V>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src,
+                     flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, cpt, (int)ncg,
+                     (int)sp_blocks);
+  return launch_status();
+}
+
+template <typename T>
+static int block_extractor_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs,
+                               int64_t Ws, int64_t Hf, int64_t Wf, int k, gfla_stream_t stream_) {
+  if (!src || !flow || !out) return GFLA_ERR_NULL_POINTER;
+  if (B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Hf <= 0 || Wf <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
+  if (Hs * Ws > 0x7fffffffLL || (k * Hf) * (k * Wf) > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  constexpr int VMAX = 16 / sizeof(T) > 4 ? 4 : 16 / sizeof(T);  // f32:4  f64:2  bf16:4 (8-byte store)
+  const int64_t Wo = k * Wf;
+  const bool aligned = (reinterpret_cast<uintptr_t>(out) % (VMAX * sizeof(T))) == 0;
+  if (aligned && Wo % VMAX == 0)
+    return launch_fwd_rows<T, VMAX>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+  if (VMAX == 4 && (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0 && Wo % 2 == 0)
+    return launch_fwd_rows<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+  return launch_fwd_rows<T, 1>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// backward, compile-time K: thread <-> (b, channel chunk, flow pixel)
+// ----------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void be_bwd_pix_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
+    T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf, int cpt,
+    int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  const int sp_blk = blockIdx.x % sp_blocks;
+  const int bc = blockIdx.x / sp_blocks;
+  const int p = sp_blk * kBlock + threadIdx.x;
+  if (p >= Hf * Wf) return;
+  const int b = bc / ncg, cg = bc - b * ncg;
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int yf = p / Wf, xf = p - yf * Wf;
+  const int Wo = K * Wf;
+  const int64_t oplane_sz = (int64_t)K * Hf * Wo;
+  const int64_t plane_sz = (int64_t)Hs * Ws;
+
+  const A fx0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf);
+  const A fy0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf);
+  int xL[K], xR[K], yT[K], yB[K];
+  A ax[K], ay[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:132-136
+    const A dy = (fy0 + (A)(t - K / 2)) + (A)yf;
+    const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+    xL[t] = clampi((int)fdx, 0, Ws - 1);
+    xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
+    yT[t] = clampi((int)fdy, 0, Hs - 1) * Ws;
+    yB[t] = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+    ax[t] = dx - fdx;
+    ay[t] = dy - fdy;
+  }
+
+  A gx_acc = 0, gy_acc = 0;
+  const T *plane = src + ((int64_t)b * C + c0) * plane_sz;
+  T *gplane = gsrc ? gsrc + ((int64_t)b * C + c0) * plane_sz : nullptr;
+  const T *gblk = gout + ((int64_t)b * C + c0) * oplane_sz + (int64_t)(yf * K) * Wo + xf * K;
+  for (int c = c0; c < c1; ++c) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const A yT_P = 1 - ay[i], yB_P = ay[i];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const A xL_P = 1 - ax[j], xR_P = ax[j];
+        const A g = Num<T>::ld(gblk + i * Wo + j);
+        if (gflow) {
+          const A vTL = Num<T>::ld(plane + yT[i] + xL[j]);
+          const A vTR = Num<T>::ld(plane + yT[i] + xR[j]);
+          const A vBL = Num<T>::ld(plane + yB[i] + xL[j]);
+          const A vBR = Num<T>::ld(plane + yB[i] + xR[j]);
+          // :163-164
+          gy_acc += g * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
+          gx_acc += g * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+        }
+        if (gplane) {  // :158-161
+          atomic_add(gplane + yT[i] + xL[j], g * xL_P * yT_P);
+          atomic_add(gplane + yT[i] + xR[j], g * xR_P * yT_P);
+          atomic_add(gplane + yB[i] + xL[j], g * xL_P * yB_P);
+          atomic_add(gplane + yB[i] + xR[j], g * xR_P * yB_P);
+        }
+      }
+    }
+    plane += plane_sz;
+    if (gplane) gplane += plane_sz;
+    gblk += oplane_sz;
+  }
+  if (gflow) {
+    T *gfx = gflow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf;
+    T *gfy = gflow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf;
+    if (ncg == 1) {  // sole writer of this flow pixel
+      *gfx = *gfx + gx_acc;
+      *gfy = *gfy + gy_acc;
+    } else {
+      atomic_add(gfx, gx_acc);
+      atomic_add(gfy, gy_acc);
+    }
+  }
+}
+
+// backward, run-time k (any kernel size): thread <-> one grad_out element, the reference's own
+// decomposition (block_extractor_kernel.cu:110-168), kept as the fallback for unusual k.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void be_bwd_elem_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
+    T *__restrict__ gsrc, T *__restrict__ gflow, int64_t n, int C, int Hs, int Ws, int Hf, int Wf,
+    int k) {
+  using A = typename Num<T>::acc;
+  const int64_t index = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (index >= n) return;
+  const int Wo = k * Wf, Ho = k * Hf;
+  const int x = (int)(index % Wo);
+  const int y = (int)((index / Wo) % Ho);
+  const int64_t bcI = index / ((int64_t)Wo * Ho);
+  const int b = (int)(bcI / C);
+  const int yf = y / k, xf = x / k;
+  const A fy = Num<T>::ld(flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf) + (A)(y % k - k / 2);
+  const A fx = Num<T>::ld(flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf) + (A)(x % k - k / 2);
+  const A dy = fy + (A)yf, dx = fx + (A)xf;
+  const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+  const int xL = clampi((int)fdx, 0, Ws - 1), xR = clampi((int)(fdx + 1), 0, Ws - 1);
+  const int yT = clampi((int)fdy, 0, Hs - 1), yB = clampi((int)(fdy + 1), 0, Hs - 1);
+  const A xL_P = 1 - (dx - fdx), xR_P = dx - fdx, yT_P = 1 - (dy - fdy), yB_P = dy - fdy;
+  const int64_t pbase = bcI * Hs * Ws;
+  const A g = Num<T>::ld(gout + index);
+  if (gsrc) {
+    atomic_add(gsrc + pbase + (int64_t)yT * Ws + xL, g * xL_P * yT_P);
+    atomic_add(gsrc + pbase + (int64_t)yT * Ws + xR, g * xR_P * yT_P);
+    atomic_add(gsrc + pbase + (int64_t)yB * Ws + xL, g * xL_P * yB_P);
+    atomic_add(gsrc + pbase + (int64_t)yB * Ws + xR, g * xR_P * yB_P);
+  }
+  if (gflow) {
+    const A vTL = Num<T>::ld(src + pbase + (int64_t)yT * Ws + xL);
+    const A vTR = Num<T>::ld(src + pbase + (int64_t)yT * Ws + xR);
+    const A vBL = Num<T>::ld(src + pbase + (int64_t)yB * Ws + xL);
+    const A vBR = Num<T>::ld(src + pbase + (int64_t)yB * Ws + xR);
+    atomic_add(gflow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf,
+               g * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR));
+    atomic_add(gflow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf,
+               g * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR));
+  }
+}
+
+template <typename T, int K>
+static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
+                          int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                          hipStream_t stream) {
+  const int64_t sp_blocks = ceil_div(Hf * Wf, kBlock);
+  int cpt = tuning(1) > 0 ? tuning(1) : pick_channels_per_thread(sp_blocks * kBlock, C, B, 16, 2 * kNumCU * kWavesPerCU);
+  if (cpt > C) cpt = (int)C;
+  const int64_t ncg = ceil_div(C, cpt);
+  const int64_t blocks = sp_blocks * ncg * B;
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((be_bwd_pix_kernel<T, K>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src,
+                     flow, gout, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, cpt,
+                     (int)ncg, (int)sp_blocks);
+  return launch_status();
+}
+
+template <typename T>
+static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
+                               int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                               gfla_stream_t stream_) {
+  if (!src || !flow || !gout) return GFLA_ERR_NULL_POINTER;
+  if (B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Hf <= 0 || Wf <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
+  if (Hs * Ws > 0x7fffffffLL || (k * Hf) * (k * Wf) > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  if (!gsrc && !gflow) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  switch (k) {
+    case 2: return launch_bwd_pix<T, 2>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream);
+    case 3: return launch_bwd_pix<T, 3>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream);
+    case 4: return launch_bwd_pix<T, 4>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream);
+    case 5: return launch_bwd_pix<T, 5>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream);
+    default: break;
+  }
+  const int64_t n = B * C * (k * Hf) * (k * Wf);
+  const int64_t blocks = ceil_div(n, kBlock);
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((be_bwd_elem_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, flow,
+                     gout, gsrc, gflow, n, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
+  return launch_status();
+}
+
+}  // namespace gfla
+
+using gfla::bf16_t;
+
+extern "C" {
+int gfla_block_extractor_fwd_f32(const float *s, const float *f, float *o, int64_t B, int64_t C,
+                                 int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                 gfla_stream_t st) {
+  return gfla::block_extractor_fwd<float>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_fwd_f64(const double *s, const double *f, double *o, int64_t B, int64_t C,
+                                 int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                 gfla_stream_t st) {
+  return gfla::block_extractor_fwd<double>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_fwd_bf16(const uint16_t *s, const uint16_t *f, uint16_t *o, int64_t B,
+                                  int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                  gfla_stream_t st) {
+  return gfla::block_extractor_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(s),
+                                           reinterpret_cast<const bf16_t *>(f),
+                                           reinterpret_cast<bf16_t *>(o), B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_bwd_f32(const float *s, const float *f, const float *go, float *gs,
+                                 float *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                 int64_t Wf, int k, gfla_stream_t st) {
+  return gfla::block_extractor_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_bwd_f64(const double *s, const double *f, const double *go, double *gs,
+                                 double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                                 int64_t Hf, int64_t Wf, int k, gfla_stream_t st) {
+  return gfla::block_extractor_bwd<double>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+}

@@ -1,0 +1,358 @@
+// resample2d for gfx950: normalised Gaussian-weighted k x k flow warping with a per-pixel sigma.
+//
+// Semantics follow resample2d_kernel.cu:20-95 (forward), :98-202 (d/d input1) and :204-330
+// (d/d input2 = d/d(dx,dy,sigma)): taps at floor(p) - f*d and floor(p) + (f+1)*d for
+// f in [0,k/2), clamped; weight exp(-dist^2 / (2 sigma^2)) evaluated in double (the reference's
+// SAFE_DIV macro promotes the argument, :15,75-78); output = sum(w*v)/sum(w).
+//
+// What is different from the reference: the Gaussian weights depend only on (b,y,x), so one lane
+// computes them ONCE for its pixel and then walks a chunk of channels (the reference recomputes
+// 4*(k/2)^2 double-precision exps for every channel of every pixel); the input2 gradient
+// produces dx, dy and sigma in one pass over the channels (the reference runs three threads per
+// pixel, each looping over all channels twice).
+#include "gfla_common.h"
+
+namespace gfla {
+
+constexpr double kEps = 1e-8;  // resample2d_kernel.cu:14
+
+// SAFE_DIV(a,b) with a,b in the arithmetic type, value in double (resample2d_kernel.cu:15).
+template <typename A>
+__device__ __forceinline__ double safe_div(A a, A b) {
+  return (b == 0) ? ((double)a / kEps) : (double)(a / b);
+}
+
+template <typename A>
+__device__ __forceinline__ A gauss(A dist, A sigma) {
+  return (A)exp(safe_div<A>(-dist * dist, 2 * sigma * sigma));  // :75-78
+}
+
+// Per-pixel state shared by all three kernels: tap row/column offsets and 1-D weights.
+template <typename A, int KH>
+struct Taps {
+  int xL[KH], xR[KH], yT[KH], yB[KH];  // yT/yB pre-multiplied by the row pitch
+  A xLd[KH], xRd[KH], yTd[KH], yBd[KH];  // distances
+  A xLp[KH], xRp[KH], yTp[KH], yBp[KH];  // Gaussian weights
+  A sum;
+  A sigma;
+
+  // floor_alpha: fractional part from floor (forward, input2 gradient) or from int() truncation
+  // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
+  __device__ __forceinline__ void init(A dx, A dy, A sg, int x, int y, int Hi, int Wi, int dil,
+                                       bool trunc_alpha) {
+    sigma = sg;
+    const A xf = (A)x + dx, yf = (A)y + dy;  // :52-53
+    const A fxf = floor_t<A>(xf), fyf = floor_t<A>(yf);
+    const A alpha = trunc_alpha ? xf - (A)(int)xf : xf - fxf;
+    const A beta = trunc_alpha ? yf - (A)(int)yf : yf - fyf;
+    sum = 0;
+#pragma unroll
+    for (int f = 0; f < KH; ++f) {
+      yT[f] = clampi((int)(fyf - (A)(f * dil)), 0, Hi - 1) * Wi;         // :62-63
+      yB[f] = clampi((int)(fyf + (A)((f + 1) * dil)), 0, Hi - 1) * Wi;
+      xL[f] = clampi((int)(fxf - (A)(f * dil)), 0, Wi - 1);              // :66-67
+      xR[f] = clampi((int)(fxf + (A)((f + 1) * dil)), 0, Wi - 1);
+      xLd[f] = (A)(f * dil) + alpha;                                     // :70-73
+      xRd[f] = (A)((1. + f) * dil) - alpha;
+      yTd[f] = (A)(f * dil) + beta;
+      yBd[f] = (A)((1. + f) * dil) - beta;
+      xLp[f] = gauss<A>(xLd[f], sg);
+      xRp[f] = gauss<A>(xRd[f], sg);
+      yTp[f] = gauss<A>(yTd[f], sg);
+      yBp[f] = gauss<A>(yBd[f], sg);
+    }
+#pragma unroll
+    for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+      for (int fx = 0; fx < KH; ++fx)  // :89
+        sum += (yTp[fy] * xLp[fx] + yTp[fy] * xRp[fx] + yBp[fy] * xLp[fx] + yBp[fy] * xRp[fx]);
+  }
+};
+
+__device__ __forceinline__ bool decode(int sp_blocks, int ncg, int HW, int W, int &b, int &cg, int &y,
+                                       int &x) {
+  const int sp_blk = blockIdx.x % sp_blocks;
+  const int bc = blockIdx.x / sp_blocks;
+  const int p = sp_blk * kBlock + threadIdx.x;
+  if (p >= HW) return false;
+  b = bc / ncg;
+  cg = bc - b * ncg;
+  y = p / W;
+  x = p - y * W;
+  return true;
+}
+
+// ---- forward ---------------------------------------------------------------------------
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_fwd_kernel(const T *__restrict__ in1,
+                                                       const T *__restrict__ in2, T *__restrict__ out,
+                                                       int C, int Hi, int Wi, int H, int W, int dil,
+                                                       int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  const T *plane = in1 + ((int64_t)b * C + c0) * plane_sz;
+  T *o = out + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
+  for (int c = c0; c < c1; ++c) {
+    A val = 0;
+#pragma unroll
+    for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+      for (int fx = 0; fx < KH; ++fx) {  // :85-88
+        val += (t.yTp[fy] * t.xLp[fx]) * Num<T>::ld(plane + t.yT[fy] + t.xL[fx]);
+        val += (t.yTp[fy] * t.xRp[fx]) * Num<T>::ld(plane + t.yT[fy] + t.xR[fx]);
+        val += (t.yBp[fy] * t.xLp[fx]) * Num<T>::ld(plane + t.yB[fy] + t.xL[fx]);
+        val += (t.yBp[fy] * t.xRp[fx]) * Num<T>::ld(plane + t.yB[fy] + t.xR[fx]);
+      }
+    *o = Num<T>::from((A)safe_div<A>(val, t.sum));  // :93
+    plane += plane_sz;
+    o += HW;
+  }
+}
+
+// ---- d/d input1 --------------------------------------------------------------------------
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ in2,
+                                                        const T *__restrict__ gout, T *__restrict__ gin1,
+                                                        int C, int Hi, int Wi, int H, int W, int dil,
+                                                        int trunc, int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
+  // normalised tap weights, SAFE_DIV(yP*xP, sum) (:195-198)
+  A q[KH][KH][4];
+#pragma unroll
+  for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+    for (int fx = 0; fx < KH; ++fx) {
+      q[fy][fx][0] = (A)safe_div<A>(t.yTp[fy] * t.xLp[fx], t.sum);
+      q[fy][fx][1] = (A)safe_div<A>(t.yTp[fy] * t.xRp[fx], t.sum);
+      q[fy][fx][2] = (A)safe_div<A>(t.yBp[fy] * t.xLp[fx], t.sum);
+      q[fy][fx][3] = (A)safe_div<A>(t.yBp[fy] * t.xRp[fx], t.sum);
+    }
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  T *gplane = gin1 + ((int64_t)b * C + c0) * plane_sz;
+  const T *g = gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
+  for (int c = c0; c < c1; ++c) {
+    const A go = Num<T>::ld(g);
+#pragma unroll
+    for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+      for (int fx = 0; fx < KH; ++fx) {
+        atomic_add(gplane + t.yT[fy] + t.xL[fx], q[fy][fx][0] * go);
+        atomic_add(gplane + t.yT[fy] + t.xR[fx], q[fy][fx][1] * go);
+        atomic_add(gplane + t.yB[fy] + t.xL[fx], q[fy][fx][2] * go);
+        atomic_add(gplane + t.yB[fy] + t.xR[fx], q[fy][fx][3] * go);
+      }
+    gplane += plane_sz;
+    g += HW;
+  }
+}
+
+// ---- d/d input2 = d/d(dx, dy, sigma) --------------------------------------------------------
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ in1,
+                                                        const T *__restrict__ in2,
+                                                        const T *__restrict__ gout, T *__restrict__ gin2,
+                                                        int C, int Hi, int Wi, int H, int W, int dil,
+                                                        int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  const A sg = t.sigma;
+  // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (:273-292)
+  const A d2 = -sg * sg, d3 = sg * sg * sg;
+  const A inv2 = (d2 == 0) ? (A)(1.0 / kEps) : (A)1 / d2;
+  const A inv3 = (d3 == 0) ? (A)(1.0 / kEps) : (A)1 / d3;
+
+  // per-tap weight and the three derivative coefficients; taps ordered TL,TR,BL,BR
+  A wt[KH][KH][4], cx[KH][KH][4], cy[KH][KH][4], cs[KH][KH][4];
+  A sgx = 0, sgy = 0, sgs = 0;  // "sumgrad" per derivative, counted once (the reference counts it C
+                                // times and divides by C, :277,318)
+#pragma unroll
+  for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+    for (int fx = 0; fx < KH; ++fx) {
+      const A xd[2] = {t.xLd[fx], t.xRd[fx]}, xp[2] = {t.xLp[fx], t.xRp[fx]};
+      const A yd[2] = {t.yTd[fy], t.yBd[fy]}, yp[2] = {t.yTp[fy], t.yBp[fy]};
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int q = r * 2 + s;
+          const A w = yp[r] * xp[s];
+          wt[fy][fx][q] = w;
+          cx[fy][fx][q] = (s == 0 ? xd[s] : -xd[s]) * w * inv2;           // :273-277
+          cy[fy][fx][q] = (r == 0 ? yd[r] : -yd[r]) * w * inv2;           // :280-284
+          cs[fy][fx][q] = (yd[r] * yd[r] + xd[s] * xd[s]) * w * inv3;     // :287-291
+          sgx += cx[fy][fx][q];
+          sgy += cy[fy][fx][q];
+          sgs += cs[fy][fx][q];
+        }
+    }
+
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  const T *plane = in1 + ((int64_t)b * C + c0) * plane_sz;
+  const T *g = gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
+  A g1x = 0, g1y = 0, g1s = 0, S = 0;
+  for (int c = c0; c < c1; ++c) {
+    const A go = Num<T>::ld(g);
+#pragma unroll
+    for (int fy = 0; fy < KH; ++fy)
+#pragma unroll
+      for (int fx = 0; fx < KH; ++fx) {
+        const A p0 = go * Num<T>::ld(plane + t.yT[fy] + t.xL[fx]);
+        const A p1 = go * Num<T>::ld(plane + t.yT[fy] + t.xR[fx]);
+        const A p2 = go * Num<T>::ld(plane + t.yB[fy] + t.xL[fx]);
+        const A p3 = go * Num<T>::ld(plane + t.yB[fy] + t.xR[fx]);
+        const A pv[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g1x += cx[fy][fx][q] * pv[q];
+          g1y += cy[fy][fx][q] * pv[q];
+          g1s += cs[fy][fx][q] * pv[q];
+          S += wt[fy][fx][q] * pv[q];
+        }
+      }
+    plane += plane_sz;
+    g += HW;
+  }
+  // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S; linear in (grad1, S) so channel
+  // chunks combine by addition.
+  const A sum = t.sum, sum2 = t.sum * t.sum;
+  const A is = (sum == 0) ? (A)(1.0 / kEps) : (A)1 / sum;
+  const A is2 = (sum2 == 0) ? (A)(1.0 / kEps) : (A)1 / sum2;
+  const A rx = g1x * is - (sgx * S) * is2;
+  const A ry = g1y * is - (sgy * S) * is2;
+  const A rs = g1s * is - (sgs * S) * is2;
+  T *o = gin2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  if (ncg == 1) {
+    o[0] = Num<T>::from(Num<T>::ld(o) + rx);
+    o[HW] = Num<T>::from(Num<T>::ld(o + HW) + ry);
+    o[2 * HW] = Num<T>::from(Num<T>::ld(o + 2 * HW) + rs);
+  } else {
+    atomic_add(o, rx);
+    atomic_add(o + HW, ry);
+    atomic_add(o + 2 * HW, rs);
+  }
+}
+
+struct Geo {
+  int cpt, ncg, sp_blocks;
+  int64_t blocks;
+};
+static Geo geometry(int64_t B, int64_t C, int64_t H, int64_t W, int max_cpt, int64_t want_waves) {
+  Geo g;
+  g.sp_blocks = (int)ceil_div(H * W, kBlock);
+  int cpt = tuning(1) > 0 ? tuning(1) : pick_channels_per_thread((int64_t)g.sp_blocks * kBlock, C, B, max_cpt, want_waves);
+  if (cpt > C) cpt = (int)C;
+  g.cpt = cpt;
+  g.ncg = (int)ceil_div(C, cpt);
+  g.blocks = (int64_t)g.sp_blocks * g.ncg * B;
+  return g;
+}
+
+template <typename T>
+static int check(const void *a, const void *b, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H,
+                 int64_t W, int k, int dil) {
+  if (!a || !b) return GFLA_ERR_NULL_POINTER;
+  if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || H <= 0 || W <= 0 || k < 2 || dil < 1) return GFLA_ERR_BAD_SHAPE;
+  if (k / 2 > 4) return GFLA_ERR_UNSUPPORTED;  // kernel_size up to 9
+  if (Hi * Wi > 0x7fffffffLL || H * W > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  return GFLA_OK;
+}
+
+#define GFLA_KH_SWITCH(KHV, ...) \
+  switch (KHV) {                  \
+    case 1: { constexpr int KH = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int KH = 2; __VA_ARGS__; } break; \
+    case 3: { constexpr int KH = 3; __VA_ARGS__; } break; \
+    default: { constexpr int KH = 4; __VA_ARGS__; } break; \
+  }
+
+template <typename T>
+static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t C, int64_t Hi,
+                          int64_t Wi, int64_t H, int64_t W, int k, int dil, gfla_stream_t stream_) {
+  int st = check<T>(in1, in2, B, C, Hi, Wi, H, W, k, dil);
+  if (st != GFLA_OK) return st;
+  if (!out) return GFLA_ERR_NULL_POINTER;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Geo g = geometry(B, C, H, W, 16, 4 * kNumCU * kWavesPerCU);
+  if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  GFLA_KH_SWITCH(k / 2, rs_fwd_kernel<T, KH><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(in1, in2, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, g.cpt, g.ncg, g.sp_blocks));
+  return launch_status();
+}
+
+template <typename T>
+static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T *gin2, int64_t B,
+                          int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int dil,
+                          int trunc, gfla_stream_t stream_) {
+  int st = check<T>(in1, in2, B, C, Hi, Wi, H, W, k, dil);
+  if (st != GFLA_OK) return st;
+  if (!gout) return GFLA_ERR_NULL_POINTER;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (gin1) {
+    Geo g = geometry(B, C, H, W, 16, 4 * kNumCU * kWavesPerCU);
+    if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+    GFLA_KH_SWITCH(k / 2, rs_bwd1_kernel<T, KH><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, g.cpt, g.ncg, g.sp_blocks));
+    st = launch_status();
+    if (st != GFLA_OK) return st;
+  }
+  if (gin2) {
+    Geo g = geometry(B, C, H, W, 512, 2 * kNumCU * kWavesPerCU);
+    if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+    GFLA_KH_SWITCH(k / 2, rs_bwd2_kernel<T, KH><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, g.cpt, g.ncg, g.sp_blocks));
+    st = launch_status();
+  }
+  return st;
+}
+
+}  // namespace gfla
+
+using gfla::bf16_t;
+
+extern "C" {
+int gfla_resample2d_fwd_f32(const float *a, const float *b, float *o, int64_t B, int64_t C, int64_t Hi,
+                            int64_t Wi, int64_t H, int64_t W, int k, int d, gfla_stream_t st) {
+  return gfla::resample2d_fwd<float>(a, b, o, B, C, Hi, Wi, H, W, k, d, st);
+}
+int gfla_resample2d_fwd_f64(const double *a, const double *b, double *o, int64_t B, int64_t C,
+                            int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int d,
+                            gfla_stream_t st) {
+  return gfla::resample2d_fwd<double>(a, b, o, B, C, Hi, Wi, H, W, k, d, st);
+}
+int gfla_resample2d_fwd_bf16(const uint16_t *a, const uint16_t *b, uint16_t *o, int64_t B, int64_t C,
+                             int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int d,
+                             gfla_stream_t st) {
+  return gfla::resample2d_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(a),
+                                      reinterpret_cast<const bf16_t *>(b), reinterpret_cast<bf16_t *>(o),
+                                      B, C, Hi, Wi, H, W, k, d, st);
+}
+int gfla_resample2d_bwd_f32(const float *a, const float *b, const float *go, float *g1, float *g2,
+                            int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,
+                            int d, int trunc, gfla_stream_t st) {
+  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st);
+}
+int gfla_resample2d_bwd_f64(const double *a, const double *b, const double *go, double *g1, double *g2,
+                            int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,
+                            int d, int trunc, gfla_stream_t st) {
+  return gfla::resample2d_bwd<double>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st);
+}
+}

@@ -1,0 +1,150 @@
+"""Local attention of GFLA: the ExtractorAttn block (reference: model/networks/base_function.py:790-818).
+
+`ExtractorAttn` here has the reference's constructor, attributes (`extractor`, `reshape`,
+`fully_connect_layer` -- so `state_dict` keys are `fully_connect_layer.{0,2}.{weight,bias}` and
+reference checkpoints load) and methods (`forward`, `hook_attn_param`).  Two evaluation modes:
+
+* fused (default): block_source is extracted once for the first convolution; the Softmax ->
+  LocalAttnReshape -> multiply -> avg_pool2d tail runs as ONE kernel straight from `source`
+  (gfla_local_attn_aggregate_*), and block_target is never built: the first convolution is split
+  into its target half -- a stride-1 convolution of the replicate-padded target, exactly equal to
+  the stride-k convolution over the zero-flow unfold -- and its source half.
+* unfused: the reference's op-by-op composition through the three standalone modules
+  (base_function.py:804-810).  Parity tests compare the two.
+
+`patch_reference_extractor_attn(cls)` swaps the fused forward into an ExtractorAttn class defined
+elsewhere (the unmodified reference file) without touching its __init__ or parameters.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from .block_extractor import BlockExtractor
+from .local_attn_reshape import LocalAttnReshape
+
+_FUSED_MAX_K = 5  # kernel sizes the fused tail is instantiated for
+
+
+class LocalAttnAggregateFunction(Function):
+    """out = avg_pool2d(LocalAttnReshape(softmax(logits)) * BlockExtractor(source, flow), k, k)
+    without materialising anything of size (B,C,kH,kW).  Returns (out, attn) where attn is the
+    post-softmax (B,k*k,H,W) map (what hook_attn_param exposes as attn_param_)."""
+
+    @staticmethod
+    def forward(ctx, source, flow_field, logits, kernel_size, apply_softmax):
+        assert source.is_contiguous() and flow_field.is_contiguous() and logits.is_contiguous()
+        _lib.require_gpu(source, flow_field, logits)
+        b, c, hs, ws = source.size()
+        bf, two, h, w = flow_field.size()
+        k = int(kernel_size)
+        if two != 2 or bf != b or tuple(logits.shape) != (b, k * k, h, w):
+            raise ValueError("local_attn_aggregate: inconsistent shapes %s %s %s" %
+                             (tuple(source.shape), tuple(flow_field.shape), tuple(logits.shape)))
+        if not (source.dtype == flow_field.dtype == logits.dtype):
+            raise TypeError("local_attn_aggregate: mixed dtypes")
+        out = source.new_empty((b, c, h, w))
+        attn = torch.empty_like(logits)
+        _lib.call("gfla_local_attn_aggregate_fwd_" + _lib.suffix(source, "local_attn_aggregate"), source,
+                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(logits), _lib.ptr(out), _lib.ptr(attn),
+                  b, c, hs, ws, h, w, k, 1 if apply_softmax else 0)
+        ctx.save_for_backward(source, flow_field, attn)
+        ctx.kernel_size = k
+        ctx.apply_softmax = bool(apply_softmax)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_attn):
+        source, flow_field, attn = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, c, hs, ws = source.size()
+        _, _, h, w = flow_field.size()
+        ns, nf, nl = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gs = torch.zeros_like(source) if ns else None
+        gf = torch.zeros_like(flow_field) if nf else None
+        gl = torch.zeros_like(attn) if nl else None
+        if ns or nf or nl:
+            _lib.call("gfla_local_attn_aggregate_bwd_" + _lib.suffix(source, "local_attn_aggregate backward"),
+                      source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(attn), _lib.ptr(grad_out),
+                      _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl),
+                      b, c, hs, ws, h, w, ctx.kernel_size, 1 if ctx.apply_softmax else 0)
+        return gs, gf, gl, None, None
+
+
+def _fused_attention(self, source, target, flow_field):
+    """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
+    k = self.kernel_size
+    fc = self.fully_connect_layer
+    conv0, act, conv1, last = fc[0], fc[1], fc[2], fc[3]
+    c = source.size(1)
+    source_c = source.contiguous()
+    flow_c = flow_field.contiguous()
+    block_source = self.extractor(source_c, flow_c)                       # base_function.py:805
+    # base_function.py:806-807: conv0(cat(block_target, block_source)) with block_target the
+    # zero-flow (replicate-padded) unfold of target == stride-1 conv of the padded target.
+    lo, hi = k // 2, k - 1 - k // 2
+    target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
+    hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
+    hidden = hidden + F.conv2d(block_source, conv0.weight[:, c:], None, stride=k)
+    logits = conv1(act(hidden))
+    if isinstance(last, nn.Softmax) and last.dim == 1:
+        result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True)
+    else:  # softmax=None builds the block with the plain nonlinearity instead (:794)
+        weights = last(logits).contiguous()
+        result, _ = LocalAttnAggregateFunction.apply(source_c, flow_c, weights, k, False)
+        attn = weights
+    return attn, result
+
+
+def _unfused_attention(self, source, target, flow_field):
+    """The reference's own composition (base_function.py:804-810 / :812-818)."""
+    block_source = self.extractor(source, flow_field)
+    block_target = self.extractor(target, torch.zeros_like(flow_field))
+    attn_param_ = self.fully_connect_layer(torch.cat((block_target, block_source), 1))
+    attn_param = self.reshape(attn_param_, self.kernel_size)
+    result = F.avg_pool2d(attn_param * block_source, self.kernel_size, self.kernel_size)
+    return attn_param_, result
+
+
+def _use_fused(self):
+    return getattr(self, "fused", True) and self.kernel_size <= _FUSED_MAX_K
+
+
+def _forward(self, source, target, flow_field):
+    fn = _fused_attention if _use_fused(self) else _unfused_attention
+    return fn(self, source, target, flow_field)[1]
+
+
+def _hook_attn_param(self, source, target, flow_field):
+    fn = _fused_attention if _use_fused(self) else _unfused_attention
+    return fn(self, source, target, flow_field)
+
+
+class ExtractorAttn(nn.Module):
+    def __init__(self, feature_nc, kernel_size=4, nonlinearity=nn.LeakyReLU(), softmax=None):
+        super(ExtractorAttn, self).__init__()
+        self.kernel_size = kernel_size
+        hidden_nc = 128
+        softmax = nonlinearity if softmax is None else nn.Softmax(dim=1)
+        self.extractor = BlockExtractor(kernel_size=kernel_size)
+        self.reshape = LocalAttnReshape()
+        self.fully_connect_layer = nn.Sequential(
+            nn.Conv2d(2 * feature_nc, hidden_nc, kernel_size=kernel_size, stride=kernel_size, padding=0),
+            nonlinearity,
+            nn.Conv2d(hidden_nc, kernel_size * kernel_size, kernel_size=1, stride=1, padding=0),
+            softmax,)
+        self.fused = True
+
+    forward = _forward
+    hook_attn_param = _hook_attn_param
+
+
+def patch_reference_extractor_attn(cls):
+    """Replace forward/hook_attn_param of an externally defined ExtractorAttn class (the
+    reference's, imported unchanged) with the fused evaluation.  __init__, attribute names and
+    state_dict keys are left alone; instances honour an optional `.fused = False`."""
+    cls.forward = _forward
+    cls.hook_attn_param = _hook_attn_param
+    return cls

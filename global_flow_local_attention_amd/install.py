@@ -1,0 +1,74 @@
+"""Make the UNMODIFIED reference network code consume these ops.
+
+The reference imports its ops by path (base_function.py:10,12,13; external_function.py:5-7;
+generator.py:6):
+    model.networks.block_extractor.block_extractor          -> BlockExtractor
+    model.networks.local_attn_reshape.local_attn_reshape    -> LocalAttnReshape
+    model.networks.resample2d_package.resample2d            -> Resample2d
+`install()` registers this package's modules under those names in sys.modules (plus light stubs
+for packages the reference imports at module scope but that the hot path never calls), so that
+`import model.networks.generator` from a reference checkout picks them up with no source change.
+See INTEGRATION.md.
+"""
+import importlib
+import os
+import sys
+import types
+
+from . import block_extractor, local_attn_reshape, resample2d
+from .extractor_attn import patch_reference_extractor_attn
+
+_ALIASES = {
+    "model.networks.block_extractor.block_extractor": block_extractor,
+    "model.networks.local_attn_reshape.local_attn_reshape": local_attn_reshape,
+    "model.networks.resample2d_package.resample2d": resample2d,
+}
+
+
+def _namespace(name, path=None):
+    mod = sys.modules.get(name)
+    if mod is None:
+        mod = types.ModuleType(name)
+        mod.__path__ = [path] if path else []
+        sys.modules[name] = mod
+    return mod
+
+
+def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True):
+    """Alias the three op modules; optionally patch the reference's ExtractorAttn with the fused
+    forward.  `reference_root` (a checkout of the reference) is only needed if `model` is not
+    already importable.  Returns the reference's `model.networks.base_function` module when it
+    could be imported, else None."""
+    if reference_root:
+        # a bare namespace for `model` skips model/__init__.py (which pulls in skimage etc.)
+        _namespace("model", os.path.join(reference_root, "model"))
+        _namespace("model.networks", os.path.join(reference_root, "model", "networks"))
+        if reference_root not in sys.path:
+            sys.path.insert(0, reference_root)
+    for pkg in ("model.networks.block_extractor", "model.networks.local_attn_reshape",
+                "model.networks.resample2d_package"):
+        if reference_root or pkg.rsplit(".", 1)[0] in sys.modules:
+            _namespace(pkg)
+    for name, mod in _ALIASES.items():
+        sys.modules[name] = mod
+        parent, _, leaf = name.rpartition(".")
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, mod)
+    if stub_missing:
+        for missing in ("imageio", "natsort"):
+            try:
+                importlib.import_module(missing)
+            except ImportError:
+                stub = types.ModuleType(missing)
+                if missing == "natsort":
+                    stub.natsorted = sorted
+                sys.modules[missing] = stub
+    base_function = None
+    if "model.networks" in sys.modules:
+        try:
+            base_function = importlib.import_module("model.networks.base_function")
+        except ImportError:
+            base_function = None
+    if base_function is not None and fuse_extractor_attn and hasattr(base_function, "ExtractorAttn"):
+        patch_reference_extractor_attn(base_function.ExtractorAttn)
+    return base_function

@@ -1,0 +1,174 @@
+/*
+ * gfla_hip.h -- C ABI of libgfla_hip.so, the MI355X (gfx950) implementation of the
+ * Global-Flow-Local-Attention feature-warping hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one `forward`/`backward` of the
+ * reference's three pybind modules (paths relative to the reference checkout):
+ *
+ *   block_extractor_cuda      model/networks/block_extractor/block_extractor_cuda.cc:5-33
+ *   local_attn_reshape_cuda   model/networks/local_attn_reshape/local_attn_reshape_cuda.cc:5-29
+ *   resample2d_cuda           model/networks/resample2d_package/resample2d_cuda.cc:6-33
+ *
+ * plus one fused entry point pair for the softmax -> reshape -> multiply -> avg_pool tail of
+ * ExtractorAttn.forward (model/networks/base_function.py:803,808-809), which the reference runs
+ * as four separate torch/custom ops.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; tensors are contiguous NCHW, exactly what
+ *     the reference wrappers assert (block_extractor.py:9-10, local_attn_reshape.py:9,
+ *     resample2d.py:10-11);
+ *   - the caller owns every buffer (the reference allocates outputs in Function.forward,
+ *     block_extractor.py:21, local_attn_reshape.py:18, resample2d.py:19); the library never
+ *     allocates, never synchronises, never touches the host copy of the data;
+ *   - `stream` is a hipStream_t (NULL = the null stream); kernels are enqueued asynchronously
+ *     on it, the way the reference enqueues on the current torch stream
+ *     (block_extractor_kernel.cu:197);
+ *   - return 0 on success, a negative gfla_status otherwise (the reference returns 1 always and
+ *     swallows launch errors, block_extractor_cuda.cc:11, block_extractor_kernel.cu:215);
+ *   - suffix = storage type: _f32, _f64 (the two types the reference dispatches,
+ *     AT_DISPATCH_FLOATING_TYPES) and _bf16 (new; forward only, fp32 arithmetic inside).
+ *     bf16 buffers are raw uint16_t bit patterns.
+ */
+#ifndef GFLA_HIP_H_
+#define GFLA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gfla_status {
+  GFLA_OK = 0,
+  GFLA_ERR_NULL_POINTER = -1,   /* a required buffer is NULL */
+  GFLA_ERR_BAD_SHAPE = -2,      /* non-positive dimension, kernel_size < 1, C != k*k ... */
+  GFLA_ERR_UNSUPPORTED = -3,    /* shape is valid but outside what the kernels index */
+  GFLA_ERR_LAUNCH = -4          /* hipGetLastError() reported a failure after the launch */
+} gfla_status;
+
+typedef void *gfla_stream_t; /* hipStream_t */
+
+int gfla_abi_version(void);
+const char *gfla_status_string(int status);
+
+/* Tuning knobs (benchmarks/tests only; defaults are chosen per shape).  Returns the old value.
+ *   key 0: block_extractor forward variant   (0 auto, 1 row kernel, 2 LDS-plane kernel)
+ *   key 1: channels-per-thread override      (0 auto)
+ *   key 2: block_extractor backward variant  (0 auto, 1 global atomics, 2 LDS-plane)
+ *   key 3: aggregate forward variant         (0 auto, 1 global gather, 2 LDS-plane)            */
+int gfla_set_tuning(int key, int value);
+
+/* ---- block_extractor ---------------------------------------------------------------------
+ * forward : replaces block_extractor_cuda.forward(source, flow_field, output, kernel_size)
+ *           (block_extractor_cuda.cc:5-12 -> block_extractor_kernel.cu:20-85)
+ *   source (B,C,Hs,Ws)   flow (B,2,Hf,Wf): channel 0 = x, 1 = y displacement in source pixels
+ *   out    (B,C,k*Hf,k*Wf), fully overwritten (need not be zeroed)
+ * backward: replaces block_extractor_cuda.backward(source, flow_field, grad_output, grad_source,
+ *           grad_flow_field, kernel_size) (block_extractor_cuda.cc:14-25 -> .cu:89-170)
+ *   grad_source (B,C,Hs,Ws) is ACCUMULATED into and must arrive zeroed, as in the reference
+ *   (block_extractor.py:35); grad_flow (B,2,Hf,Wf) likewise.  Either may be NULL to skip that
+ *   gradient (the reference always computes both).                                             */
+#define GFLA_DECL_BLOCK_EXTRACTOR(SFX, T)                                                          \
+  int gfla_block_extractor_fwd_##SFX(const T *source, const T *flow, T *out, int64_t B, int64_t C, \
+                                     int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,               \
+                                     int kernel_size, gfla_stream_t stream);
+GFLA_DECL_BLOCK_EXTRACTOR(f32, float)
+GFLA_DECL_BLOCK_EXTRACTOR(f64, double)
+GFLA_DECL_BLOCK_EXTRACTOR(bf16, uint16_t)
+#undef GFLA_DECL_BLOCK_EXTRACTOR
+
+#define GFLA_DECL_BLOCK_EXTRACTOR_BWD(SFX, T)                                                      \
+  int gfla_block_extractor_bwd_##SFX(const T *source, const T *flow, const T *grad_out,            \
+                                     T *grad_source, T *grad_flow, int64_t B, int64_t C,           \
+                                     int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,               \
+                                     int kernel_size, gfla_stream_t stream);
+GFLA_DECL_BLOCK_EXTRACTOR_BWD(f32, float)
+GFLA_DECL_BLOCK_EXTRACTOR_BWD(f64, double)
+#undef GFLA_DECL_BLOCK_EXTRACTOR_BWD
+
+/* ---- local_attn_reshape ------------------------------------------------------------------
+ * forward : replaces local_attn_reshape_cuda.forward(inputs, output, kernel_size)
+ *           (local_attn_reshape_cuda.cc:5-11 -> local_attn_reshape_kernel.cu:20-61)
+ *   in (B,k*k,H,W) -> out (B,1,k*H,k*W): out[b,0,ys*k+i,xs*k+j] = in[b,i*k+j,ys,xs]; bit-exact
+ * backward: replaces local_attn_reshape_cuda.backward(inputs, grad_output, grad_inputs, k)
+ *           (local_attn_reshape_cuda.cc:13-21 -> .cu:65-108); the inverse permutation.
+ *   grad_in is fully OVERWRITTEN (the reference atomically adds into a zeroed buffer; the map
+ *   is a bijection so the result is identical).                                                */
+#define GFLA_DECL_RESHAPE(SFX, T)                                                                  \
+  int gfla_local_attn_reshape_fwd_##SFX(const T *in, T *out, int64_t B, int64_t H, int64_t W,      \
+                                        int kernel_size, gfla_stream_t stream);                    \
+  int gfla_local_attn_reshape_bwd_##SFX(const T *grad_out, T *grad_in, int64_t B, int64_t H,       \
+                                        int64_t W, int kernel_size, gfla_stream_t stream);
+GFLA_DECL_RESHAPE(f32, float)
+GFLA_DECL_RESHAPE(f64, double)
+GFLA_DECL_RESHAPE(bf16, uint16_t)
+#undef GFLA_DECL_RESHAPE
+
+/* ---- resample2d --------------------------------------------------------------------------
+ * forward : replaces resample2d_cuda.forward(input1, input2, output, kernel_size, dilation)
+ *           (resample2d_cuda.cc:6-14 -> resample2d_kernel.cu:20-95)
+ *   in1 (B,C,Hi,Wi)   in2 (B,3,H,W) = (dx, dy, sigma)   out (B,C,H,W), fully overwritten
+ * backward: replaces resample2d_cuda.backward(input1, input2, gradOutput, gradInput1,
+ *           gradInput2, kernel_size, dilation) (resample2d_cuda.cc:16-26 -> .cu:98-202, :204-330)
+ *   grad_in1 (B,C,Hi,Wi) is ACCUMULATED into, must arrive zeroed (resample2d.py:32);
+ *   grad_in2 (B,3,H,W) must arrive zeroed as well.  Either may be NULL.
+ *   trunc_compat != 0 reproduces the reference's `xf - int(xf)` in the input1 gradient
+ *   (resample2d_kernel.cu:137-138); 0 uses floor, which is the true gradient of the forward.    */
+#define GFLA_DECL_RESAMPLE_FWD(SFX, T)                                                             \
+  int gfla_resample2d_fwd_##SFX(const T *in1, const T *in2, T *out, int64_t B, int64_t C,          \
+                                int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size,     \
+                                int dilation, gfla_stream_t stream);
+GFLA_DECL_RESAMPLE_FWD(f32, float)
+GFLA_DECL_RESAMPLE_FWD(f64, double)
+GFLA_DECL_RESAMPLE_FWD(bf16, uint16_t)
+#undef GFLA_DECL_RESAMPLE_FWD
+
+#define GFLA_DECL_RESAMPLE_BWD(SFX, T)                                                             \
+  int gfla_resample2d_bwd_##SFX(const T *in1, const T *in2, const T *grad_out, T *grad_in1,        \
+                                T *grad_in2, int64_t B, int64_t C, int64_t Hi, int64_t Wi,         \
+                                int64_t H, int64_t W, int kernel_size, int dilation,               \
+                                int trunc_compat, gfla_stream_t stream);
+GFLA_DECL_RESAMPLE_BWD(f32, float)
+GFLA_DECL_RESAMPLE_BWD(f64, double)
+#undef GFLA_DECL_RESAMPLE_BWD
+
+/* ---- local-attention softmax + aggregate (fused) -------------------------------------------
+ * Replaces, in ExtractorAttn.forward (base_function.py:804-810), the chain
+ *   Softmax(dim=1) (:803) -> LocalAttnReshape (:808) -> attn * block_source -> avg_pool2d (:809)
+ * together with the block_source extraction that feeds the product (:805), without ever
+ * materialising the (B,C,kH,kW) product:
+ *   out[b,c,y,x] = (1/k^2) * sum_{i,j} a[b,i*k+j,y,x] * bilinear(source[b,c], tap_ij(flow[b,:,y,x]))
+ *   a = softmax over the k*k channel of `logits` if apply_softmax != 0, else `logits` as given
+ *   (ExtractorAttn swaps the softmax for the plain nonlinearity when built with softmax=None,
+ *   base_function.py:794).
+ *   source (B,C,Hs,Ws)  flow (B,2,H,W)  logits (B,k*k,H,W)  out (B,C,H,W)
+ *   attn_out (B,k*k,H,W) optional (NULL to skip): the post-softmax weights, i.e. what
+ *   hook_attn_param returns as attn_param_ (base_function.py:815,818) and what backward needs.
+ * backward: given grad_out (B,C,H,W) and the saved `attn` (post-softmax), produces
+ *   grad_source (B,C,Hs,Ws; accumulated, must arrive zeroed), grad_flow (B,2,H,W; zeroed) and
+ *   grad_logits (B,k*k,H,W; zeroed) -- the gradient w.r.t. the pre-softmax logits when
+ *   apply_softmax != 0, else w.r.t. the weights.  Any of the three may be NULL.                 */
+#define GFLA_DECL_AGGREGATE_FWD(SFX, T)                                                            \
+  int gfla_local_attn_aggregate_fwd_##SFX(const T *source, const T *flow, const T *logits, T *out, \
+                                          T *attn_out, int64_t B, int64_t C, int64_t Hs,           \
+                                          int64_t Ws, int64_t H, int64_t W, int kernel_size,       \
+                                          int apply_softmax, gfla_stream_t stream);
+GFLA_DECL_AGGREGATE_FWD(f32, float)
+GFLA_DECL_AGGREGATE_FWD(f64, double)
+GFLA_DECL_AGGREGATE_FWD(bf16, uint16_t)
+#undef GFLA_DECL_AGGREGATE_FWD
+
+#define GFLA_DECL_AGGREGATE_BWD(SFX, T)                                                            \
+  int gfla_local_attn_aggregate_bwd_##SFX(const T *source, const T *flow, const T *attn,           \
+                                          const T *grad_out, T *grad_source, T *grad_flow,         \
+                                          T *grad_logits, int64_t B, int64_t C, int64_t Hs,        \
+                                          int64_t Ws, int64_t H, int64_t W, int kernel_size,       \
+                                          int apply_softmax, gfla_stream_t stream);
+GFLA_DECL_AGGREGATE_BWD(f32, float)
+GFLA_DECL_AGGREGATE_BWD(f64, double)
+#undef GFLA_DECL_AGGREGATE_BWD
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFLA_HIP_H_ */

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` via gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is visible, e.g. `pytest tests/` on CPU."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import cpu_oracle
+    cpu_oracle.build()
+    return cpu_oracle
+
+
+@pytest.fixture(scope="session")
+def gfla():
+    import global_flow_local_attention_amd as g
+    return g
