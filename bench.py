@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the GFLA feature-warping hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of B synthetic images
+per GPU, forward AND backward, at the feature-map shapes PoseGenerator has for a 256x176 image with
+attn_layer=2,3 / kernel_size 2=5,3=3 (SURVEY.md section 8, table of shapes):
+
+    ExtractorAttn layer 3:  source/target (B,256,32,22), flow (B,2,32,22), k=3
+    ExtractorAttn layer 2:  source/target (B,128,64,44), flow (B,2,64,44), k=5
+       = block_extractor + both FC convolutions + softmax/reshape/aggregate, gradients to
+         source, target, flow and the FC parameters (base_function.py:790-810)
+    Resample2d(4,1,sigma=2) (PerceptualCorrectness, external_function.py:233,274), fwd + bwd:
+       relu4_1-shaped (B,512,32,22) with the layer-3 flow, relu3_1-shaped (B,256,64,44) with the
+       layer-2 flow
+
+The stock convolutions/normalisations of the rest of PoseGenerator are out of scope
+and the reference network code does not exist on the GPU box, so `value` is images/s THROUGH THE
+HOT PATH, not end-to-end generator throughput.  Inputs are resident in HBM before timing starts.
+
+Rank 0 prints ONE JSON line (contract in the task statement) that additionally carries
+  "roofline":     the dominant gfx950 kernel of the step, algorithmic bytes / HIP-event duration
+  "kernels":      the same figure for every C-ABI entry point the step calls
+  "cpu_baseline": the reference composition with the CPU oracle kernels on the host cores,
+                  timed on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import global_flow_local_attention_amd as gfla  # noqa: E402
+from global_flow_local_attention_amd import _lib, dist as gdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+LAYERS = (  # (name, C, H, W, k) for a 256x176 input, layers=3, ngf=64
+    ("attn3", 256, 32, 22, 3),
+    ("attn2", 128, 64, 44, 5),
+)
+VGG = (  # Resample2d call sites of PerceptualCorrectness: (name, C, H, W)
+    ("relu4_1", 512, 32, 22),
+    ("relu3_1", 256, 64, 44),
+)
+
+
+def smooth_flow(B, H, W, device, gen):
+    n = torch.randn(B, 2, H, W, device=device, generator=gen) * 12
+    n = torch.nn.functional.pad(n, (3, 3, 3, 3), mode="replicate")
+    return torch.nn.functional.avg_pool2d(n, 7, 1).contiguous()
+
+
+class HotPath:
+    """Synthetic inputs + modules of one rank."""
+
+    def __init__(self, B, device, seed, modules=None):
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.B, self.device = B, device
+        self.attn, self.inputs, self.vgg = [], [], []
+        torch.manual_seed(1234)  # identical FC parameters on every rank
+        for i, (name, C, H, W, k) in enumerate(LAYERS):
+            mod = modules[i] if modules else gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+            self.attn.append(mod.to(device))
+            src = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
+            tgt = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
+            flow = smooth_flow(B, H, W, device, gen).requires_grad_()
+            self.inputs.append((src, tgt, flow))
+        self.resample = None
+        for (name, C, H, W) in VGG:
+            feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
+            self.vgg.append(feat)
+
+    def params(self):
+        return [p for m in self.attn for p in m.parameters()]
+
+    def step(self, resample, allreduce=True):
+        loss = 0
+        for mod, (src, tgt, flow) in zip(self.attn, self.inputs):
+            out = mod(src, tgt, flow)
+            loss = loss + out.square().mean()
+        for feat, (_, _, flow) in zip(self.vgg, self.inputs):
+            warped = resample(feat, flow)
+            loss = loss + warped.square().mean()
+        for t in [x for tup in self.inputs for x in tup] + self.vgg + self.params():
+            t.grad = None
+        loss.backward()
+        if allreduce:
+            gdist.allreduce_grads(self.params())
+        return loss
+
+
+# ---- algorithmic bytes per C-ABI call (4 bytes per fp32 element) -------
+def algorithmic_bytes(name, a, esz=4):
+    base = name.rsplit("_", 1)[0]
+    if base == "gfla_block_extractor_fwd":
+        B, C, Hs, Ws, Hf, Wf, k = a[3:10]
+        return esz * (B * C * Hs * Ws + 2 * B * Hf * Wf + B * C * k * k * Hf * Wf)
+    if base == "gfla_block_extractor_bwd":
+        B, C, Hs, Ws, Hf, Wf, k = a[5:12]
+        n = B * C * Hs * Ws + 2 * B * Hf * Wf + B * C * k * k * Hf * Wf   # reads
+        if a[3] is not None:
+            n += B * C * Hs * Ws
+        if a[4] is not None:
+            n += 2 * B * Hf * Wf
+        return esz * n
+    if base in ("gfla_local_attn_reshape_fwd", "gfla_local_attn_reshape_bwd"):
+        B, H, W, k = a[2:6]
+        return 2 * esz * B * k * k * H * W
+    if base == "gfla_resample2d_fwd":
+        B, C, Hi, Wi, H, W = a[3:9]
+        return esz * (B * C * Hi * Wi + B * C * H * W + 3 * B * H * W)
+    if base == "gfla_resample2d_bwd":
+        B, C, Hi, Wi, H, W = a[5:11]
+        n = B * C * H * W + 3 * B * H * W
+        if a[3] is not None:
+            n += B * C * Hi * Wi
+        if a[4] is not None:
+            n += B * C * Hi * Wi + 3 * B * H * W
+        return esz * n
+    if base == "gfla_local_attn_aggregate_fwd":
+        B, C, Hs, Ws, H, W, k = a[5:12]
+        n = B * C * Hs * Ws + 2 * B * H * W + B * k * k * H * W + B * C * H * W
+        if a[4] is not None:
+            n += B * k * k * H * W
+        return esz * n
+    if base == "gfla_local_attn_aggregate_bwd":
+        B, C, Hs, Ws, H, W, k = a[7:14]
+        n = B * C * Hs * Ws + 2 * B * H * W + B * k * k * H * W + B * C * H * W
+        n += (B * C * Hs * Ws if a[4] is not None else 0) + (2 * B * H * W if a[5] is not None else 0)
+        n += (B * k * k * H * W if a[6] is not None else 0)
+        return esz * n
+    return 0
+
+
+class KernelTimer:
+    """Brackets every C-ABI call with HIP events on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = _lib.call
+
+        def timed(name, ref_tensor, *args):
+            stream = torch.cuda.current_stream(ref_tensor.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            self._orig(name, ref_tensor, *args)
+            e1.record(stream)
+            plain = tuple(x if isinstance(x, int) else (None if (x is None or x.value is None) else "ptr")
+                          for x in args)
+            self.records.append((name, plain, e0, e1))
+
+        _lib.call = timed  # the op modules look `_lib.call` up at call time
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call = self._orig
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, args, e0, e1 in self.records:
+            key = (name,) + tuple(x for x in args if isinstance(x, int))
+            ent = agg.setdefault(key, {"name": name, "calls": 0, "ms": 0.0, "bytes": algorithmic_bytes(name, args)})
+            ent["calls"] += 1
+            ent["ms"] += e0.elapsed_time(e1)
+        rows = []
+        for key, ent in agg.items():
+            avg_ms = ent["ms"] / ent["calls"]
+            gbs = ent["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            rows.append({"entry": ent["name"], "dims": list(key[1:]), "calls": ent["calls"],
+                         "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ent["ms"], 3),
+                         "alg_MB": round(ent["bytes"] / 1e6, 3), "GBps": round(gbs, 1),
+                         "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference composition on the host cores with the oracle kernels (kind "port")."""
+    from oracle import cpu_modules, cpu_oracle
+    cpu_oracle.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu_oracle.set_threads(cores)
+    b = 1
+    mods = [cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True) for (_, C, _, _, k) in LAYERS]
+    hp = HotPath(b, "cpu", seed=0, modules=mods)
+    res = cpu_modules.Resample2dCPU(4, 1, 2)
+    hp.step(res, allreduce=False)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        hp.step(res, allreduce=False)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) of batch %d of the same workload (reference op-by-op composition, oracle/gfla_oracle.c "
+                      "kernels with OpenMP + torch CPU convolutions), %.1f s" % (n, b, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
+    rank, world, local = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True  # as the reference does (options/base_options.py:83)
+
+    hp = HotPath(args.batch, device, seed=100 + rank)
+    resample = gfla.Resample2d(4, 1, 2)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step(resample)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hp.step(resample)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # instrumented pass: the same K steps with every C-ABI call bracketed by HIP events
+    with KernelTimer() as kt:
+        for _ in range(args.steps):
+            hp.step(resample)
+    rows = kt.summary()
+    dom = rows[0]
+
+    line = {
+        "metric": "images/sec (fwd+bwd) PoseGenerator 256x176 attn_layer=2,3 -- feature-warping hot path",
+        "value": round(args.batch * world * args.steps / elapsed, 2),
+        "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
+                               "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. FC convs, "
+                               "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)",
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world},
+        "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
+                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],
+                     "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"], "traffic": None,
+                     "timing": "HIP events around each C-ABI call on the launch stream, instrumented pass of the same %d steps" % args.steps},
+        "kernels": rows,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

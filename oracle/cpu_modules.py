@@ -1,0 +1,84 @@
+"""TEST INFRASTRUCTURE ONLY -- the reference's module surface on the CPU, backed by the oracle.
+
+The reference has no CPU path (block_extractor.py:23-24 raises), so "the reference on the host
+cores" is the reference's own composition (base_function.py:790-818, resample2d.py:41-53) with the
+oracle's literal kernels underneath.  bench.py's cpu_baseline leg and the tests use these; the
+product never does.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import cpu_oracle as O
+
+
+class _BlockExtractorCPU(Function):
+    @staticmethod
+    def forward(ctx, source, flow, k):
+        ctx.save_for_backward(source, flow)
+        ctx.k = k
+        return O.block_extractor_fwd(source.contiguous(), flow.contiguous(), k)
+
+    @staticmethod
+    def backward(ctx, g):
+        source, flow = ctx.saved_tensors
+        gs, gf = O.block_extractor_bwd(source.contiguous(), flow.contiguous(), g.contiguous(), ctx.k)
+        return gs, gf, None
+
+
+class _LocalAttnReshapeCPU(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return O.local_attn_reshape_fwd(x.contiguous(), k)
+
+    @staticmethod
+    def backward(ctx, g):
+        return O.local_attn_reshape_bwd(g.contiguous(), ctx.k), None
+
+
+class _Resample2dCPU(Function):
+    @staticmethod
+    def forward(ctx, i1, i2, k, d):
+        ctx.save_for_backward(i1, i2)
+        ctx.k, ctx.d = k, d
+        return O.resample2d_fwd(i1.contiguous(), i2.contiguous(), k, d)
+
+    @staticmethod
+    def backward(ctx, g):
+        i1, i2 = ctx.saved_tensors
+        g1, g2 = O.resample2d_bwd(i1.contiguous(), i2.contiguous(), g.contiguous(), ctx.k, ctx.d, True)
+        return g1, g2, None, None
+
+
+class Resample2dCPU(nn.Module):
+    def __init__(self, kernel_size=2, dilation=1, sigma=5):
+        super().__init__()
+        self.kernel_size, self.dilation, self.sigma = kernel_size, dilation, float(sigma)
+
+    def forward(self, input1, input2):
+        sig = torch.full_like(input2[:, :1], self.sigma)
+        return _Resample2dCPU.apply(input1, torch.cat((input2, sig), 1), self.kernel_size, self.dilation)
+
+
+class ExtractorAttnCPU(nn.Module):
+    """base_function.py:790-810, op by op."""
+
+    def __init__(self, feature_nc, kernel_size=4, nonlinearity=nn.LeakyReLU(), softmax=None):
+        super().__init__()
+        self.kernel_size = kernel_size
+        softmax = nonlinearity if softmax is None else nn.Softmax(dim=1)
+        self.fully_connect_layer = nn.Sequential(
+            nn.Conv2d(2 * feature_nc, 128, kernel_size=kernel_size, stride=kernel_size, padding=0),
+            nonlinearity,
+            nn.Conv2d(128, kernel_size * kernel_size, kernel_size=1, stride=1, padding=0),
+            softmax,)
+
+    def forward(self, source, target, flow_field):
+        k = self.kernel_size
+        block_source = _BlockExtractorCPU.apply(source, flow_field, k)
+        block_target = _BlockExtractorCPU.apply(target, torch.zeros_like(flow_field), k)
+        attn = self.fully_connect_layer(torch.cat((block_target, block_source), 1))
+        attn = _LocalAttnReshapeCPU.apply(attn, k)
+        return F.avg_pool2d(attn * block_source, k, k)

