@@ -307,10 +307,11 @@ def test_config3_size_properties(gfla, oracle):
         for b in (0, B - 1):
             want = oracle.block_extractor_fwd(s[b:b + 1].cpu(), f[b:b + 1].cpu(), k)
             assert_close(o1[b:b + 1].cpu(), want, F32_FWD, "config3 sample %d" % b)
-        # uniform attention + zero flow = k x k box filter with replicate padding
+        # uniform attention (a = 1/k^2) + zero flow = k x k box filter with replicate padding, then
+        # avg_pool2d divides by k^2 once more (base_function.py:809)
         lg = torch.zeros(B, k * k, H, W, device=DEV)
         agg, attn = gfla.LocalAttnAggregateFunction.apply(s, z, lg, k, True)
-        box = F.avg_pool2d(F.pad(s, (k // 2,) * 4, mode="replicate"), k, 1)
+        box = F.avg_pool2d(F.pad(s, (k // 2,) * 4, mode="replicate"), k, 1) / (k * k)
         assert max_abs(agg, box) <= 2e-6 * max(1.0, box.abs().max().item())
         assert torch.allclose(attn.sum(1), torch.ones(B, H, W, device=DEV), atol=1e-6)
         del out, o1, o2

@@ -19,6 +19,6 @@ timeout 600 python tools/opbench.py --iters 20 --out $OUT/opbench.jsonl > $OUT/o
 echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== rocprof"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.log 2>&1); echo "rocprof rc=$?"
-find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.log 2>&1); echo "rocprof rc=$?"
+find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20
 ls $OUT
