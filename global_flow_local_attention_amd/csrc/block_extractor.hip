@@ -15,6 +15,7 @@
 //            instead of C*k^2 colliding atomics per address), grad_source is scattered with
 //            relaxed device-scope float atomics.
 #include "gfla_common.h"
+#include "lds_plane.h"
 
 namespace gfla {
 
@@ -109,6 +110,108 @@ static int launch_fwd_rows(const T *src, const T *flow, T *out, int64_t B, int64
   return launch_status();
 }
 
+// ----------------------------------------------------------------------------------------
+// forward, planes in LDS: workgroup <-> (b, group of G channels[, 1/split of the rows]).
+// The G source planes are read from HBM once (16 B per lane, coalesced) into LDS; every lane then
+// produces V consecutive outputs of one output row per channel: 4 ds_read_b32 + 4 FMA per
+// output, one 16-byte store per channel.  HBM sees only the minimum traffic: source once,
+// output once.
+// ----------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs,
+    int Ws, int Hf, int Wf, int k, int G, int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hs * Ws;
+  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
+  __syncthreads();
+
+  const int Wo = k * Wf, Ho = k * Hf, WG = Wo / V;
+  const int npos = Ho * WG;
+  const int per = (npos + split - 1) / split;
+  const int p_end = min(npos, (sp + 1) * per);
+  const int64_t oplane_sz = (int64_t)Ho * Wo;
+  for (int pos = sp * per + threadIdx.x; pos < p_end; pos += blockDim.x) {
+    const int y = pos / WG;
+    const int x0 = (pos - y * WG) * V;
+    const int yf = y / k;
+    const int oy = (y - yf * k) - k / 2;
+    int off[V][4];
+    A w[V][4];
+    const T *flow_x = flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf;
+    const T *flow_y = flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int x = x0 + e;
+      const int xf = x / k;
+      const int ox = (x - xf * k) - k / 2;
+      const A fy = Num<T>::ld(flow_y + xf) + (A)oy;  // block_extractor_kernel.cu:62-67
+      const A fx = Num<T>::ld(flow_x + xf) + (A)ox;
+      const A dy = fy + (A)yf;
+      const A dx = fx + (A)xf;
+      const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+      const int xL = clampi((int)fdx, 0, Ws - 1);  // :69-76
+      const int xR = clampi((int)(fdx + 1), 0, Ws - 1);
+      const int yT = clampi((int)fdy, 0, Hs - 1);
+      const int yB = clampi((int)(fdy + 1), 0, Hs - 1);
+      const A xL_P = 1 - (dx - fdx), xR_P = dx - fdx;
+      const A yT_P = 1 - (dy - fdy), yB_P = dy - fdy;
+      off[e][0] = yT * Ws + xL;
+      off[e][1] = yT * Ws + xR;
+      off[e][2] = yB * Ws + xL;
+      off[e][3] = yB * Ws + xR;
+      w[e][0] = xL_P * yT_P;
+      w[e][1] = xR_P * yT_P;
+      w[e][2] = xL_P * yB_P;
+      w[e][3] = xR_P * yB_P;
+    }
+    T *orow = out + ((int64_t)b * C + c0) * oplane_sz + (int64_t)y * Wo + x0;
+    const A *pl = planes;
+    for (int c = 0; c < gc; ++c) {
+      Pack<T, V> r;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        A s = w[e][0] * pl[off[e][0]];  // :78-84, same order of accumulation
+        s += w[e][1] * pl[off[e][1]];
+        s += w[e][2] * pl[off[e][2]];
+        s += w[e][3] * pl[off[e][3]];
+        r.v[e] = Num<T>::from(s);
+      }
+      *reinterpret_cast<Pack<T, V> *>(orow) = r;
+      pl += plane_sz;
+      orow += oplane_sz;
+    }
+  }
+}
+
+template <typename T, int V>
+static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                      int64_t Hf, int64_t Wf, int k, hipStream_t stream) {
+  using A = typename Num<T>::acc;
+  const int variant = tuning(0);
+  if (variant != 1) {
+    const int64_t npos = (k * Hf) * ((k * Wf) / V);
+    PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), 1, B, C, npos, true);
+    if (g.G > 0) {
+      const int64_t blocks = B * g.ngroups * g.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      be_fwd_lds_kernel<T, V><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split);
+      return launch_status();
+    }
+  }
+  return launch_fwd_rows<T, V>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+}
+
 template <typename T>
 static int block_extractor_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs,
                                int64_t Ws, int64_t Hf, int64_t Wf, int k, gfla_stream_t stream_) {
@@ -120,10 +223,10 @@ static int block_extractor_fwd(const T *src, const T *flow, T *out, int64_t B, i
   const int64_t Wo = k * Wf;
   const bool aligned = (reinterpret_cast<uintptr_t>(out) % (VMAX * sizeof(T))) == 0;
   if (aligned && Wo % VMAX == 0)
-    return launch_fwd_rows<T, VMAX>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+    return launch_fwd<T, VMAX>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
   if (VMAX == 4 && (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T))) == 0 && Wo % 2 == 0)
-    return launch_fwd_rows<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
-  return launch_fwd_rows<T, 1>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+    return launch_fwd<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
+  return launch_fwd<T, 1>(src, flow, out, B, C, Hs, Ws, Hf, Wf, k, stream);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -252,10 +355,135 @@ __global__ __launch_bounds__(kBlock) void be_bwd_elem_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// backward, planes in LDS: workgroup <-> (b, group of G channels).  grad_source of the group is
+// accumulated with ds_add_f32 in LDS planes and flushed once, coalesced; when d/dflow is wanted the
+// source planes of the group are staged in LDS as well, so the only global traffic is the
+// streaming read of grad_out (the dominant, k^2-amplified tensor) plus one atomic pair per lane
+// and group for d/dflow.
+// ----------------------------------------------------------------------------------------
+template <typename T, int K, bool NEED_SRC, bool NEED_FLOW>
+__global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
+    T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf, int G,
+    int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hs * Ws;
+  A *gplanes = reinterpret_cast<A *>(gfla_smem);                       // [G][plane]  (NEED_SRC)
+  A *splanes = gplanes + (NEED_SRC ? (size_t)G * plane_sz : 0);        // [G][plane]  (NEED_FLOW)
+  if (NEED_SRC) zero_planes<A>(gplanes, gc * plane_sz);
+  if (NEED_FLOW) stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, splanes, gc * plane_sz);
+  __syncthreads();
+
+  const int Wo = K * Wf;
+  const int64_t oplane_sz = (int64_t)K * Hf * Wo;
+  const int npix = Hf * Wf;
+  const int per = (npix + split - 1) / split;
+  const int p_end = min(npix, (sp + 1) * per);
+  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int yf = p / Wf, xf = p - yf * Wf;
+    const A fx0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf);
+    const A fy0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf);
+    // column taps live in registers (the j loop is unrolled); row taps are recomputed per row so
+    // the i loop can stay rolled and only one row of loads is in flight per lane.
+    int xL[K], xR[K];
+    A ax[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:132-136
+      const A fdx = floor_t<A>(dx);
+      xL[t] = clampi((int)fdx, 0, Ws - 1);
+      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
+      ax[t] = dx - fdx;
+    }
+    A gx_acc = 0, gy_acc = 0;
+    const T *gblk = gout + ((int64_t)b * C + c0) * oplane_sz + (int64_t)(yf * K) * Wo + xf * K;
+    A *gp = gplanes;
+    const A *spl = splanes;
+    for (int c = 0; c < gc; ++c) {
+#pragma unroll 1
+      for (int i = 0; i < K; ++i) {
+        const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+        const A fdy = floor_t<A>(dy);
+        const int yT = clampi((int)fdy, 0, Hs - 1) * Ws;
+        const int yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+        const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+        A gv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) gv[j] = Num<T>::ld(gblk + i * Wo + j);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const A xL_P = 1 - ax[j], xR_P = ax[j];
+          if (NEED_FLOW) {
+            const A vTL = spl[yT + xL[j]], vTR = spl[yT + xR[j]];
+            const A vBL = spl[yB + xL[j]], vBR = spl[yB + xR[j]];
+            gy_acc += gv[j] * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);  // :163-164
+            gx_acc += gv[j] * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+          }
+          if (NEED_SRC) {  // :158-161
+            lds_add(gp + yT + xL[j], gv[j] * xL_P * yT_P);
+            lds_add(gp + yT + xR[j], gv[j] * xR_P * yT_P);
+            lds_add(gp + yB + xL[j], gv[j] * xL_P * yB_P);
+            lds_add(gp + yB + xR[j], gv[j] * xR_P * yB_P);
+          }
+        }
+      }
+      gblk += oplane_sz;
+      gp += plane_sz;
+      spl += plane_sz;
+    }
+    if (NEED_FLOW) {
+      atomic_add(gflow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf, (T)gx_acc);
+      atomic_add(gflow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf, (T)gy_acc);
+    }
+  }
+  if (NEED_SRC) {
+    __syncthreads();
+    flush_planes<T, A>(gsrc + ((int64_t)b * C + c0) * plane_sz, gplanes, gc * plane_sz, split == 1);
+  }
+}
+
+template <typename T, int K>
+static int launch_bwd_lds(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
+                          int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, hipStream_t stream,
+                          bool *done) {
+  using A = typename Num<T>::acc;
+  *done = false;
+  const int nplanes = (gsrc ? 1 : 0) + (gflow ? 1 : 0);
+  PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), nplanes, B, C, Hf * Wf, true);
+  if (g.G == 0) return GFLA_OK;
+  const int64_t blocks = B * g.ngroups * g.split;
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks), blk(kLdsThreads);
+#define GFLA_BE_BWD_LAUNCH(S, F)                                                                       \
+  be_bwd_lds_kernel<T, K, S, F><<<grid, blk, g.lds_bytes, stream>>>(src, flow, gout, gsrc, gflow, (int)C, \
+                                                                   (int)Hs, (int)Ws, (int)Hf, (int)Wf, \
+                                                                   g.G, g.ngroups, g.split)
+  if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true);
+  else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false);
+  else GFLA_BE_BWD_LAUNCH(false, true);
+#undef GFLA_BE_BWD_LAUNCH
+  *done = true;
+  return launch_status();
+}
+
 template <typename T, int K>
 static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
                           int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                           hipStream_t stream) {
+  if (tuning(2) != 1) {
+    bool done = false;
+    int st = launch_bwd_lds<T, K>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
+    if (done || st != GFLA_OK) return st;
+  }
   const int64_t sp_blocks = ceil_div(Hf * Wf, kBlock);
   int cpt = tuning(1) > 0 ? tuning(1) : pick_channels_per_thread(sp_blocks * kBlock, C, B, 16, 2 * kNumCU * kWavesPerCU);
   if (cpt > C) cpt = (int)C;

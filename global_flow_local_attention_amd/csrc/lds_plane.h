@@ -1,0 +1,109 @@
+// "Plane in LDS" building blocks shared by the gather/scatter kernels.
+//
+// Every op on the hot path gathers from (or scatters into) ONE (b,c) feature plane at positions
+// chosen by the flow field.  Planes at the attention layers are small (32x22 .. 64x64 floats =
+// 2.8 .. 16 KB), so a workgroup can hold a GROUP of G whole planes in the CU's 160 KB LDS:
+//   * gathers become ds_read_b32 at 128 B/clk/CU instead of L1/TA-limited global loads, after
+//     ONE coalesced 16-byte-per-lane read of the planes from HBM;
+//   * scatters become ds_add_f32 into the LDS plane followed by ONE coalesced flush, instead of
+//     k^2*4 global atomics per pixel and channel (the reference's decomposition and the reason its
+//     backward kernels run at ~0.5 % of HBM bandwidth).
+// Arbitrary flow needs no special case: the whole plane is resident, clamping is index math.
+// Planes that do not fit (e.g. 256x176) use the global-memory kernels.
+#pragma once
+
+#include "gfla_common.h"
+
+namespace gfla {
+
+constexpr int kLdsBudget = 64 * 1024;  // per workgroup: two workgroups of 512 threads per CU
+constexpr int kLdsThreads = 512;
+
+struct PlaneGeo {
+  int G;        // channels (planes) per workgroup; 0 = does not fit, use the global kernels
+  int ngroups;  // ceil(C / G)
+  int split;    // workgroups sharing one (b, group): each takes 1/split of the positions
+  unsigned lds_bytes;
+};
+
+// plane_elems: elements of one plane; acc_bytes: sizeof(arithmetic type); planes_per_channel: 1
+// (gather-only or scatter-only) or 2 (both); work_items: positions one (b, group) iterates over.
+inline PlaneGeo plane_geometry(int64_t plane_elems, int acc_bytes, int planes_per_channel, int64_t B,
+                               int64_t C, int64_t work_items, bool allow_split) {
+  PlaneGeo g{0, 0, 1, 0};
+  const int64_t per_channel = plane_elems * acc_bytes * planes_per_channel;
+  if (per_channel > kLdsBudget) return g;
+  int64_t G = kLdsBudget / per_channel;
+  if (G > C) G = C;
+  if (tuning(4) > 0 && tuning(4) < G) G = tuning(4);
+  // keep >= 2 workgroups per CU in flight when the batch is small
+  while (G > 1 && B * ceil_div(C, G) < 2 * kNumCU) G = (G + 1) / 2;
+  g.G = (int)G;
+  g.ngroups = (int)ceil_div(C, G);
+  int split = 1;
+  if (allow_split) {
+    const int64_t wgs = B * g.ngroups;
+    while (wgs * split < 4 * kNumCU && work_items / (split * 2) >= 2 * kLdsThreads && split < 64) split *= 2;
+  }
+  if (tuning(5) > 0) split = tuning(5);
+  g.split = split;
+  g.lds_bytes = (unsigned)(G * per_channel);
+  return g;
+}
+
+// global (n contiguous storage elements) -> LDS (arithmetic type), all threads of the block
+template <typename T, typename A>
+__device__ __forceinline__ void stage_planes(const T *__restrict__ g, A *lds, int n) {
+  if constexpr (sizeof(T) == 4 && sizeof(A) == 4) {
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+      const int n4 = n >> 2;
+      const float4 *g4 = reinterpret_cast<const float4 *>(g);
+      float4 *l4 = reinterpret_cast<float4 *>(lds);
+      for (int i = threadIdx.x; i < n4; i += blockDim.x) l4[i] = g4[i];
+      for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) lds[i] = Num<T>::ld(g + i);
+      return;
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = Num<T>::ld(g + i);
+}
+
+template <typename A>
+__device__ __forceinline__ void zero_planes(A *lds, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = 0;
+}
+
+// g[i] += lds[i].  exclusive = this workgroup is the only writer of these planes (plain
+// read-modify-write, coalesced); otherwise device-scope atomics.
+template <typename T, typename A>
+__device__ __forceinline__ void flush_planes(T *__restrict__ g, const A *lds, int n, bool exclusive) {
+  if (exclusive) {
+    if constexpr (sizeof(T) == 4 && sizeof(A) == 4) {
+      if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int n4 = n >> 2;
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        const float4 *l4 = reinterpret_cast<const float4 *>(lds);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+          float4 a = g4[i];
+          const float4 d = l4[i];
+          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+          g4[i] = a;
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + lds[i]);
+        return;
+      }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + lds[i]);
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomic_add(g + i, (T)lds[i]);
+  }
+}
+
+// LDS atomic add without return value (ds_add_f32 / ds_add_f64)
+__device__ __forceinline__ void lds_add(float *p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+}  // namespace gfla

@@ -14,6 +14,7 @@
 // fractional offset, so they read a dense patch), and then walks a chunk of channels doing
 // (k+1)^2 loads + FMAs each.
 #include "gfla_common.h"
+#include "lds_plane.h"
 
 namespace gfla {
 
@@ -251,6 +252,272 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// LDS-plane variants: workgroup <-> (b, group of G channels[, 1/split of the pixels]).  The G source
+// planes are staged in LDS once; every lane then evaluates its pixels for the G channels with
+// ds_read_b32 gathers ((K+1)^2 per output in the dense case).  Backward additionally keeps G gradient
+// planes in LDS (ds_add_f32) and flushes them once.
+// ----------------------------------------------------------------------------------------------
+constexpr int kAggChunk = 4;  // channels whose accumulators one lane keeps in registers at a time
+
+template <typename T, int K>
+__global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ logits,
+    T *__restrict__ out, T *__restrict__ attn_out, int C, int Hs, int Ws, int H, int W,
+    int apply_softmax, int G, int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hs * Ws;
+  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
+  __syncthreads();
+  const int HW = H * W;
+  const int per = (HW + split - 1) / split;
+  const int p_end = min(HW, (sp + 1) * per);
+  const A inv_kk = (A)1 / (A)KK;
+  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int yf = p / W, xf = p - yf * W;
+    A a[KK];
+    const T *lg = logits + (int64_t)b * KK * HW + p;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) a[t] = Num<T>::ld(lg + (int64_t)t * HW);
+    A sm_max = 0, sm_inv = 1;
+    if (apply_softmax) {  // base_function.py:803
+      sm_max = a[0];
+#pragma unroll
+      for (int t = 1; t < KK; ++t) sm_max = fmax(sm_max, a[t]);
+      A ssum = 0;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        a[t] = exp_t<A>(a[t] - sm_max);
+        ssum += a[t];
+      }
+      sm_inv = (A)1 / ssum;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) a[t] *= sm_inv;
+    }
+    if (attn_out && g == 0) {
+      T *ao = attn_out + (int64_t)b * KK * HW + p;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) ao[(int64_t)t * HW] = Num<T>::from(a[t]);
+    }
+    PatchTaps<A, K> tp;
+    tp.init(Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p), Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p), xf,
+            yf, Hs, Ws);
+    T *o = out + ((int64_t)b * C + c0) * HW + p;
+    if (tp.dense) {
+      // Patch rows outermost, channels innermost: only ONE row of the (K+1)x(K+1) coefficient patch
+      // and kAggChunk channel accumulators are live, instead of the whole patch.
+      int col[K + 1];
+#pragma unroll
+      for (int q = 0; q <= K; ++q) col[q] = clampi(tp.x0 + q, 0, Ws - 1);
+      for (int cb = 0; cb < gc; cb += kAggChunk) {
+        A acc[kAggChunk];
+#pragma unroll
+        for (int c = 0; c < kAggChunk; ++c) acc[c] = 0;
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          A Pr[K + 1];
+#pragma unroll
+          for (int q = 0; q <= K; ++q) Pr[q] = 0;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const A xL_P = 1 - tp.ax[j], xR_P = tp.ax[j];
+            A wrow = 0;  // attention mass of tap column j that lands on patch row r
+            if (r < K) wrow += a[r * K + j] * (1 - tp.ay[r]);          // tap row r, top weight
+            if (r > 0) wrow += a[(r - 1) * K + j] * tp.ay[r - 1];       // tap row r-1, bottom weight
+            Pr[j] += wrow * xL_P;
+            Pr[j + 1] += wrow * xR_P;
+          }
+          const int rowoff = clampi(tp.y0 + r, 0, Hs - 1) * Ws;
+#pragma unroll
+          for (int c = 0; c < kAggChunk; ++c) {
+            const A *pl = planes + (size_t)min(cb + c, gc - 1) * plane_sz + rowoff;
+            A v = 0;
+#pragma unroll
+            for (int q = 0; q <= K; ++q) v += Pr[q] * pl[col[q]];
+            acc[c] += v;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < kAggChunk; ++c)
+          if (cb + c < gc) o[(int64_t)(cb + c) * HW] = Num<T>::from(acc[c] * inv_kk);
+      }
+    } else {
+      // Some tap's floor() landed one off the dense patch (a flow value within rounding of an
+      // integer).  Rare: evaluate tap by tap exactly as block_extractor does, with rolled loops that
+      // re-derive a_ij from the logits so this path costs no registers.
+      const A *pl = planes;
+      const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
+      const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+      for (int c = 0; c < gc; ++c) {
+        A acc = 0;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+          const A fdy = floor_t<A>(dy);
+          const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+          const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+#pragma unroll 1
+          for (int j = 0; j < K; ++j) {
+            const A dx = (fx0 + (A)(j - K / 2)) + (A)xf;
+            const A fdx = floor_t<A>(dx);
+            const int xL = clampi((int)fdx, 0, Ws - 1), xR = clampi((int)(fdx + 1), 0, Ws - 1);
+            const A xR_P = dx - fdx, xL_P = 1 - xR_P;
+            A aij = Num<T>::ld(lg + (int64_t)(i * K + j) * HW);
+            if (apply_softmax) aij = exp_t<A>(aij - sm_max) * sm_inv;
+            A v = (xL_P * yT_P) * pl[yT + xL];
+            v += (xR_P * yT_P) * pl[yT + xR];
+            v += (xL_P * yB_P) * pl[yB + xL];
+            v += (xR_P * yB_P) * pl[yB + xR];
+            acc += aij * v;
+          }
+        }
+        *o = Num<T>::from(acc * inv_kk);
+        pl += plane_sz;
+        o += HW;
+      }
+    }
+  }
+}
+
+// Backward, tap rows outermost: for one tap row i a lane keeps K attention weights and K
+// attention-gradient accumulators, walks the G channels of the group, and publishes the row's raw
+// d/d a_ij sums with K coalesced atomics; d/dflow is carried across rows.  The softmax Jacobian is
+// applied afterwards by agg_softmax_bwd_kernel (it needs the sums over ALL channel groups).
+template <typename T, int K, bool NEED_SRC>
+__global__ __launch_bounds__(kLdsThreads) void agg_bwd_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ attn,
+    const T *__restrict__ gout, T *__restrict__ gsrc, T *__restrict__ gflow, T *__restrict__ glogits,
+    int C, int Hs, int Ws, int H, int W, int G, int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hs * Ws;
+  A *splanes = reinterpret_cast<A *>(gfla_smem);  // [G][plane] source values
+  A *gplanes = splanes + (size_t)G * plane_sz;    // [G][plane] grad_source accumulators (NEED_SRC)
+  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, splanes, gc * plane_sz);
+  if (NEED_SRC) zero_planes<A>(gplanes, gc * plane_sz);
+  __syncthreads();
+  const int HW = H * W;
+  const int per = (HW + split - 1) / split;
+  const int p_end = min(HW, (sp + 1) * per);
+  const A inv_kk = (A)1 / (A)KK;
+  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int yf = p / W, xf = p - yf * W;
+    const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
+    const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+    int xL[K], xR[K];
+    A ax[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:62-67
+      const A fdx = floor_t<A>(dx);
+      xL[t] = clampi((int)fdx, 0, Ws - 1);
+      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
+      ax[t] = dx - fdx;
+    }
+    A gx_acc = 0, gy_acc = 0;
+    const T *at = attn + (int64_t)b * KK * HW + p;
+    T *gl = glogits ? glogits + (int64_t)b * KK * HW + p : nullptr;
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+      const A fdy = floor_t<A>(dy);
+      const int yT = clampi((int)fdy, 0, Hs - 1) * Ws;
+      const int yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+      const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+      A a_row[K], ga_row[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        a_row[j] = Num<T>::ld(at + (int64_t)(i * K + j) * HW);
+        ga_row[j] = 0;
+      }
+      const T *gp_out = gout + ((int64_t)b * C + c0) * HW + p;
+      const A *spl = splanes;
+      A *gpl = gplanes;
+      for (int c = 0; c < gc; ++c) {
+        const A go = Num<T>::ld(gp_out) * inv_kk;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const A xL_P = 1 - ax[j], xR_P = ax[j];
+          const A vTL = spl[yT + xL[j]], vTR = spl[yT + xR[j]];
+          const A vBL = spl[yB + xL[j]], vBR = spl[yB + xR[j]];
+          A bs = (xL_P * yT_P) * vTL;
+          bs += (xR_P * yT_P) * vTR;
+          bs += (xL_P * yB_P) * vBL;
+          bs += (xR_P * yB_P) * vBR;
+          ga_row[j] += go * bs;
+          const A gb = go * a_row[j];  // gradient reaching block_source[b,c,yf*K+i,xf*K+j]
+          gy_acc += gb * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
+          gx_acc += gb * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+          if (NEED_SRC) {
+            lds_add(gpl + yT + xL[j], gb * xL_P * yT_P);
+            lds_add(gpl + yT + xR[j], gb * xR_P * yT_P);
+            lds_add(gpl + yB + xL[j], gb * xL_P * yB_P);
+            lds_add(gpl + yB + xR[j], gb * xR_P * yB_P);
+          }
+        }
+        gp_out += HW;
+        spl += plane_sz;
+        gpl += plane_sz;
+      }
+      if (gl) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga_row[j]);
+      }
+    }
+    if (gflow) {
+      atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, (T)gx_acc);
+      atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, (T)gy_acc);
+    }
+  }
+  if (NEED_SRC) {
+    __syncthreads();
+    flush_planes<T, A>(gsrc + ((int64_t)b * C + c0) * plane_sz, gplanes, gc * plane_sz, split == 1);
+  }
+}
+
+// In place: glogits holds ga (d/d a_ij); turn it into d/d logit_ij = a_ij * (ga_ij - sum_mn a_mn ga_mn).
+template <typename T, int K>
+__global__ __launch_bounds__(kBlock) void agg_softmax_bwd_kernel(const T *__restrict__ attn,
+                                                                T *__restrict__ glogits, int64_t n, int HW) {
+  using A = typename Num<T>::acc;
+  constexpr int KK = K * K;
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // over (b, p)
+  if (idx >= n) return;
+  const int64_t b = idx / HW;
+  const int p = (int)(idx - b * HW);
+  const T *at = attn + b * KK * HW + p;
+  T *gl = glogits + b * KK * HW + p;
+  A a[KK], ga[KK];
+  A dot = 0;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    a[t] = Num<T>::ld(at + (int64_t)t * HW);
+    ga[t] = Num<T>::ld(gl + (int64_t)t * HW);
+    dot += a[t] * ga[t];
+  }
+#pragma unroll
+  for (int t = 0; t < KK; ++t) gl[(int64_t)t * HW] = Num<T>::from(a[t] * (ga[t] - dot));
+}
+
 struct AggGeo {
   int cpt, ncg, sp_blocks;
   int64_t blocks;
@@ -291,6 +558,17 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
   int st = agg_check(B, C, Hs, Ws, H, W, k);
   if (st != GFLA_OK) return st;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  using A = typename Num<T>::acc;
+  if (tuning(3) != 1) {
+    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), 1, B, C, H * W, true);
+    if (pg.G > 0) {
+      const int64_t blocks = B * pg.ngroups * pg.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      GFLA_K_SWITCH(k, agg_fwd_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                           src, flow, logits, out, attn_out, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, pg.G, pg.ngroups, pg.split));
+      return launch_status();
+    }
+  }
   AggGeo g = agg_geometry(B, C, H, W, 32, 4 * kNumCU * kWavesPerCU);
   if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   GFLA_K_SWITCH(k, agg_fwd_kernel<T, K><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(src, flow, logits, out, attn_out, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, g.cpt, g.ncg, g.sp_blocks));
@@ -306,6 +584,29 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
   if (st != GFLA_OK) return st;
   if (!gsrc && !gflow && !glogits) return GFLA_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  using A = typename Num<T>::acc;
+  if (tuning(3) != 1) {
+    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), gsrc ? 2 : 1, B, C, H * W, true);
+    if (pg.G > 0) {
+      const int64_t blocks = B * pg.ngroups * pg.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      if (gsrc) {
+        GFLA_K_SWITCH(k, agg_bwd_lds_kernel<T, K, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                             src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, pg.G, pg.ngroups, pg.split));
+      } else {
+        GFLA_K_SWITCH(k, agg_bwd_lds_kernel<T, K, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                             src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, pg.G, pg.ngroups, pg.split));
+      }
+      st = launch_status();
+      if (st == GFLA_OK && glogits && sm) {
+        const int64_t n = B * H * W;
+        GFLA_K_SWITCH(k, agg_softmax_bwd_kernel<T, K><<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, stream>>>(
+                             attn, glogits, n, (int)(H * W)));
+        st = launch_status();
+      }
+      return st;
+    }
+  }
   AggGeo g = agg_geometry(B, C, H, W, 32, 2 * kNumCU * kWavesPerCU);
   if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   GFLA_K_SWITCH(k, agg_bwd_kernel<T, K><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, g.cpt, g.ncg, g.sp_blocks));

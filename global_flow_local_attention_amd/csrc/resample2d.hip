@@ -11,6 +11,7 @@
 // produces dx, dy and sigma in one pass over the channels (the reference runs three threads per
 // pixel, each looping over all channels twice).
 #include "gfla_common.h"
+#include "lds_plane.h"
 
 namespace gfla {
 
@@ -26,6 +27,18 @@ template <typename A>
 __device__ __forceinline__ A gauss(A dist, A sigma) {
   return (A)exp(safe_div<A>(-dist * dist, 2 * sigma * sigma));  // :75-78
 }
+// Single-precision exp for the LDS-plane kernels, where the weights are recomputed once per channel
+// GROUP and eight double-precision exps per lane would dominate the instruction stream.  expf is
+// within 1 ulp of the reference's (float)exp((double)q): a 6e-8 relative change of a weight.
+template <typename A>
+__device__ __forceinline__ A gauss_fast(A dist, A sigma) {
+  return gauss<A>(dist, sigma);
+}
+template <>
+__device__ __forceinline__ float gauss_fast<float>(float dist, float sigma) {
+  const float num = -dist * dist, den = 2 * sigma * sigma;
+  return (den == 0) ? (float)exp((double)num / kEps) : expf(num / den);
+}
 
 // Per-pixel state shared by all three kernels: tap row/column offsets and 1-D weights.
 template <typename A, int KH>
@@ -38,6 +51,7 @@ struct Taps {
 
   // floor_alpha: fractional part from floor (forward, input2 gradient) or from int() truncation
   // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
+  template <bool FAST = false>
   __device__ __forceinline__ void init(A dx, A dy, A sg, int x, int y, int Hi, int Wi, int dil,
                                        bool trunc_alpha) {
     sigma = sg;
@@ -56,10 +70,10 @@ struct Taps {
       xRd[f] = (A)((1. + f) * dil) - alpha;
       yTd[f] = (A)(f * dil) + beta;
       yBd[f] = (A)((1. + f) * dil) - beta;
-      xLp[f] = gauss<A>(xLd[f], sg);
-      xRp[f] = gauss<A>(xRd[f], sg);
-      yTp[f] = gauss<A>(yTd[f], sg);
-      yBp[f] = gauss<A>(yBd[f], sg);
+      xLp[f] = FAST ? gauss_fast<A>(xLd[f], sg) : gauss<A>(xLd[f], sg);
+      xRp[f] = FAST ? gauss_fast<A>(xRd[f], sg) : gauss<A>(xRd[f], sg);
+      yTp[f] = FAST ? gauss_fast<A>(yTd[f], sg) : gauss<A>(yTd[f], sg);
+      yBp[f] = FAST ? gauss_fast<A>(yBd[f], sg) : gauss<A>(yBd[f], sg);
     }
 #pragma unroll
     for (int fy = 0; fy < KH; ++fy)
@@ -82,55 +96,42 @@ __device__ __forceinline__ bool decode(int sp_blocks, int ncg, int HW, int W, in
   return true;
 }
 
-// ---- forward ---------------------------------------------------------------------------
-template <typename T, int KH>
-__global__ __launch_bounds__(kBlock) void rs_fwd_kernel(const T *__restrict__ in1,
-                                                       const T *__restrict__ in2, T *__restrict__ out,
-                                                       int C, int Hi, int Wi, int H, int W, int dil,
-                                                       int cpt, int ncg, int sp_blocks) {
-  using A = typename Num<T>::acc;
-  int b, cg, y, x;
-  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
-  const int64_t HW = (int64_t)H * W;
-  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
-  Taps<A, KH> t;
-  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+// Where a plane lives decides how it is added to: device-scope atomics in global memory, ds_add in LDS.
+struct GlobalPlane {
+  template <typename P, typename A>
+  static __device__ __forceinline__ void add(P *p, A v) { atomic_add(p, (P)v); }
+};
+struct LdsPlane {
+  template <typename P, typename A>
+  static __device__ __forceinline__ void add(P *p, A v) { lds_add(p, (P)v); }
+};
 
-  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
-  const int64_t plane_sz = (int64_t)Hi * Wi;
-  const T *plane = in1 + ((int64_t)b * C + c0) * plane_sz;
-  T *o = out + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
-  for (int c = c0; c < c1; ++c) {
+// ---- per-pixel bodies, shared by the global-memory and the LDS-plane kernels ------------------
+// forward: `nch` channels, planes `plane_sz` apart starting at `plane`, outputs `ostride` apart.
+template <typename T, typename PT, int KH, typename A>
+__device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__restrict__ plane, int64_t plane_sz,
+                                             T *__restrict__ o, int64_t ostride, int nch) {
+  for (int c = 0; c < nch; ++c) {
     A val = 0;
 #pragma unroll
     for (int fy = 0; fy < KH; ++fy)
 #pragma unroll
-      for (int fx = 0; fx < KH; ++fx) {  // :85-88
-        val += (t.yTp[fy] * t.xLp[fx]) * Num<T>::ld(plane + t.yT[fy] + t.xL[fx]);
-        val += (t.yTp[fy] * t.xRp[fx]) * Num<T>::ld(plane + t.yT[fy] + t.xR[fx]);
-        val += (t.yBp[fy] * t.xLp[fx]) * Num<T>::ld(plane + t.yB[fy] + t.xL[fx]);
-        val += (t.yBp[fy] * t.xRp[fx]) * Num<T>::ld(plane + t.yB[fy] + t.xR[fx]);
+      for (int fx = 0; fx < KH; ++fx) {  // resample2d_kernel.cu:85-88
+        val += (t.yTp[fy] * t.xLp[fx]) * Num<PT>::ld(plane + t.yT[fy] + t.xL[fx]);
+        val += (t.yTp[fy] * t.xRp[fx]) * Num<PT>::ld(plane + t.yT[fy] + t.xR[fx]);
+        val += (t.yBp[fy] * t.xLp[fx]) * Num<PT>::ld(plane + t.yB[fy] + t.xL[fx]);
+        val += (t.yBp[fy] * t.xRp[fx]) * Num<PT>::ld(plane + t.yB[fy] + t.xR[fx]);
       }
     *o = Num<T>::from((A)safe_div<A>(val, t.sum));  // :93
     plane += plane_sz;
-    o += HW;
+    o += ostride;
   }
 }
 
-// ---- d/d input1 --------------------------------------------------------------------------
-template <typename T, int KH>
-__global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ in2,
-                                                        const T *__restrict__ gout, T *__restrict__ gin1,
-                                                        int C, int Hi, int Wi, int H, int W, int dil,
-                                                        int trunc, int cpt, int ncg, int sp_blocks) {
-  using A = typename Num<T>::acc;
-  int b, cg, y, x;
-  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
-  const int64_t HW = (int64_t)H * W;
-  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
-  Taps<A, KH> t;
-  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
-  // normalised tap weights, SAFE_DIV(yP*xP, sum) (:195-198)
+// d/d input1: scatter SAFE_DIV(w, sum) * grad_out into the gradient planes (:195-198)
+template <typename T, typename PT, int KH, typename A, typename Where>
+__device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__restrict__ g, int64_t gstride,
+                                              PT *__restrict__ gplane, int64_t plane_sz, int nch) {
   A q[KH][KH][4];
 #pragma unroll
   for (int fy = 0; fy < KH; ++fy)
@@ -141,50 +142,37 @@ __global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ i
       q[fy][fx][2] = (A)safe_div<A>(t.yBp[fy] * t.xLp[fx], t.sum);
       q[fy][fx][3] = (A)safe_div<A>(t.yBp[fy] * t.xRp[fx], t.sum);
     }
-  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
-  const int64_t plane_sz = (int64_t)Hi * Wi;
-  T *gplane = gin1 + ((int64_t)b * C + c0) * plane_sz;
-  const T *g = gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
-  for (int c = c0; c < c1; ++c) {
+  for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
 #pragma unroll
     for (int fy = 0; fy < KH; ++fy)
 #pragma unroll
       for (int fx = 0; fx < KH; ++fx) {
-        atomic_add(gplane + t.yT[fy] + t.xL[fx], q[fy][fx][0] * go);
-        atomic_add(gplane + t.yT[fy] + t.xR[fx], q[fy][fx][1] * go);
-        atomic_add(gplane + t.yB[fy] + t.xL[fx], q[fy][fx][2] * go);
-        atomic_add(gplane + t.yB[fy] + t.xR[fx], q[fy][fx][3] * go);
+        Where::add(gplane + t.yT[fy] + t.xL[fx], q[fy][fx][0] * go);
+        Where::add(gplane + t.yT[fy] + t.xR[fx], q[fy][fx][1] * go);
+        Where::add(gplane + t.yB[fy] + t.xL[fx], q[fy][fx][2] * go);
+        Where::add(gplane + t.yB[fy] + t.xR[fx], q[fy][fx][3] * go);
       }
     gplane += plane_sz;
-    g += HW;
+    g += gstride;
   }
 }
 
-// ---- d/d input2 = d/d(dx, dy, sigma) --------------------------------------------------------
-template <typename T, int KH>
-__global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ in1,
-                                                        const T *__restrict__ in2,
-                                                        const T *__restrict__ gout, T *__restrict__ gin2,
-                                                        int C, int Hi, int Wi, int H, int W, int dil,
-                                                        int cpt, int ncg, int sp_blocks) {
-  using A = typename Num<T>::acc;
-  int b, cg, y, x;
-  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
-  const int64_t HW = (int64_t)H * W;
-  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
-  Taps<A, KH> t;
-  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+// d/d input2 = d/d(dx, dy, sigma) for `nch` channels; returns the three partial results (linear in
+// the channel sums, so channel chunks combine by addition).
+template <typename T, typename PT, int KH, typename A>
+__device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__restrict__ plane, int64_t plane_sz,
+                                              const T *__restrict__ g, int64_t gstride, int nch, A &rx, A &ry,
+                                              A &rs) {
   const A sg = t.sigma;
-  // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (:273-292)
+  // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (resample2d_kernel.cu:273-292)
   const A d2 = -sg * sg, d3 = sg * sg * sg;
   const A inv2 = (d2 == 0) ? (A)(1.0 / kEps) : (A)1 / d2;
   const A inv3 = (d3 == 0) ? (A)(1.0 / kEps) : (A)1 / d3;
-
   // per-tap weight and the three derivative coefficients; taps ordered TL,TR,BL,BR
   A wt[KH][KH][4], cx[KH][KH][4], cy[KH][KH][4], cs[KH][KH][4];
-  A sgx = 0, sgy = 0, sgs = 0;  // "sumgrad" per derivative, counted once (the reference counts it C
-                                // times and divides by C, :277,318)
+  A sgx = 0, sgy = 0, sgs = 0;  // "sumgrad", counted once (the reference counts it C times and
+                                // divides by C, :277,318)
 #pragma unroll
   for (int fy = 0; fy < KH; ++fy)
 #pragma unroll
@@ -198,31 +186,23 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ i
           const int q = r * 2 + s;
           const A w = yp[r] * xp[s];
           wt[fy][fx][q] = w;
-          cx[fy][fx][q] = (s == 0 ? xd[s] : -xd[s]) * w * inv2;           // :273-277
-          cy[fy][fx][q] = (r == 0 ? yd[r] : -yd[r]) * w * inv2;           // :280-284
-          cs[fy][fx][q] = (yd[r] * yd[r] + xd[s] * xd[s]) * w * inv3;     // :287-291
+          cx[fy][fx][q] = (s == 0 ? xd[s] : -xd[s]) * w * inv2;        // :273-277
+          cy[fy][fx][q] = (r == 0 ? yd[r] : -yd[r]) * w * inv2;        // :280-284
+          cs[fy][fx][q] = (yd[r] * yd[r] + xd[s] * xd[s]) * w * inv3;  // :287-291
           sgx += cx[fy][fx][q];
           sgy += cy[fy][fx][q];
           sgs += cs[fy][fx][q];
         }
     }
-
-  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
-  const int64_t plane_sz = (int64_t)Hi * Wi;
-  const T *plane = in1 + ((int64_t)b * C + c0) * plane_sz;
-  const T *g = gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x;
   A g1x = 0, g1y = 0, g1s = 0, S = 0;
-  for (int c = c0; c < c1; ++c) {
+  for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
 #pragma unroll
     for (int fy = 0; fy < KH; ++fy)
 #pragma unroll
       for (int fx = 0; fx < KH; ++fx) {
-        const A p0 = go * Num<T>::ld(plane + t.yT[fy] + t.xL[fx]);
-        const A p1 = go * Num<T>::ld(plane + t.yT[fy] + t.xR[fx]);
-        const A p2 = go * Num<T>::ld(plane + t.yB[fy] + t.xL[fx]);
-        const A p3 = go * Num<T>::ld(plane + t.yB[fy] + t.xR[fx]);
-        const A pv[4] = {p0, p1, p2, p3};
+        const A pv[4] = {go * Num<PT>::ld(plane + t.yT[fy] + t.xL[fx]), go * Num<PT>::ld(plane + t.yT[fy] + t.xR[fx]),
+                         go * Num<PT>::ld(plane + t.yB[fy] + t.xL[fx]), go * Num<PT>::ld(plane + t.yB[fy] + t.xR[fx])};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           g1x += cx[fy][fx][q] * pv[q];
@@ -232,25 +212,133 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ i
         }
       }
     plane += plane_sz;
-    g += HW;
+    g += gstride;
   }
-  // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S; linear in (grad1, S) so channel
-  // chunks combine by addition.
+  // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S
   const A sum = t.sum, sum2 = t.sum * t.sum;
   const A is = (sum == 0) ? (A)(1.0 / kEps) : (A)1 / sum;
   const A is2 = (sum2 == 0) ? (A)(1.0 / kEps) : (A)1 / sum2;
-  const A rx = g1x * is - (sgx * S) * is2;
-  const A ry = g1y * is - (sgy * S) * is2;
-  const A rs = g1s * is - (sgs * S) * is2;
+  rx = g1x * is - (sgx * S) * is2;
+  ry = g1y * is - (sgy * S) * is2;
+  rs = g1s * is - (sgs * S) * is2;
+}
+
+// ---- global-memory kernels: thread <-> (b, channel chunk, pixel) ---------------------------------
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_fwd_kernel(const T *__restrict__ in1,
+                                                       const T *__restrict__ in2, T *__restrict__ out,
+                                                       int C, int Hi, int Wi, int H, int W, int dil,
+                                                       int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  rs_fwd_pixel<T, T, KH, A>(t, in1 + ((int64_t)b * C + c0) * plane_sz, plane_sz,
+                            out + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW, c1 - c0);
+}
+
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ in2,
+                                                        const T *__restrict__ gout, T *__restrict__ gin1,
+                                                        int C, int Hi, int Wi, int H, int W, int dil,
+                                                        int trunc, int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
+                                          gin1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, c1 - c0);
+}
+
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ in1,
+                                                        const T *__restrict__ in2,
+                                                        const T *__restrict__ gout, T *__restrict__ gin2,
+                                                        int C, int Hi, int Wi, int H, int W, int dil,
+                                                        int cpt, int ncg, int sp_blocks) {
+  using A = typename Num<T>::acc;
+  int b, cg, y, x;
+  if (!decode(sp_blocks, ncg, H * W, W, b, cg, y, x)) return;
+  const int64_t HW = (int64_t)H * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
+  Taps<A, KH> t;
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  A rx, ry, rs;
+  rs_bwd2_pixel<T, T, KH, A>(t, in1 + ((int64_t)b * C + c0) * plane_sz, plane_sz,
+                             gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW, c1 - c0, rx, ry, rs);
   T *o = gin2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
   if (ncg == 1) {
     o[0] = Num<T>::from(Num<T>::ld(o) + rx);
     o[HW] = Num<T>::from(Num<T>::ld(o + HW) + ry);
     o[2 * HW] = Num<T>::from(Num<T>::ld(o + 2 * HW) + rs);
   } else {
-    atomic_add(o, rx);
-    atomic_add(o + HW, ry);
-    atomic_add(o + 2 * HW, rs);
+    atomic_add(o, (T)rx);
+    atomic_add(o + HW, (T)ry);
+    atomic_add(o + 2 * HW, (T)rs);
+  }
+}
+
+// ---- LDS-plane kernels: workgroup <-> (b, group of G channels[, 1/split of the pixels]) ----------
+// MODE 0 forward (source planes staged), 1 d/d input1 (gradient planes accumulated in LDS, flushed
+// once), 2 d/d input2 (source planes staged, three atomics per lane and group).
+template <typename T, int KH, int MODE>
+__global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
+                                                            const T *__restrict__ gout, T *__restrict__ outp,
+                                                            int C, int Hi, int Wi, int H, int W, int dil,
+                                                            int trunc, int G, int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hi * Wi;
+  if constexpr (MODE == 1)
+    zero_planes<A>(planes, gc * plane_sz);
+  else
+    stage_planes<T, A>(in1 + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
+  __syncthreads();
+  const int HW = H * W;
+  const int per = (HW + split - 1) / split;
+  const int p_end = min(HW, (sp + 1) * per);
+  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const T *i2 = in2 + (int64_t)b * 3 * HW + p;
+    Taps<A, KH> t;
+    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
+                          MODE == 1 && trunc != 0);
+    if constexpr (MODE == 0) {
+      rs_fwd_pixel<T, A, KH, A>(t, planes, plane_sz, outp + ((int64_t)b * C + c0) * HW + p, HW, gc);
+    } else if constexpr (MODE == 1) {
+      rs_bwd1_pixel<T, A, KH, A, LdsPlane>(t, gout + ((int64_t)b * C + c0) * HW + p, HW, planes, plane_sz, gc);
+    } else {
+      A rx, ry, rs;
+      rs_bwd2_pixel<T, A, KH, A>(t, planes, plane_sz, gout + ((int64_t)b * C + c0) * HW + p, HW, gc, rx, ry, rs);
+      T *o = outp + (int64_t)b * 3 * HW + p;
+      atomic_add(o, (T)rx);
+      atomic_add(o + HW, (T)ry);
+      atomic_add(o + 2 * HW, (T)rs);
+    }
+  }
+  if constexpr (MODE == 1) {
+    __syncthreads();
+    flush_planes<T, A>(outp + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz, split == 1);
   }
 }
 
@@ -294,6 +382,17 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   if (st != GFLA_OK) return st;
   if (!out) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  using A = typename Num<T>::acc;
+  if (tuning(6) != 1) {
+    PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), 1, B, C, H * W, true);
+    if (pg.G > 0) {
+      const int64_t blocks = B * pg.ngroups * pg.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 0><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                                in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split));
+      return launch_status();
+    }
+  }
   Geo g = geometry(B, C, H, W, 16, 4 * kNumCU * kWavesPerCU);
   if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   GFLA_KH_SWITCH(k / 2, rs_fwd_kernel<T, KH><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(in1, in2, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, g.cpt, g.ncg, g.sp_blocks));
@@ -308,6 +407,24 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
   if (st != GFLA_OK) return st;
   if (!gout) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  using A = typename Num<T>::acc;
+  PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), 1, B, C, H * W, true);
+  if (tuning(6) != 1 && pg.G > 0) {
+    const int64_t blocks = B * pg.ngroups * pg.split;
+    if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+    if (gin1) {
+      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 1><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg.G, pg.ngroups, pg.split));
+      st = launch_status();
+      if (st != GFLA_OK) return st;
+    }
+    if (gin2) {
+      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 2><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg.G, pg.ngroups, pg.split));
+      st = launch_status();
+    }
+    return st;
+  }
   if (gin1) {
     Geo g = geometry(B, C, H, W, 16, 4 * kNumCU * kWavesPerCU);
     if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;

@@ -52,10 +52,13 @@ int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
 /* Tuning knobs (benchmarks/tests only; defaults are chosen per shape).  Returns the old value.
- *   key 0: block_extractor forward variant   (0 auto, 1 row kernel, 2 LDS-plane kernel)
- *   key 1: channels-per-thread override      (0 auto)
- *   key 2: block_extractor backward variant  (0 auto, 1 global atomics, 2 LDS-plane)
- *   key 3: aggregate forward variant         (0 auto, 1 global gather, 2 LDS-plane)            */
+ *   key 0: block_extractor forward   0 auto (planes in LDS when they fit), 1 force global-gather kernel
+ *   key 1: channels per thread of the global kernels (0 auto)
+ *   key 2: block_extractor backward  0 auto, 1 force global-atomics kernel
+ *   key 3: aggregate fwd/bwd         0 auto, 1 force global kernels
+ *   key 4: cap on G, the channel planes one workgroup keeps in LDS (0 auto)
+ *   key 5: split, workgroups sharing one (b, channel group) (0 auto)
+ *   key 6: resample2d fwd/bwd        0 auto, 1 force global kernels                              */
 int gfla_set_tuning(int key, int value);
 
 /* ---- block_extractor ---------------------------------------------------------------------

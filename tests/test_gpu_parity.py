@@ -28,6 +28,18 @@ def tol(dtype, grad=False):
     return F32_GRAD if grad else F32_FWD
 
 
+@pytest.fixture(params=["lds", "global"], autouse=True)
+def kernel_variant(request, gfla):
+    """Every test runs twice: default dispatch (planes in LDS where they fit) and with the
+    global-memory kernels forced (tuning keys 0,2,3,6 of include/gfla_hip.h)."""
+    force = 1 if request.param == "global" else 0
+    for key in (0, 2, 3, 6):
+        gfla.set_tuning(key, force)
+    yield request.param
+    for key in (0, 2, 3, 6):
+        gfla.set_tuning(key, 0)
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _native_library_is_loaded(gfla):
     from global_flow_local_attention_amd import _lib

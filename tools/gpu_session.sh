@@ -11,14 +11,16 @@ echo "== env" | tee $OUT/env.txt
 echo "== golden"
 timeout 300 python tests/golden/make_ref_golden.py $OUT/ref_golden.npz > $OUT/golden.log 2>&1; echo "golden rc=$?"
 echo "== pytest gpu"
-timeout 900 python -m pytest tests -m gpu -q --maxfail=25 -x --timeout=600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 $OUT/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q --maxfail=40 --timeout=600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | tail -45
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log
+echo "== diag conv"
+timeout 300 python tools/diag_conv.py > $OUT/diag_conv.log 2>&1; tail -12 $OUT/diag_conv.log
 echo "== opbench"
 timeout 600 python tools/opbench.py --iters 20 --out $OUT/opbench.jsonl > $OUT/opbench.log 2>&1; echo "opbench rc=$?"; tail -5 $OUT/opbench.log
 echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== rocprof"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.log 2>&1); echo "rocprof rc=$?"
-find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20
+find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20; cat $OUT/*kernel_stats.csv 2>/dev/null | head -30 | cut -c1-220
 ls $OUT
