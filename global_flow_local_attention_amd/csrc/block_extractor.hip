@@ -13,9 +13,9 @@
 //  backward  one lane owns one flow pixel and a chunk of channels: d/dflow is reduced in
 //            registers over the k^2 taps and the channel chunk (1 atomic per lane per component
 //            instead of C*k^2 colliding atomics per address), grad_source is scattered with
-//            relaxed device-scope float atomics.
+//            double-precision LDS planes (ds_add_f64) flushed once, or relaxed device-scope float atomics when the plane does not fit.
 #include "gfla_common.h"
-#include "lds_plane.h"
+#include "be_bwd_lds.h"
 
 namespace gfla {
 
@@ -200,7 +200,7 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
   const int variant = tuning(0);
   if (variant != 1) {
     const int64_t npos = (k * Hf) * ((k * Wf) / V);
-    PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), 1, B, C, npos, true);
+    PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), B, C, npos, true);
     if (g.G > 0) {
       const int64_t blocks = B * g.ngroups * g.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -355,133 +355,13 @@ __global__ __launch_bounds__(kBlock) void be_bwd_elem_kernel(
   }
 }
 
-// ----------------------------------------------------------------------------------------
-// backward, planes in LDS: workgroup <-> (b, group of G channels).  grad_source of the group is
-// accumulated with ds_add_f32 in LDS planes and flushed once, coalesced; when d/dflow is wanted the
-// source planes of the group are staged in LDS as well, so the only global traffic is the
-// streaming read of grad_out (the dominant, k^2-amplified tensor) plus one atomic pair per lane
-// and group for d/dflow.
-// ----------------------------------------------------------------------------------------
-template <typename T, int K, bool NEED_SRC, bool NEED_FLOW>
-__global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
-    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf, int G,
-    int ngroups, int split) {
-  using A = typename Num<T>::acc;
-  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  int bid = blockIdx.x;
-  const int sp = bid % split;
-  bid /= split;
-  const int g = bid % ngroups;
-  const int b = bid / ngroups;
-  const int c0 = g * G;
-  const int gc = min(G, C - c0);
-  const int plane_sz = Hs * Ws;
-  A *gplanes = reinterpret_cast<A *>(gfla_smem);                       // [G][plane]  (NEED_SRC)
-  A *splanes = gplanes + (NEED_SRC ? (size_t)G * plane_sz : 0);        // [G][plane]  (NEED_FLOW)
-  if (NEED_SRC) zero_planes<A>(gplanes, gc * plane_sz);
-  if (NEED_FLOW) stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, splanes, gc * plane_sz);
-  __syncthreads();
-
-  const int Wo = K * Wf;
-  const int64_t oplane_sz = (int64_t)K * Hf * Wo;
-  const int npix = Hf * Wf;
-  const int per = (npix + split - 1) / split;
-  const int p_end = min(npix, (sp + 1) * per);
-  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
-    const int yf = p / Wf, xf = p - yf * Wf;
-    const A fx0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf);
-    const A fy0 = Num<T>::ld(flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf);
-    // column taps live in registers (the j loop is unrolled); row taps are recomputed per row so
-    // the i loop can stay rolled and only one row of loads is in flight per lane.
-    int xL[K], xR[K];
-    A ax[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:132-136
-      const A fdx = floor_t<A>(dx);
-      xL[t] = clampi((int)fdx, 0, Ws - 1);
-      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
-      ax[t] = dx - fdx;
-    }
-    A gx_acc = 0, gy_acc = 0;
-    const T *gblk = gout + ((int64_t)b * C + c0) * oplane_sz + (int64_t)(yf * K) * Wo + xf * K;
-    A *gp = gplanes;
-    const A *spl = splanes;
-    for (int c = 0; c < gc; ++c) {
-#pragma unroll 1
-      for (int i = 0; i < K; ++i) {
-        const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
-        const A fdy = floor_t<A>(dy);
-        const int yT = clampi((int)fdy, 0, Hs - 1) * Ws;
-        const int yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
-        const A yB_P = dy - fdy, yT_P = 1 - yB_P;
-        A gv[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) gv[j] = Num<T>::ld(gblk + i * Wo + j);
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const A xL_P = 1 - ax[j], xR_P = ax[j];
-          if (NEED_FLOW) {
-            const A vTL = spl[yT + xL[j]], vTR = spl[yT + xR[j]];
-            const A vBL = spl[yB + xL[j]], vBR = spl[yB + xR[j]];
-            gy_acc += gv[j] * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);  // :163-164
-            gx_acc += gv[j] * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
-          }
-          if (NEED_SRC) {  // :158-161
-            lds_add(gp + yT + xL[j], gv[j] * xL_P * yT_P);
-            lds_add(gp + yT + xR[j], gv[j] * xR_P * yT_P);
-            lds_add(gp + yB + xL[j], gv[j] * xL_P * yB_P);
-            lds_add(gp + yB + xR[j], gv[j] * xR_P * yB_P);
-          }
-        }
-      }
-      gblk += oplane_sz;
-      gp += plane_sz;
-      spl += plane_sz;
-    }
-    if (NEED_FLOW) {
-      atomic_add(gflow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf + xf, (T)gx_acc);
-      atomic_add(gflow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf + xf, (T)gy_acc);
-    }
-  }
-  if (NEED_SRC) {
-    __syncthreads();
-    flush_planes<T, A>(gsrc + ((int64_t)b * C + c0) * plane_sz, gplanes, gc * plane_sz, split == 1);
-  }
-}
-
-template <typename T, int K>
-static int launch_bwd_lds(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
-                          int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, hipStream_t stream,
-                          bool *done) {
-  using A = typename Num<T>::acc;
-  *done = false;
-  const int nplanes = (gsrc ? 1 : 0) + (gflow ? 1 : 0);
-  PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), nplanes, B, C, Hf * Wf, true);
-  if (g.G == 0) return GFLA_OK;
-  const int64_t blocks = B * g.ngroups * g.split;
-  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)blocks), blk(kLdsThreads);
-#define GFLA_BE_BWD_LAUNCH(S, F)                                                                       \
-  be_bwd_lds_kernel<T, K, S, F><<<grid, blk, g.lds_bytes, stream>>>(src, flow, gout, gsrc, gflow, (int)C, \
-                                                                   (int)Hs, (int)Ws, (int)Hf, (int)Wf, \
-                                                                   g.G, g.ngroups, g.split)
-  if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true);
-  else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false);
-  else GFLA_BE_BWD_LAUNCH(false, true);
-#undef GFLA_BE_BWD_LAUNCH
-  *done = true;
-  return launch_status();
-}
-
 template <typename T, int K>
 static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
                           int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                           hipStream_t stream) {
   if (tuning(2) != 1) {
     bool done = false;
-    int st = launch_bwd_lds<T, K>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
+    int st = launch_be_bwd_lds<T, K>(src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
     if (done || st != GFLA_OK) return st;
   }
   const int64_t sp_blocks = ceil_div(Hf * Wf, kBlock);

@@ -5,8 +5,8 @@
 // 2.8 .. 16 KB), so a workgroup can hold a GROUP of G whole planes in the CU's 160 KB LDS:
 //   * gathers become ds_read_b32 at 128 B/clk/CU instead of L1/TA-limited global loads, after
 //     ONE coalesced 16-byte-per-lane read of the planes from HBM;
-//   * scatters become ds_add_f32 into the LDS plane followed by ONE coalesced flush, instead of
-//     k^2*4 global atomics per pixel and channel (the reference's decomposition and the reason its
+//   * scatters become ds_add_f64 into a double-precision LDS plane followed by ONE coalesced flush,
+//     instead of k^2*4 global atomics per pixel and channel (the reference's decomposition and the reason its
 //     backward kernels run at ~0.5 % of HBM bandwidth).
 // Arbitrary flow needs no special case: the whole plane is resident, clamping is index math.
 // Planes that do not fit (e.g. 256x176) use the global-memory kernels.
@@ -19,6 +19,16 @@ namespace gfla {
 constexpr int kLdsBudget = 64 * 1024;  // per workgroup: two workgroups of 512 threads per CU
 constexpr int kLdsThreads = 512;
 
+// LDS atomic add without return value.  Measured on MI355X (profiles/r1_ubench_lds_atomics.txt):
+// ds_add_f64 runs at 3.2-3.9 lanes/clk/CU, ds_add_f32 at 0.33 -- a 10x gap -- so every scatter
+// accumulator plane in LDS is DOUBLE, whatever the tensor type.  As a bonus the sum is (almost)
+// order-independent: float gradients come out bit-reproducible run to run in practice, unlike the
+// reference's float atomics.
+using lds_acc_t = double;
+__device__ __forceinline__ void lds_add(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct PlaneGeo {
   int G;        // channels (planes) per workgroup; 0 = does not fit, use the global kernels
   int ngroups;  // ceil(C / G)
@@ -26,12 +36,13 @@ struct PlaneGeo {
   unsigned lds_bytes;
 };
 
-// plane_elems: elements of one plane; acc_bytes: sizeof(arithmetic type); planes_per_channel: 1
-// (gather-only or scatter-only) or 2 (both); work_items: positions one (b, group) iterates over.
-inline PlaneGeo plane_geometry(int64_t plane_elems, int acc_bytes, int planes_per_channel, int64_t B,
-                               int64_t C, int64_t work_items, bool allow_split) {
+// plane_elems: elements of one plane; bytes_per_elem: LDS bytes one channel needs per plane element
+// (sizeof(arithmetic type) for a gather plane, 8 for a scatter plane, their sum for both);
+// work_items: positions one (b, group) iterates over.
+inline PlaneGeo plane_geometry(int64_t plane_elems, int bytes_per_elem, int64_t B, int64_t C,
+                               int64_t work_items, bool allow_split) {
   PlaneGeo g{0, 0, 1, 0};
-  const int64_t per_channel = plane_elems * acc_bytes * planes_per_channel;
+  const int64_t per_channel = plane_elems * bytes_per_elem;
   if (per_channel > kLdsBudget) return g;
   int64_t G = kLdsBudget / per_channel;
   if (G > C) G = C;
@@ -74,36 +85,28 @@ __device__ __forceinline__ void zero_planes(A *lds, int n) {
 
 // g[i] += lds[i].  exclusive = this workgroup is the only writer of these planes (plain
 // read-modify-write, coalesced); otherwise device-scope atomics.
-template <typename T, typename A>
-__device__ __forceinline__ void flush_planes(T *__restrict__ g, const A *lds, int n, bool exclusive) {
+template <typename T>
+__device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t *lds, int n, bool exclusive) {
+  using A = typename Num<T>::acc;
   if (exclusive) {
-    if constexpr (sizeof(T) == 4 && sizeof(A) == 4) {
+    if constexpr (sizeof(T) == 4) {
       if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
         const int n4 = n >> 2;
         float4 *g4 = reinterpret_cast<float4 *>(g);
-        const float4 *l4 = reinterpret_cast<const float4 *>(lds);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
           float4 a = g4[i];
-          const float4 d = l4[i];
-          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+          const lds_acc_t *d = lds + 4 * i;
+          a.x += (float)d[0]; a.y += (float)d[1]; a.z += (float)d[2]; a.w += (float)d[3];
           g4[i] = a;
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + lds[i]);
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)lds[i]);
         return;
       }
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + lds[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)lds[i]);
   } else {
     for (int i = threadIdx.x; i < n; i += blockDim.x) atomic_add(g + i, (T)lds[i]);
   }
-}
-
-// LDS atomic add without return value (ds_add_f32 / ds_add_f64)
-__device__ __forceinline__ void lds_add(float *p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_add(double *p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 }  // namespace gfla

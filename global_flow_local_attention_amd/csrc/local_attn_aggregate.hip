@@ -14,7 +14,7 @@
 // fractional offset, so they read a dense patch), and then walks a chunk of channels doing
 // (k+1)^2 loads + FMAs each.
 #include "gfla_common.h"
-#include "lds_plane.h"
+#include "be_bwd_lds.h"
 
 namespace gfla {
 
@@ -390,107 +390,113 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
   }
 }
 
-// Backward, tap rows outermost: for one tap row i a lane keeps K attention weights and K
-// attention-gradient accumulators, walks the G channels of the group, and publishes the row's raw
-// d/d a_ij sums with K coalesced atomics; d/dflow is carried across rows.  The softmax Jacobian is
-// applied afterwards by agg_softmax_bwd_kernel (it needs the sums over ALL channel groups).
-template <typename T, int K, bool NEED_SRC>
-__global__ __launch_bounds__(kLdsThreads) void agg_bwd_lds_kernel(
-    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ attn,
-    const T *__restrict__ gout, T *__restrict__ gsrc, T *__restrict__ gflow, T *__restrict__ glogits,
-    int C, int Hs, int Ws, int H, int W, int G, int ngroups, int split) {
+// d/d a_ij (the attention gradient before the softmax Jacobian):
+//     ga[b,ij,p] = (1/K^2) * sum_c grad_out[b,c,p] * block_source_ij[b,c,p]
+// workgroup <-> (b, channel super-group, tile of blockDim pixels); lane <-> ONE pixel, K*K register
+// accumulators.  The workgroup walks its channels in sub-groups of G planes staged in LDS; the
+// (K+1)x(K+1) source patch of the pixel is read row by row (ds_read_b32) and reused by the four taps
+// that share each element.  One coalesced atomic per (ij, super-group) publishes the sums; the
+// softmax Jacobian needs the totals over ALL channels and is applied by agg_softmax_bwd_kernel.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void agg_ga_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
+    T *__restrict__ glogits, int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
   int bid = blockIdx.x;
-  const int sp = bid % split;
-  bid /= split;
-  const int g = bid % ngroups;
-  const int b = bid / ngroups;
-  const int c0 = g * G;
-  const int gc = min(G, C - c0);
-  const int plane_sz = Hs * Ws;
-  A *splanes = reinterpret_cast<A *>(gfla_smem);  // [G][plane] source values
-  A *gplanes = splanes + (size_t)G * plane_sz;    // [G][plane] grad_source accumulators (NEED_SRC)
-  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, splanes, gc * plane_sz);
-  if (NEED_SRC) zero_planes<A>(gplanes, gc * plane_sz);
-  __syncthreads();
+  const int tile = bid % ntiles;
+  bid /= ntiles;
+  const int sg = bid % nsuper;
+  const int b = bid / nsuper;
   const int HW = H * W;
-  const int per = (HW + split - 1) / split;
-  const int p_end = min(HW, (sp + 1) * per);
+  const int plane_sz = Hs * Ws;
+  const int p = tile * blockDim.x + threadIdx.x;
+  const bool active = p < HW;
+  const int yf = active ? p / W : 0, xf = active ? p - yf * W : 0;
+  const int pc = active ? p : 0;
+  const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + pc);
+  const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + pc);
+  PatchTaps<A, K> tp;
+  tp.init(fx0, fy0, xf, yf, Hs, Ws);
+  int col[K + 1];
+#pragma unroll
+  for (int q = 0; q <= K; ++q) col[q] = clampi(tp.x0 + q, 0, Ws - 1);
+  A ga[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) ga[t] = 0;
   const A inv_kk = (A)1 / (A)KK;
-  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
-    const int yf = p / W, xf = p - yf * W;
-    const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
-    const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
-    int xL[K], xR[K];
-    A ax[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:62-67
-      const A fdx = floor_t<A>(dx);
-      xL[t] = clampi((int)fdx, 0, Ws - 1);
-      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
-      ax[t] = dx - fdx;
-    }
-    A gx_acc = 0, gy_acc = 0;
-    const T *at = attn + (int64_t)b * KK * HW + p;
-    T *gl = glogits ? glogits + (int64_t)b * KK * HW + p : nullptr;
-#pragma unroll 1
-    for (int i = 0; i < K; ++i) {
-      const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
-      const A fdy = floor_t<A>(dy);
-      const int yT = clampi((int)fdy, 0, Hs - 1) * Ws;
-      const int yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
-      const A yB_P = dy - fdy, yT_P = 1 - yB_P;
-      A a_row[K], ga_row[K];
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        a_row[j] = Num<T>::ld(at + (int64_t)(i * K + j) * HW);
-        ga_row[j] = 0;
-      }
-      const T *gp_out = gout + ((int64_t)b * C + c0) * HW + p;
-      const A *spl = splanes;
-      A *gpl = gplanes;
+  const int cs0 = sg * CS;
+  const int cs1 = min(C, cs0 + CS);
+  T *gl = glogits + (int64_t)b * KK * HW + pc;
+  for (int cb = cs0; cb < cs1; cb += G) {
+    const int gc = min(G, cs1 - cb);
+    __syncthreads();  // previous sub-group fully consumed
+    stage_planes<T, A>(src + ((int64_t)b * C + cb) * plane_sz, planes, gc * plane_sz);
+    __syncthreads();
+    if (!active) continue;
+    const T *go_p = gout + ((int64_t)b * C + cb) * HW + p;
+    if (tp.dense) {
       for (int c = 0; c < gc; ++c) {
-        const A go = Num<T>::ld(gp_out) * inv_kk;
+        const A go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
+        const A *pl = planes + (size_t)c * plane_sz;
+        A vA[K + 1];
+        {
+          const int off = clampi(tp.y0, 0, Hs - 1) * Ws;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const A xL_P = 1 - ax[j], xR_P = ax[j];
-          const A vTL = spl[yT + xL[j]], vTR = spl[yT + xR[j]];
-          const A vBL = spl[yB + xL[j]], vBR = spl[yB + xR[j]];
-          A bs = (xL_P * yT_P) * vTL;
-          bs += (xR_P * yT_P) * vTR;
-          bs += (xL_P * yB_P) * vBL;
-          bs += (xR_P * yB_P) * vBR;
-          ga_row[j] += go * bs;
-          const A gb = go * a_row[j];  // gradient reaching block_source[b,c,yf*K+i,xf*K+j]
-          gy_acc += gb * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
-          gx_acc += gb * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
-          if (NEED_SRC) {
-            lds_add(gpl + yT + xL[j], gb * xL_P * yT_P);
-            lds_add(gpl + yT + xR[j], gb * xR_P * yT_P);
-            lds_add(gpl + yB + xL[j], gb * xL_P * yB_P);
-            lds_add(gpl + yB + xR[j], gb * xR_P * yB_P);
+          for (int q = 0; q <= K; ++q) vA[q] = pl[off + col[q]];
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          const int off = clampi(tp.y0 + i + 1, 0, Hs - 1) * Ws;
+          A vB[K + 1];
+#pragma unroll
+          for (int q = 0; q <= K; ++q) vB[q] = pl[off + col[q]];
+          const A yT_P = 1 - tp.ay[i], yB_P = tp.ay[i];
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const A xL_P = 1 - tp.ax[j], xR_P = tp.ax[j];
+            A bs = (xL_P * yT_P) * vA[j];  // block_extractor_kernel.cu:78-84
+            bs += (xR_P * yT_P) * vA[j + 1];
+            bs += (xL_P * yB_P) * vB[j];
+            bs += (xR_P * yB_P) * vB[j + 1];
+            ga[i * K + j] += go * bs;
+          }
+#pragma unroll
+          for (int q = 0; q <= K; ++q) vA[q] = vB[q];
+        }
+      }
+    } else {
+      // rare (a tap within rounding of an integer): tap by tap, published directly
+      for (int c = 0; c < gc; ++c) {
+        const A go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
+        const A *pl = planes + (size_t)c * plane_sz;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+          const A fdy = floor_t<A>(dy);
+          const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+          const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+#pragma unroll 1
+          for (int j = 0; j < K; ++j) {
+            const A dx = (fx0 + (A)(j - K / 2)) + (A)xf;
+            const A fdx = floor_t<A>(dx);
+            const int xL = clampi((int)fdx, 0, Ws - 1), xR = clampi((int)(fdx + 1), 0, Ws - 1);
+            const A xR_P = dx - fdx, xL_P = 1 - xR_P;
+            A bs = (xL_P * yT_P) * pl[yT + xL];
+            bs += (xR_P * yT_P) * pl[yT + xR];
+            bs += (xL_P * yB_P) * pl[yB + xL];
+            bs += (xR_P * yB_P) * pl[yB + xR];
+            atomic_add(gl + (int64_t)(i * K + j) * HW, (T)(go * bs));
           }
         }
-        gp_out += HW;
-        spl += plane_sz;
-        gpl += plane_sz;
       }
-      if (gl) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga_row[j]);
-      }
-    }
-    if (gflow) {
-      atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, (T)gx_acc);
-      atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, (T)gy_acc);
     }
   }
-  if (NEED_SRC) {
-    __syncthreads();
-    flush_planes<T, A>(gsrc + ((int64_t)b * C + c0) * plane_sz, gplanes, gc * plane_sz, split == 1);
+  if (active && tp.dense) {
+#pragma unroll
+    for (int t = 0; t < KK; ++t) atomic_add(gl + (int64_t)t * HW, (T)ga[t]);
   }
 }
 
@@ -560,7 +566,7 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   if (tuning(3) != 1) {
-    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), 1, B, C, H * W, true);
+    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), B, C, H * W, true);
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -585,27 +591,39 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
   if (!gsrc && !gflow && !glogits) return GFLA_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
-  if (tuning(3) != 1) {
-    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), gsrc ? 2 : 1, B, C, H * W, true);
-    if (pg.G > 0) {
-      const int64_t blocks = B * pg.ngroups * pg.split;
+  if (tuning(3) != 1 && Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) <= kLdsBudget) {
+    // (1) grad_source + grad_flow: block_extractor backward of the factored gradient a_ij*g_c/k^2
+    if (gsrc || gflow) {
+      bool done = false;
+      GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(src, flow, gout, attn, gsrc, gflow, B, C, Hs, Ws, H, W, stream, &done));
+      if (st != GFLA_OK) return st;
+      if (!done) return GFLA_ERR_UNSUPPORTED;
+    }
+    // (2) d/d a_ij, then (3) the softmax Jacobian in place
+    if (glogits) {
+      const int threads = 256;
+      const int64_t ntiles = ceil_div(H * W, threads);
+      int64_t G = kLdsBudget / (Hs * Ws * (int64_t)sizeof(A));
+      if (G > C) G = C;
+      int64_t nsuper = 1;  // split the channels until the launch has >= 4 workgroups per CU
+      while (B * ntiles * nsuper < 4 * kNumCU && nsuper * 2 * G <= C) nsuper *= 2;
+      const int64_t CS = ceil_div(C, nsuper);
+      nsuper = ceil_div(C, CS);
+      if (G > CS) G = CS;
+      const int64_t blocks = B * nsuper * ntiles;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      if (gsrc) {
-        GFLA_K_SWITCH(k, agg_bwd_lds_kernel<T, K, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                             src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, pg.G, pg.ngroups, pg.split));
-      } else {
-        GFLA_K_SWITCH(k, agg_bwd_lds_kernel<T, K, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                             src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, pg.G, pg.ngroups, pg.split));
-      }
+      const unsigned lds = (unsigned)(G * Hs * Ws * sizeof(A));
+      GFLA_K_SWITCH(k, agg_ga_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(threads), lds, stream>>>(
+                           src, flow, gout, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, (int)G, (int)nsuper, (int)CS, (int)ntiles));
       st = launch_status();
-      if (st == GFLA_OK && glogits && sm) {
+      if (st == GFLA_OK && sm) {
         const int64_t n = B * H * W;
         GFLA_K_SWITCH(k, agg_softmax_bwd_kernel<T, K><<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, stream>>>(
                              attn, glogits, n, (int)(H * W)));
         st = launch_status();
       }
-      return st;
     }
+    return st;
   }
   AggGeo g = agg_geometry(B, C, H, W, 32, 2 * kNumCU * kWavesPerCU);
   if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;

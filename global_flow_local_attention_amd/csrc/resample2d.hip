@@ -11,6 +11,8 @@
 // produces dx, dy and sigma in one pass over the channels (the reference runs three threads per
 // pixel, each looping over all channels twice).
 #include "gfla_common.h"
+#include <type_traits>
+
 #include "lds_plane.h"
 
 namespace gfla {
@@ -299,8 +301,9 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
                                                             int C, int Hi, int Wi, int H, int W, int dil,
                                                             int trunc, int G, int ngroups, int split) {
   using A = typename Num<T>::acc;
+  using PT = typename std::conditional<MODE == 1, lds_acc_t, A>::type;  // scatter planes are double
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  A *planes = reinterpret_cast<A *>(gfla_smem);
+  PT *planes = reinterpret_cast<PT *>(gfla_smem);
   int bid = blockIdx.x;
   const int sp = bid % split;
   bid /= split;
@@ -310,9 +313,9 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   const int gc = min(G, C - c0);
   const int plane_sz = Hi * Wi;
   if constexpr (MODE == 1)
-    zero_planes<A>(planes, gc * plane_sz);
+    zero_planes<PT>(planes, gc * plane_sz);
   else
-    stage_planes<T, A>(in1 + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
+    stage_planes<T, PT>(in1 + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
   __syncthreads();
   const int HW = H * W;
   const int per = (HW + split - 1) / split;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     if constexpr (MODE == 0) {
       rs_fwd_pixel<T, A, KH, A>(t, planes, plane_sz, outp + ((int64_t)b * C + c0) * HW + p, HW, gc);
     } else if constexpr (MODE == 1) {
-      rs_bwd1_pixel<T, A, KH, A, LdsPlane>(t, gout + ((int64_t)b * C + c0) * HW + p, HW, planes, plane_sz, gc);
+      rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, gout + ((int64_t)b * C + c0) * HW + p, HW, planes, plane_sz, gc);
     } else {
       A rx, ry, rs;
       rs_bwd2_pixel<T, A, KH, A>(t, planes, plane_sz, gout + ((int64_t)b * C + c0) * HW + p, HW, gc, rx, ry, rs);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   }
   if constexpr (MODE == 1) {
     __syncthreads();
-    flush_planes<T, A>(outp + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz, split == 1);
+    flush_planes<T>(outp + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz, split == 1);
   }
 }
 
@@ -384,7 +387,7 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   if (tuning(6) != 1) {
-    PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), 1, B, C, H * W, true);
+    PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), B, C, H * W, true);
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -408,19 +411,22 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
   if (!gout) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
-  PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), 1, B, C, H * W, true);
-  if (tuning(6) != 1 && pg.G > 0) {
-    const int64_t blocks = B * pg.ngroups * pg.split;
-    if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  PlaneGeo pg1 = plane_geometry(Hi * Wi, sizeof(lds_acc_t), B, C, H * W, true);  // double scatter planes
+  PlaneGeo pg2 = plane_geometry(Hi * Wi, sizeof(A), B, C, H * W, true);          // gather planes
+  if (tuning(6) != 1 && pg1.G > 0 && pg2.G > 0) {
     if (gin1) {
-      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 1><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg.G, pg.ngroups, pg.split));
+      const int64_t blocks = B * pg1.ngroups * pg1.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 1><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(
+                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split));
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
     if (gin2) {
-      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 2><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg.G, pg.ngroups, pg.split));
+      const int64_t blocks = B * pg2.ngroups * pg2.split;
+      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 2><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(
+                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split));
       st = launch_status();
     }
     return st;

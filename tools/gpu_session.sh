@@ -14,8 +14,8 @@ echo "== pytest gpu"
 timeout 900 python -m pytest tests -m gpu -q --maxfail=40 --timeout=600 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | tail -45
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log
-echo "== diag conv"
-timeout 300 python tools/diag_conv.py > $OUT/diag_conv.log 2>&1; tail -12 $OUT/diag_conv.log
+echo "== diag conv (skipped)"
+true
 echo "== opbench"
 timeout 600 python tools/opbench.py --iters 20 --out $OUT/opbench.jsonl > $OUT/opbench.log 2>&1; echo "opbench rc=$?"; tail -5 $OUT/opbench.log
 echo "== bench"
