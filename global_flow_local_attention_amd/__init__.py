@@ -8,8 +8,8 @@ from ._lib import build, exported_symbols, set_tuning  # noqa: F401
 from .block_extractor import BlockExtractor, BlockExtractorFunction  # noqa: F401
 from .local_attn_reshape import LocalAttnReshape, LocalAttnReshapeFunction  # noqa: F401
 from .resample2d import Resample2d, Resample2dFunction  # noqa: F401
-from .extractor_attn import (ExtractorAttn, LocalAttnAggregateFunction,  # noqa: F401
-                             patch_reference_extractor_attn)
+from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn,  # noqa: F401
+                             LocalAttnAggregateFunction, patch_reference_extractor_attn)
 from .install import install  # noqa: F401
 
 __version__ = "0.1.0"

@@ -20,6 +20,8 @@ _i64, _int, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 _SIGNATURES = {
     "gfla_block_extractor_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _ptr],
     "gfla_block_extractor_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _ptr],
+    "gfla_block_extractor_unfold_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _ptr],
+    "gfla_block_extractor_unfold_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _ptr],
     "gfla_local_attn_reshape_fwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
     "gfla_local_attn_reshape_bwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
     "gfla_resample2d_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _int, _ptr],
@@ -27,12 +29,13 @@ _SIGNATURES = {
     "gfla_local_attn_aggregate_fwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
 }
-_FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_resample2d_bwd", "gfla_local_attn_aggregate_bwd"}
+_FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
+                  "gfla_local_attn_aggregate_bwd"}
 
 
 def exported_symbols():
     """Every symbol include/gfla_hip.h declares."""
-    names = ["gfla_abi_version", "gfla_status_string", "gfla_set_tuning"]
+    names = ["gfla_abi_version", "gfla_status_string", "gfla_set_tuning", "gfla_unfold_supported"]
     for base in _SIGNATURES:
         for sfx in ("f32", "f64", "bf16"):
             if sfx == "bf16" and base in _FWD_ONLY_BF16:
@@ -61,6 +64,7 @@ def lib():
         handle.gfla_status_string.restype = ctypes.c_char_p
         handle.gfla_status_string.argtypes = [_int]
         handle.gfla_set_tuning.argtypes = [_int, _int]
+        handle.gfla_unfold_supported.argtypes = [_i64, _i64, _int, _int]
         for base, args in _SIGNATURES.items():
             for sfx in ("f32", "f64", "bf16"):
                 if sfx == "bf16" and base in _FWD_ONLY_BF16:
@@ -102,6 +106,10 @@ def call(name, ref_tensor, *args):
         status = fn(*args, stream)
     if status != 0:
         raise RuntimeError("%s failed: %s (status %d)" % (name, lib().gfla_status_string(status).decode(), status))
+
+
+def unfold_supported(Hs, Ws, k, elem_size):
+    return bool(lib().gfla_unfold_supported(int(Hs), int(Ws), int(k), int(elem_size)))
 
 
 def set_tuning(key, value):

@@ -15,7 +15,11 @@
 namespace gfla {
 
 // Gradient reaching block_source[b, c, yf*K+i, xf*K+j] for j = 0..K-1 of tap row i.
-template <typename T, int K, bool ATTN>
+// MODE 0: gout is the reference-layout tensor (B,C,K*Hf,K*Wf)
+// MODE 1: gout is (B,C,Hf,Wf) and the gradient is attn[b,ij,p] * gout[b,c,p] / K^2 (never materialised)
+// MODE 2: gout is in "unfold" layout (B, C*K*K, Hf, Wf), channel index c*K*K + i*K + j
+constexpr int kGoutTensor = 0, kGoutAttn = 1, kGoutUnfold = 2;
+template <typename T, int K, int MODE>
 struct GoutRow {
   using A = typename Num<T>::acc;
   // tensor form: base = &gout[b, c0, yf*K, xf*K], row pitch Wo, channel pitch K*Hf*Wo
@@ -28,10 +32,14 @@ struct GoutRow {
   A inv_kk;
 
   __device__ __forceinline__ void load(int c, int i, A (&g)[K]) const {
-    if constexpr (ATTN) {
+    if constexpr (MODE == kGoutAttn) {
       const A go = Num<T>::ld(base + (int64_t)c * cstride) * inv_kk;
 #pragma unroll
       for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(attn_p + (int64_t)(i * K + j) * HW) * go;
+    } else if constexpr (MODE == kGoutUnfold) {
+      const T *r = base + ((int64_t)c * K * K + i * K) * HW;
+#pragma unroll
+      for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(r + (int64_t)j * HW);
     } else {
       const T *r = base + (int64_t)c * cstride + (int64_t)i * pitch;
 #pragma unroll
@@ -40,7 +48,7 @@ struct GoutRow {
   }
 };
 
-template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, bool ATTN>
+template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     const T *__restrict__ attn, T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws,
@@ -88,11 +96,16 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
       ax[t] = dx - fdx;
     }
-    GoutRow<T, K, ATTN> gr;
-    if constexpr (ATTN) {
+    GoutRow<T, K, MODE> gr;
+    if constexpr (MODE == kGoutAttn) {
       gr.base = gout + ((int64_t)b * C + c0) * HW + p;
       gr.attn_p = attn + (int64_t)b * K * K * HW + p;
       gr.cstride = HW;
+      gr.pitch = 0;
+    } else if constexpr (MODE == kGoutUnfold) {
+      gr.base = gout + ((int64_t)b * C + c0) * K * K * HW + p;
+      gr.attn_p = nullptr;
+      gr.cstride = 0;
       gr.pitch = 0;
     } else {
       gr.base = gout + ((int64_t)b * C + c0) * ((int64_t)K * Hf * Wo) + (int64_t)(yf * K) * Wo + xf * K;
@@ -206,11 +219,11 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
   }
 }
 
-// Launch helper.  attn == nullptr: gout is the (B,C,K*Hf,K*Wf) tensor; otherwise gout is (B,C,Hf,Wf)
-// and the gradient is attn[b,ij,p] * gout[b,c,p] / K^2.  *done = false when the planes do not fit.
+// Launch helper.  mode = kGoutTensor / kGoutAttn / kGoutUnfold (see GoutRow).  *done = false when the
+// planes do not fit in LDS.
 template <typename T, int K>
-static int launch_be_bwd_lds(const T *src, const T *flow, const T *gout, const T *attn, T *gsrc, T *gflow,
-                             int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gout, const T *attn, T *gsrc,
+                             T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                              hipStream_t stream, bool *done) {
   using A = typename Num<T>::acc;
   *done = false;
@@ -223,14 +236,18 @@ static int launch_be_bwd_lds(const T *src, const T *flow, const T *gout, const T
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
   be_bwd_lds_kernel<T, K, S, F, AT><<<grid, blk, g.lds_bytes, stream>>>(                             \
       src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split)
-  if (attn) {
-    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, true);
-    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, true);
-    else GFLA_BE_BWD_LAUNCH(false, true, true);
+  if (mode == kGoutAttn) {
+    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutAttn);
+    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutAttn);
+    else GFLA_BE_BWD_LAUNCH(false, true, kGoutAttn);
+  } else if (mode == kGoutUnfold) {
+    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutUnfold);
+    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutUnfold);
+    else GFLA_BE_BWD_LAUNCH(false, true, kGoutUnfold);
   } else {
-    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, false);
-    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, false);
-    else GFLA_BE_BWD_LAUNCH(false, true, false);
+    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutTensor);
+    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutTensor);
+    else GFLA_BE_BWD_LAUNCH(false, true, kGoutTensor);
   }
 #undef GFLA_BE_BWD_LAUNCH
   *done = true;

@@ -361,7 +361,7 @@ static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T
                           hipStream_t stream) {
   if (tuning(2) != 1) {
     bool done = false;
-    int st = launch_be_bwd_lds<T, K>(src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
+    int st = launch_be_bwd_lds<T, K>(kGoutTensor, src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
     if (done || st != GFLA_OK) return st;
   }
   const int64_t sp_blocks = ceil_div(Hf * Wf, kBlock);
@@ -400,6 +400,167 @@ static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gs
   return launch_status();
 }
 
+// ----------------------------------------------------------------------------------------
+// "unfold" layout: out (B, C*K*K, Hf, Wf), channel c*K*K + i*K + j = tap (i,j) of source channel c.
+// Same values as the reference layout (B,C,K*Hf,K*Wf), arranged so that the stride-K convolution
+// that consumes it in ExtractorAttn (base_function.py:800) is a plain batched GEMM
+// W(128, C*K*K) @ out[b](C*K*K, Hf*Wf) and every lane writes/reads consecutive pixels.
+// workgroup <-> (b, group of G channels in LDS[, 1/split of the pixels]); lane <-> pixel: the
+// (K+1)x(K+1) patch is read once per channel ((K+1)^2 ds_read_b32) and yields all K*K outputs.
+// ----------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs, int Ws,
+    int Hf, int Wf, int G, int ngroups, int split) {
+  using A = typename Num<T>::acc;
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  int bid = blockIdx.x;
+  const int sp = bid % split;
+  bid /= split;
+  const int g = bid % ngroups;
+  const int b = bid / ngroups;
+  const int c0 = g * G;
+  const int gc = min(G, C - c0);
+  const int plane_sz = Hs * Ws;
+  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
+  __syncthreads();
+  const int HW = Hf * Wf;
+  const int per = (HW + split - 1) / split;
+  const int p_end = min(HW, (sp + 1) * per);
+  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+    const int yf = p / Wf, xf = p - yf * Wf;
+    const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
+    const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+    int xL[K], xR[K];
+    A ax[K];
+    int x0 = 0, y0 = 0;
+    bool dense = true;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:62-67
+      const A dy = (fy0 + (A)(t - K / 2)) + (A)yf;
+      const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+      if (t == 0) {
+        x0 = (int)fdx;
+        y0 = (int)fdy;
+      }
+      dense = dense && ((int)fdx == x0 + t) && ((int)fdy == y0 + t);
+      xL[t] = clampi((int)fdx, 0, Ws - 1);
+      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
+      ax[t] = dx - fdx;
+    }
+    T *o = out + ((int64_t)b * C + c0) * KK * HW + p;
+    if (dense) {
+      int col[K + 1];
+#pragma unroll
+      for (int q = 0; q <= K; ++q) col[q] = clampi(x0 + q, 0, Ws - 1);
+      for (int c = 0; c < gc; ++c) {
+        const A *pl = planes + (size_t)c * plane_sz;
+        A vA[K + 1];
+        {
+          const int off = clampi(y0, 0, Hs - 1) * Ws;
+#pragma unroll
+          for (int q = 0; q <= K; ++q) vA[q] = pl[off + col[q]];
+        }
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+          const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
+          const int off = clampi(y0 + i + 1, 0, Hs - 1) * Ws;
+          A vB[K + 1];
+#pragma unroll
+          for (int q = 0; q <= K; ++q) vB[q] = pl[off + col[q]];
+          T *orow = o + (int64_t)(c * KK + i * K) * HW;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const A xL_P = 1 - ax[j], xR_P = ax[j];
+            A s = (xL_P * yT_P) * vA[j];  // :78-84, same order of accumulation
+            s += (xR_P * yT_P) * vA[j + 1];
+            s += (xL_P * yB_P) * vB[j];
+            s += (xR_P * yB_P) * vB[j + 1];
+            orow[(int64_t)j * HW] = Num<T>::from(s);
+          }
+#pragma unroll
+          for (int q = 0; q <= K; ++q) vA[q] = vB[q];
+        }
+      }
+    } else {
+      for (int c = 0; c < gc; ++c) {
+        const A *pl = planes + (size_t)c * plane_sz;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+          const A fdy = floor_t<A>(dy);
+          const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+          const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+          T *orow = o + (int64_t)(c * KK + i * K) * HW;
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const A xL_P = 1 - ax[j], xR_P = ax[j];
+            A s = (xL_P * yT_P) * pl[yT + xL[j]];
+            s += (xR_P * yT_P) * pl[yT + xR[j]];
+            s += (xL_P * yB_P) * pl[yB + xL[j]];
+            s += (xR_P * yB_P) * pl[yB + xR[j]];
+            orow[(int64_t)j * HW] = Num<T>::from(s);
+          }
+        }
+      }
+    }
+  }
+}
+
+#define GFLA_BE_K_SWITCH(KV, ...)                  \
+  switch (KV) {                                    \
+    case 1: { constexpr int K = 1; __VA_ARGS__; } break;  \
+    case 2: { constexpr int K = 2; __VA_ARGS__; } break;  \
+    case 3: { constexpr int K = 3; __VA_ARGS__; } break;  \
+    case 4: { constexpr int K = 4; __VA_ARGS__; } break;  \
+    default: { constexpr int K = 5; __VA_ARGS__; } break; \
+  }
+
+static int unfold_check(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                        int bytes_per_elem) {
+  if (B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Hf <= 0 || Wf <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
+  if (k > 5) return GFLA_ERR_UNSUPPORTED;
+  if (Hs * Ws * bytes_per_elem > kLdsBudget || Hf * Wf > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  return GFLA_OK;
+}
+
+template <typename T>
+static int block_extractor_unfold_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs,
+                                      int64_t Ws, int64_t Hf, int64_t Wf, int k, gfla_stream_t stream_) {
+  using A = typename Num<T>::acc;
+  if (!src || !flow || !out) return GFLA_ERR_NULL_POINTER;
+  int st = unfold_check(B, C, Hs, Ws, Hf, Wf, k, sizeof(A));
+  if (st != GFLA_OK) return st;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), B, C, Hf * Wf, true);
+  const int64_t blocks = B * g.ngroups * g.split;
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  GFLA_BE_K_SWITCH(k, be_unfold_fwd_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+                          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split));
+  return launch_status();
+}
+
+template <typename T>
+static int block_extractor_unfold_bwd(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
+                                      int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                      gfla_stream_t stream_) {
+  using A = typename Num<T>::acc;
+  if (!src || !flow || !gout) return GFLA_ERR_NULL_POINTER;
+  int st = unfold_check(B, C, Hs, Ws, Hf, Wf, k, sizeof(lds_acc_t) + sizeof(A));
+  if (st != GFLA_OK) return st;
+  if (!gsrc && !gflow) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  bool done = false;
+  GFLA_BE_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutUnfold, src, flow, gout, static_cast<const T *>(nullptr), gsrc,
+                                                   gflow, B, C, Hs, Ws, Hf, Wf, stream, &done));
+  if (st == GFLA_OK && !done) st = GFLA_ERR_UNSUPPORTED;
+  return st;
+}
+
 }  // namespace gfla
 
 using gfla::bf16_t;
@@ -431,5 +592,36 @@ int gfla_block_extractor_bwd_f64(const double *s, const double *f, const double 
                                  double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
                                  int64_t Hf, int64_t Wf, int k, gfla_stream_t st) {
   return gfla::block_extractor_bwd<double>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_unfold_supported(int64_t Hs, int64_t Ws, int k, int elem_size) {
+  const int acc = elem_size == 8 ? 8 : 4;
+  return (k >= 1 && k <= 5 && Hs > 0 && Ws > 0 && Hs * Ws * (int64_t)(8 + acc) <= gfla::kLdsBudget) ? 1 : 0;
+}
+int gfla_block_extractor_unfold_fwd_f32(const float *s, const float *f, float *o, int64_t B, int64_t C,
+                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                        gfla_stream_t st) {
+  return gfla::block_extractor_unfold_fwd<float>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_unfold_fwd_f64(const double *s, const double *f, double *o, int64_t B, int64_t C,
+                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                        gfla_stream_t st) {
+  return gfla::block_extractor_unfold_fwd<double>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_unfold_fwd_bf16(const uint16_t *s, const uint16_t *f, uint16_t *o, int64_t B,
+                                         int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                         gfla_stream_t st) {
+  return gfla::block_extractor_unfold_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(s),
+                                                  reinterpret_cast<const bf16_t *>(f),
+                                                  reinterpret_cast<bf16_t *>(o), B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_unfold_bwd_f32(const float *s, const float *f, const float *go, float *gs, float *gf,
+                                        int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                                        int k, gfla_stream_t st) {
+  return gfla::block_extractor_unfold_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+}
+int gfla_block_extractor_unfold_bwd_f64(const double *s, const double *f, const double *go, double *gs,
+                                        double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                        int64_t Wf, int k, gfla_stream_t st) {
+  return gfla::block_extractor_unfold_bwd<double>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
 }
 }

@@ -595,7 +595,7 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
     // (1) grad_source + grad_flow: block_extractor backward of the factored gradient a_ij*g_c/k^2
     if (gsrc || gflow) {
       bool done = false;
-      GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(src, flow, gout, attn, gsrc, gflow, B, C, Hs, Ws, H, W, stream, &done));
+      GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutAttn, src, flow, gout, attn, gsrc, gflow, B, C, Hs, Ws, H, W, stream, &done));
       if (st != GFLA_OK) return st;
       if (!done) return GFLA_ERR_UNSUPPORTED;
     }

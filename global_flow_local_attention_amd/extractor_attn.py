@@ -4,7 +4,8 @@
 `fully_connect_layer` -- so `state_dict` keys are `fully_connect_layer.{0,2}.{weight,bias}` and
 reference checkpoints load) and methods (`forward`, `hook_attn_param`).  Two evaluation modes:
 
-* fused (default): block_source is extracted once for the first convolution; the Softmax ->
+* fused (default): block_source is extracted once, directly as the GEMM operand of the first
+  convolution ("unfold" layout, BlockExtractorUnfoldFunction); the Softmax ->
   LocalAttnReshape -> multiply -> avg_pool2d tail runs as ONE kernel straight from `source`
   (gfla_local_attn_aggregate_*), and block_target is never built: the first convolution is split
   into its target half -- a stride-1 convolution of the replicate-padded target, exactly equal to
@@ -73,6 +74,56 @@ class LocalAttnAggregateFunction(Function):
         return gs, gf, gl, None, None
 
 
+class BlockExtractorUnfoldFunction(Function):
+    """block_extractor in "unfold" layout: (B,C,Hs,Ws),(B,2,H,W) -> (B, C*k*k, H, W) with channel
+    c*k*k + i*k + j = tap (i,j) of channel c -- the GEMM operand of ExtractorAttn's first FC layer."""
+
+    @staticmethod
+    def forward(ctx, source, flow_field, kernel_size):
+        assert source.is_contiguous() and flow_field.is_contiguous()
+        _lib.require_gpu(source, flow_field)
+        b, c, hs, ws = source.size()
+        bf, two, h, w = flow_field.size()
+        k = int(kernel_size)
+        if two != 2 or bf != b or source.dtype != flow_field.dtype:
+            raise ValueError("block_extractor_unfold: inconsistent inputs")
+        out = source.new_empty((b, c * k * k, h, w))
+        _lib.call("gfla_block_extractor_unfold_fwd_" + _lib.suffix(source, "block_extractor_unfold"), source,
+                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(out), b, c, hs, ws, h, w, k)
+        ctx.save_for_backward(source, flow_field)
+        ctx.kernel_size = k
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        source, flow_field = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, c, hs, ws = source.size()
+        _, _, h, w = flow_field.size()
+        ns, nf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gs = torch.zeros_like(source) if ns else None
+        gf = torch.zeros_like(flow_field) if nf else None
+        if ns or nf:
+            _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
+                      source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
+                      b, c, hs, ws, h, w, ctx.kernel_size)
+        return gs, gf, None
+
+
+def _source_half_fc(self, source_c, flow_c, conv0, c, k):
+    """conv_{k, stride k}(block_source, W[:, C:]) (base_function.py:800,805-807).  When the source
+    planes fit in LDS the extractor writes its samples directly as the GEMM operand (unfold layout)
+    and the convolution is one batched fp32 GEMM; otherwise the reference layout + a strided conv."""
+    if getattr(self, "unfold_gemm", True) and _lib.unfold_supported(source_c.size(2), source_c.size(3), k,
+                                                                     source_c.element_size()):
+        unf = BlockExtractorUnfoldFunction.apply(source_c, flow_c, k)          # (B, C*k*k, H, W)
+        b, kk_c, h, w = unf.shape
+        w_s = conv0.weight[:, c:].reshape(conv0.out_channels, kk_c)           # (128, C*k*k), index c*k*k+i*k+j
+        return torch.matmul(w_s, unf.view(b, kk_c, h * w)).view(b, conv0.out_channels, h, w)
+    block_source = self.extractor(source_c, flow_c)
+    return F.conv2d(block_source, conv0.weight[:, c:], None, stride=k)
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
@@ -81,13 +132,14 @@ def _fused_attention(self, source, target, flow_field):
     c = source.size(1)
     source_c = source.contiguous()
     flow_c = flow_field.contiguous()
-    block_source = self.extractor(source_c, flow_c)                       # base_function.py:805
-    # base_function.py:806-807: conv0(cat(block_target, block_source)) with block_target the
-    # zero-flow (replicate-padded) unfold of target == stride-1 conv of the padded target.
+    # base_function.py:805-807: conv0(cat(block_target, block_source)).  block_target is the
+    # zero-flow (replicate-padded) unfold of target, so its half of the convolution equals a
+    # stride-1 convolution of the padded target and block_target is never built; block_source's half
+    # runs on the extractor's output (see _source_half_fc).
     lo, hi = k // 2, k - 1 - k // 2
     target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
     hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
-    hidden = hidden + F.conv2d(block_source, conv0.weight[:, c:], None, stride=k)
+    hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k)
     logits = conv1(act(hidden))
     if isinstance(last, nn.Softmax) and last.dim == 1:
         result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True)

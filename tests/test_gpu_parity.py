@@ -125,6 +125,45 @@ def test_block_extractor_bf16_forward(gfla, oracle):
     assert max_abs(out.float().cpu(), want) <= 2 ** -8 * max(1.0, want.abs().max().item())
 
 
+def _to_unfold(t, k):
+    """(B,C,kH,kW) reference layout -> (B, C*k*k, H, W) unfold layout."""
+    B, C, kH, kW = t.shape
+    H, W = kH // k, kW // k
+    return t.view(B, C, H, k, W, k).permute(0, 1, 3, 5, 2, 4).reshape(B, C * k * k, H, W).contiguous()
+
+
+def _from_unfold(t, k, C):
+    B, _, H, W = t.shape
+    return t.view(B, C, k, k, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, C, k * H, k * W).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["zero", "coherent", "wild", "integer"])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+def test_block_extractor_unfold_layout(gfla, oracle, dtype, kind, k):
+    B, C, H, W = 2, 7, 13, 9
+    s, f = randn((B, C, H, W), dtype, seed=50), make_flow(kind, B, H, W, dtype, seed=51)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractorUnfoldFunction.apply(sd, fd, k)
+    want = oracle.block_extractor_fwd(s, f, k)
+    assert out.shape == (B, C * k * k, H, W)
+    assert_close(out.cpu(), _to_unfold(want, k), tol(dtype), "unfold fwd")
+    # identical samples to the reference-layout entry point
+    assert_close(_from_unfold(out.detach(), k, C), gfla.BlockExtractorFunction.apply(sd.detach(), fd.detach(), k), tol(dtype))
+    g = randn(tuple(out.shape), dtype, seed=52)
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(s, f, _from_unfold(g, k, C), k)
+    assert_close(sd.grad.cpu(), gs, tol(dtype, True), "unfold grad_source")
+    assert_close(fd.grad.cpu(), gf, tol(dtype, True), "unfold grad_flow")
+
+
+def test_unfold_supported_query(gfla):
+    from global_flow_local_attention_amd import _lib
+    assert _lib.unfold_supported(64, 64, 5, 4) and _lib.unfold_supported(32, 22, 3, 4)
+    assert not _lib.unfold_supported(256, 176, 3, 4)      # 180 KB plane: reference layout + global kernels
+    assert not _lib.unfold_supported(32, 32, 7, 4)
+
+
 # --------------------------------------------------------------------------- local_attn_reshape
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
 @pytest.mark.parametrize("k", [1, 2, 3, 5])
@@ -250,9 +289,20 @@ def test_extractor_attn_fused_equals_unfused_and_oracle(gfla, oracle, k, C, soft
     f = make_flow("coherent", B, H, W, seed=33)
     args = [x.to(DEV).requires_grad_() for x in (s, t, f)]
     m.fused = True
+    m.unfold_gemm = False  # fused tail, FC on the reference-layout block tensor
+    attn_c, out_c = m.hook_attn_param(*args)
+    (out_c.square().sum()).backward()
+    grads_c = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    for a in args:
+        a.grad = None
+    m.zero_grad()
+    m.unfold_gemm = True   # default: extractor writes the GEMM operand, FC = batched GEMM
     attn_f, out_f = m.hook_attn_param(*args)
     (out_f.square().sum()).backward()
     grads_f = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    assert_close(out_c.detach().cpu(), out_f.detach().cpu(), 2e-5, "conv vs GEMM formulation of the FC")
+    for gc_, gf_ in zip(grads_c, grads_f):
+        assert_close(gc_.cpu(), gf_.cpu(), 2e-4, "conv vs GEMM grads")
     for a in args:
         a.grad = None
     m.zero_grad()

@@ -23,4 +23,9 @@ timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/benc
 echo "== rocprof"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.log 2>&1); echo "rocprof rc=$?"
 find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20; cat $OUT/*kernel_stats.csv 2>/dev/null | head -30 | cut -c1-220
-ls $OUT
+echo "== pmc (HBM traffic of the gfla kernels; separate passes, kernel-trace only)"
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/pmc_${TAG}_$CNT -o pmc -- python $OLDPWD/tools/opbench.py --iters 2 --no-ref --only be_fwd,be_bwd,agg_fwd,agg_bwd,rs_fwd,rs_bwd,be_unfold > $OLDPWD/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT rc=$?"
+  find /tmp/pmc_${TAG}_$CNT -name "*counter_collection.csv" -exec cp {} $OUT/pmc_${CNT}_counter_collection.csv \; 2>/dev/null
+done
+ls -la $OUT
