@@ -100,6 +100,10 @@ class HotPath:
 # ---- algorithmic bytes per C-ABI call (4 bytes per fp32 element) -------
 def algorithmic_bytes(name, a, esz=4):
     base = name.rsplit("_", 1)[0]
+    if base == "gfla_block_extractor_unfold_fwd":
+        base, a = "gfla_block_extractor_fwd", a[:10]
+    if base == "gfla_block_extractor_unfold_bwd":
+        base, a = "gfla_block_extractor_bwd", a[:12]
     if base == "gfla_block_extractor_fwd":
         B, C, Hs, Ws, Hf, Wf, k = a[3:10]
         return esz * (B * C * Hs * Ws + 2 * B * Hf * Wf + B * C * k * k * Hf * Wf)

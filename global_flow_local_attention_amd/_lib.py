@@ -20,8 +20,8 @@ _i64, _int, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
 _SIGNATURES = {
     "gfla_block_extractor_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _ptr],
     "gfla_block_extractor_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _ptr],
-    "gfla_block_extractor_unfold_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _ptr],
-    "gfla_block_extractor_unfold_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _ptr],
+    "gfla_block_extractor_unfold_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_block_extractor_unfold_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_reshape_fwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
     "gfla_local_attn_reshape_bwd": [_ptr] * 2 + [_i64] * 3 + [_int, _ptr],
     "gfla_resample2d_fwd": [_ptr] * 3 + [_i64] * 6 + [_int, _int, _ptr],

@@ -37,9 +37,9 @@ struct GoutRow {
 #pragma unroll
       for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(attn_p + (int64_t)(i * K + j) * HW) * go;
     } else if constexpr (MODE == kGoutUnfold) {
-      const T *r = base + ((int64_t)c * K * K + i * K) * HW;
+      const T *r = base + ((int64_t)c * K * K + i * K) * cstride;
 #pragma unroll
-      for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(r + (int64_t)j * HW);
+      for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(r + (int64_t)j * cstride);
     } else {
       const T *r = base + (int64_t)c * cstride + (int64_t)i * pitch;
 #pragma unroll
@@ -52,7 +52,7 @@ template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     const T *__restrict__ attn, T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws,
-    int Hf, int Wf, int G, int ngroups, int split) {
+    int Hf, int Wf, int G, int ngroups, int split, int64_t u_cs, int64_t u_bs) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   int bid = blockIdx.x;
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       gr.attn_p = attn + (int64_t)b * K * K * HW + p;
       gr.cstride = HW;
       gr.pitch = 0;
-    } else if constexpr (MODE == kGoutUnfold) {
-      gr.base = gout + ((int64_t)b * C + c0) * K * K * HW + p;
+    } else if constexpr (MODE == kGoutUnfold) {  // element (b, ch, p) at b*u_bs + ch*u_cs + p
+      gr.base = gout + (int64_t)b * u_bs + (int64_t)c0 * K * K * u_cs + p;
       gr.attn_p = nullptr;
-      gr.cstride = 0;
+      gr.cstride = u_cs;
       gr.pitch = 0;
     } else {
       gr.base = gout + ((int64_t)b * C + c0) * ((int64_t)K * Hf * Wo) + (int64_t)(yf * K) * Wo + xf * K;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
 template <typename T, int K>
 static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gout, const T *attn, T *gsrc,
                              T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
-                             hipStream_t stream, bool *done) {
+                             hipStream_t stream, bool *done, int64_t u_cs = 0, int64_t u_bs = 0) {
   using A = typename Num<T>::acc;
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
@@ -235,7 +235,7 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
   const dim3 grid((unsigned)blocks), blk(kLdsThreads);
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
   be_bwd_lds_kernel<T, K, S, F, AT><<<grid, blk, g.lds_bytes, stream>>>(                             \
-      src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split)
+      src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, u_cs, u_bs)
   if (mode == kGoutAttn) {
     if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutAttn);
     else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutAttn);

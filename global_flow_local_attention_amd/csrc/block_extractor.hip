@@ -411,7 +411,7 @@ static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gs
 template <typename T, int K>
 __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs, int Ws,
-    int Hf, int Wf, int G, int ngroups, int split) {
+    int Hf, int Wf, int G, int ngroups, int split, int64_t u_cs, int64_t u_bs) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
       xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
       ax[t] = dx - fdx;
     }
-    T *o = out + ((int64_t)b * C + c0) * KK * HW + p;
+    T *o = out + (int64_t)b * u_bs + (int64_t)c0 * KK * u_cs + p;  // element (b, ch, p) at b*u_bs + ch*u_cs + p
     if (dense) {
       int col[K + 1];
 #pragma unroll
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
           A vB[K + 1];
 #pragma unroll
           for (int q = 0; q <= K; ++q) vB[q] = pl[off + col[q]];
-          T *orow = o + (int64_t)(c * KK + i * K) * HW;
+          T *orow = o + (int64_t)(c * KK + i * K) * u_cs;
 #pragma unroll
           for (int j = 0; j < K; ++j) {
             const A xL_P = 1 - ax[j], xR_P = ax[j];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
             s += (xR_P * yT_P) * vA[j + 1];
             s += (xL_P * yB_P) * vB[j];
             s += (xR_P * yB_P) * vB[j + 1];
-            orow[(int64_t)j * HW] = Num<T>::from(s);
+            orow[(int64_t)j * u_cs] = Num<T>::from(s);
           }
 #pragma unroll
           for (int q = 0; q <= K; ++q) vA[q] = vB[q];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
           const A fdy = floor_t<A>(dy);
           const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
           const A yB_P = dy - fdy, yT_P = 1 - yB_P;
-          T *orow = o + (int64_t)(c * KK + i * K) * HW;
+          T *orow = o + (int64_t)(c * KK + i * K) * u_cs;
 #pragma unroll
           for (int j = 0; j < K; ++j) {
             const A xL_P = 1 - ax[j], xR_P = ax[j];
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_unfold_fwd_lds_kernel(
             s += (xR_P * yT_P) * pl[yT + xR[j]];
             s += (xL_P * yB_P) * pl[yB + xL[j]];
             s += (xR_P * yB_P) * pl[yB + xR[j]];
-            orow[(int64_t)j * HW] = Num<T>::from(s);
+            orow[(int64_t)j * u_cs] = Num<T>::from(s);
           }
         }
       }
@@ -528,9 +528,20 @@ static int unfold_check(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf
   return GFLA_OK;
 }
 
+static void unfold_strides(int layout, int64_t B, int64_t C, int64_t HW, int k, int64_t *cs, int64_t *bs) {
+  if (layout == 1) {  // (C*k*k, B, Hf, Wf): one GEMM operand (C*k*k) x (B*Hf*Wf) for the whole batch
+    *cs = B * HW;
+    *bs = HW;
+  } else {            // (B, C*k*k, Hf, Wf)
+    *cs = HW;
+    *bs = C * k * k * HW;
+  }
+}
+
 template <typename T>
 static int block_extractor_unfold_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs,
-                                      int64_t Ws, int64_t Hf, int64_t Wf, int k, gfla_stream_t stream_) {
+                                      int64_t Ws, int64_t Hf, int64_t Wf, int k, int layout,
+                                      gfla_stream_t stream_) {
   using A = typename Num<T>::acc;
   if (!src || !flow || !out) return GFLA_ERR_NULL_POINTER;
   int st = unfold_check(B, C, Hs, Ws, Hf, Wf, k, sizeof(A));
@@ -539,15 +550,17 @@ static int block_extractor_unfold_fwd(const T *src, const T *flow, T *out, int64
   PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), B, C, Hf * Wf, true);
   const int64_t blocks = B * g.ngroups * g.split;
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  int64_t cs, bs;
+  unfold_strides(layout, B, C, (int64_t)(Hf * Wf), k, &cs, &bs);
   GFLA_BE_K_SWITCH(k, be_unfold_fwd_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
-                          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split));
+                          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, cs, bs));
   return launch_status();
 }
 
 template <typename T>
 static int block_extractor_unfold_bwd(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
                                       int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
-                                      gfla_stream_t stream_) {
+                                      int layout, gfla_stream_t stream_) {
   using A = typename Num<T>::acc;
   if (!src || !flow || !gout) return GFLA_ERR_NULL_POINTER;
   int st = unfold_check(B, C, Hs, Ws, Hf, Wf, k, sizeof(lds_acc_t) + sizeof(A));
@@ -555,8 +568,10 @@ static int block_extractor_unfold_bwd(const T *src, const T *flow, const T *gout
   if (!gsrc && !gflow) return GFLA_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   bool done = false;
+  int64_t cs, bs;
+  unfold_strides(layout, B, C, (int64_t)(Hf * Wf), k, &cs, &bs);
   GFLA_BE_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutUnfold, src, flow, gout, static_cast<const T *>(nullptr), gsrc,
-                                                   gflow, B, C, Hs, Ws, Hf, Wf, stream, &done));
+                                                   gflow, B, C, Hs, Ws, Hf, Wf, stream, &done, cs, bs));
   if (st == GFLA_OK && !done) st = GFLA_ERR_UNSUPPORTED;
   return st;
 }
@@ -598,30 +613,30 @@ int gfla_unfold_supported(int64_t Hs, int64_t Ws, int k, int elem_size) {
   return (k >= 1 && k <= 5 && Hs > 0 && Ws > 0 && Hs * Ws * (int64_t)(8 + acc) <= gfla::kLdsBudget) ? 1 : 0;
 }
 int gfla_block_extractor_unfold_fwd_f32(const float *s, const float *f, float *o, int64_t B, int64_t C,
-                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, int layout,
                                         gfla_stream_t st) {
-  return gfla::block_extractor_unfold_fwd<float>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+  return gfla::block_extractor_unfold_fwd<float>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 int gfla_block_extractor_unfold_fwd_f64(const double *s, const double *f, double *o, int64_t B, int64_t C,
-                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                        int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, int layout,
                                         gfla_stream_t st) {
-  return gfla::block_extractor_unfold_fwd<double>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, st);
+  return gfla::block_extractor_unfold_fwd<double>(s, f, o, B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 int gfla_block_extractor_unfold_fwd_bf16(const uint16_t *s, const uint16_t *f, uint16_t *o, int64_t B,
-                                         int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                         int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, int layout,
                                          gfla_stream_t st) {
   return gfla::block_extractor_unfold_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(s),
                                                   reinterpret_cast<const bf16_t *>(f),
-                                                  reinterpret_cast<bf16_t *>(o), B, C, Hs, Ws, Hf, Wf, k, st);
+                                                  reinterpret_cast<bf16_t *>(o), B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 int gfla_block_extractor_unfold_bwd_f32(const float *s, const float *f, const float *go, float *gs, float *gf,
                                         int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
-                                        int k, gfla_stream_t st) {
-  return gfla::block_extractor_unfold_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+                                        int k, int layout, gfla_stream_t st) {
+  return gfla::block_extractor_unfold_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 int gfla_block_extractor_unfold_bwd_f64(const double *s, const double *f, const double *go, double *gs,
                                         double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
-                                        int64_t Wf, int k, gfla_stream_t st) {
-  return gfla::block_extractor_unfold_bwd<double>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
+                                        int64_t Wf, int k, int layout, gfla_stream_t st) {
+  return gfla::block_extractor_unfold_bwd<double>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 }

@@ -76,10 +76,11 @@ class LocalAttnAggregateFunction(Function):
 
 class BlockExtractorUnfoldFunction(Function):
     """block_extractor in "unfold" layout: (B,C,Hs,Ws),(B,2,H,W) -> (B, C*k*k, H, W) with channel
-    c*k*k + i*k + j = tap (i,j) of channel c -- the GEMM operand of ExtractorAttn's first FC layer."""
+    c*k*k + i*k + j = tap (i,j) of channel c -- the GEMM operand of ExtractorAttn's first FC layer.
+    batch_inner=True returns (C*k*k, B, H, W) instead: one GEMM operand for the whole batch."""
 
     @staticmethod
-    def forward(ctx, source, flow_field, kernel_size):
+    def forward(ctx, source, flow_field, kernel_size, batch_inner=False):
         assert source.is_contiguous() and flow_field.is_contiguous()
         _lib.require_gpu(source, flow_field)
         b, c, hs, ws = source.size()
@@ -87,11 +88,13 @@ class BlockExtractorUnfoldFunction(Function):
         k = int(kernel_size)
         if two != 2 or bf != b or source.dtype != flow_field.dtype:
             raise ValueError("block_extractor_unfold: inconsistent inputs")
-        out = source.new_empty((b, c * k * k, h, w))
+        layout = 1 if batch_inner else 0
+        out = source.new_empty((c * k * k, b, h, w) if batch_inner else (b, c * k * k, h, w))
         _lib.call("gfla_block_extractor_unfold_fwd_" + _lib.suffix(source, "block_extractor_unfold"), source,
-                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(out), b, c, hs, ws, h, w, k)
+                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(out), b, c, hs, ws, h, w, k, layout)
         ctx.save_for_backward(source, flow_field)
         ctx.kernel_size = k
+        ctx.layout = layout
         return out
 
     @staticmethod
@@ -106,8 +109,8 @@ class BlockExtractorUnfoldFunction(Function):
         if ns or nf:
             _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
                       source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
-                      b, c, hs, ws, h, w, ctx.kernel_size)
-        return gs, gf, None
+                      b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
+        return gs, gf, None, None
 
 
 def _source_half_fc(self, source_c, flow_c, conv0, c, k):
@@ -116,10 +119,11 @@ def _source_half_fc(self, source_c, flow_c, conv0, c, k):
     and the convolution is one batched fp32 GEMM; otherwise the reference layout + a strided conv."""
     if getattr(self, "unfold_gemm", True) and _lib.unfold_supported(source_c.size(2), source_c.size(3), k,
                                                                      source_c.element_size()):
-        unf = BlockExtractorUnfoldFunction.apply(source_c, flow_c, k)          # (B, C*k*k, H, W)
-        b, kk_c, h, w = unf.shape
+        unf = BlockExtractorUnfoldFunction.apply(source_c, flow_c, k, True)    # (C*k*k, B, H, W)
+        kk_c, b, h, w = unf.shape
         w_s = conv0.weight[:, c:].reshape(conv0.out_channels, kk_c)           # (128, C*k*k), index c*k*k+i*k+j
-        return torch.matmul(w_s, unf.view(b, kk_c, h * w)).view(b, conv0.out_channels, h, w)
+        hid = torch.mm(w_s, unf.view(kk_c, b * h * w))                        # ONE GEMM for the whole batch
+        return hid.view(conv0.out_channels, b, h, w).permute(1, 0, 2, 3)      # strided (B,128,H,W) view
     block_source = self.extractor(source_c, flow_c)
     return F.conv2d(block_source, conv0.weight[:, c:], None, stride=k)
 

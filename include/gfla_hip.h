@@ -94,7 +94,9 @@ GFLA_DECL_BLOCK_EXTRACTOR_BWD(f64, double)
  * c*k*k + i*k + j = tap (i,j) of source channel c, i.e. out_unfold[b, c*k*k+i*k+j, yf, xf] ==
  * out[b, c, yf*k+i, xf*k+j].  In this layout the stride-k convolution of ExtractorAttn
  * (base_function.py:800) is the batched GEMM  W(128, C*k*k) @ out_unfold[b](C*k*k, Hf*Wf)  and all
- * kernel traffic is coalesced along the pixel index.  backward takes the gradient in the same layout;
+ * kernel traffic is coalesced along the pixel index.  layout = 1 stores (C*k*k, B, Hf, Wf) instead,
+ * so the whole batch is ONE GEMM  W(128, C*k*k) @ out_unfold(C*k*k, B*Hf*Wf)  (and one each for the
+ * data and weight gradients).  backward takes the gradient in the same layout;
  * grad_source / grad_flow accumulate (pass zeroed buffers), either may be NULL.
  * Only for kernel_size <= 5 and source planes that fit the LDS budget: gfla_unfold_supported() says
  * so (1/0); otherwise the entry points return GFLA_ERR_UNSUPPORTED and the caller uses the reference
@@ -103,7 +105,7 @@ int gfla_unfold_supported(int64_t Hs, int64_t Ws, int kernel_size, int elem_size
 #define GFLA_DECL_UNFOLD_FWD(SFX, T)                                                               \
   int gfla_block_extractor_unfold_fwd_##SFX(const T *source, const T *flow, T *out_unfold,         \
                                             int64_t B, int64_t C, int64_t Hs, int64_t Ws,          \
-                                            int64_t Hf, int64_t Wf, int kernel_size,               \
+                                            int64_t Hf, int64_t Wf, int kernel_size, int layout,   \
                                             gfla_stream_t stream);
 GFLA_DECL_UNFOLD_FWD(f32, float)
 GFLA_DECL_UNFOLD_FWD(f64, double)
@@ -114,7 +116,7 @@ GFLA_DECL_UNFOLD_FWD(bf16, uint16_t)
   int gfla_block_extractor_unfold_bwd_##SFX(const T *source, const T *flow, const T *grad_unfold,  \
                                             T *grad_source, T *grad_flow, int64_t B, int64_t C,    \
                                             int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,        \
-                                            int kernel_size, gfla_stream_t stream);
+                                            int kernel_size, int layout, gfla_stream_t stream);
 GFLA_DECL_UNFOLD_BWD(f32, float)
 GFLA_DECL_UNFOLD_BWD(f64, double)
 #undef GFLA_DECL_UNFOLD_BWD

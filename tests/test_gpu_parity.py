@@ -147,6 +147,8 @@ def test_block_extractor_unfold_layout(gfla, oracle, dtype, kind, k):
     out = gfla.BlockExtractorUnfoldFunction.apply(sd, fd, k)
     want = oracle.block_extractor_fwd(s, f, k)
     assert out.shape == (B, C * k * k, H, W)
+    out_bi = gfla.BlockExtractorUnfoldFunction.apply(sd.detach(), fd.detach(), k, True)   # (C*k*k, B, H, W)
+    assert torch.equal(out_bi.permute(1, 0, 2, 3), out.detach())
     assert_close(out.cpu(), _to_unfold(want, k), tol(dtype), "unfold fwd")
     # identical samples to the reference-layout entry point
     assert_close(_from_unfold(out.detach(), k, C), gfla.BlockExtractorFunction.apply(sd.detach(), fd.detach(), k), tol(dtype))
@@ -155,6 +157,10 @@ def test_block_extractor_unfold_layout(gfla, oracle, dtype, kind, k):
     gs, gf = oracle.block_extractor_bwd(s, f, _from_unfold(g, k, C), k)
     assert_close(sd.grad.cpu(), gs, tol(dtype, True), "unfold grad_source")
     assert_close(fd.grad.cpu(), gf, tol(dtype, True), "unfold grad_flow")
+    s2, f2 = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()                          # batch-inner layout
+    gfla.BlockExtractorUnfoldFunction.apply(s2, f2, k, True).backward(g.to(DEV).permute(1, 0, 2, 3).contiguous())
+    assert_close(s2.grad.cpu(), gs, tol(dtype, True), "unfold(batch-inner) grad_source")
+    assert_close(f2.grad.cpu(), gf, tol(dtype, True), "unfold(batch-inner) grad_flow")
 
 
 def test_unfold_supported_query(gfla):

@@ -17,7 +17,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 echo "== diag conv (skipped)"
 true
 echo "== opbench"
-timeout 600 python tools/opbench.py --iters 20 --out $OUT/opbench.jsonl > $OUT/opbench.log 2>&1; echo "opbench rc=$?"; tail -5 $OUT/opbench.log
+timeout 600 python tools/opbench.py --iters 20 ${OPBENCH_ARGS:-} --out $OUT/opbench.jsonl > $OUT/opbench.log 2>&1; echo "opbench rc=$?"; tail -5 $OUT/opbench.log
 echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== rocprof"
@@ -25,7 +25,8 @@ echo "== rocprof"
 find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20; cat $OUT/*kernel_stats.csv 2>/dev/null | head -30 | cut -c1-220
 echo "== pmc (HBM traffic of the gfla kernels; separate passes, kernel-trace only)"
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/pmc_${TAG}_$CNT -o pmc -- python $OLDPWD/tools/opbench.py --iters 2 --no-ref --only be_fwd,be_bwd,agg_fwd,agg_bwd,rs_fwd,rs_bwd,be_unfold > $OLDPWD/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/pmc_${TAG}_$CNT -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT rc=$?"
   find /tmp/pmc_${TAG}_$CNT -name "*counter_collection.csv" -exec cp {} $OUT/pmc_${CNT}_counter_collection.csv \; 2>/dev/null
 done
+python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_counter_collection.csv $OUT/pmc_WRITE_SIZE_counter_collection.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1; cat $OUT/pmc_traffic.txt
 ls -la $OUT

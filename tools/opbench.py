@@ -133,14 +133,14 @@ def main():
                 del gout, gs, gf
             if want("be_unfold") and tag != "cfg2" and kind == "smooth":
                 outu = torch.empty(B, C * k * k, H, W, device=DEV)
-                fn = lambda: _lib.call("gfla_block_extractor_unfold_fwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(outu), B, C, H, W, H, W, k)
+                fn = lambda: _lib.call("gfla_block_extractor_unfold_fwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(outu), B, C, H, W, H, W, k, 1)
                 emit("be_unfold_fwd " + case, "gfla_block_extractor_fwd_f32", pa, time_fn(fn, args.iters))
                 gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
-                fn = lambda: _lib.call("gfla_block_extractor_unfold_bwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(outu), _lib.ptr(gs), _lib.ptr(gf), B, C, H, W, H, W, k)
+                fn = lambda: _lib.call("gfla_block_extractor_unfold_bwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(outu), _lib.ptr(gs), _lib.ptr(gf), B, C, H, W, H, W, k, 1)
                 emit("be_unfold_bwd " + case, "gfla_block_extractor_bwd_f32", ("ptr",) * 5 + (B, C, H, W, H, W, k), time_fn(fn, max(3, args.iters // 2)))
                 # the GEMM that consumes it (W: 128 x C*k*k)
                 wmat = torch.randn(128, C * k * k, device=DEV)
-                us = time_fn(lambda: torch.matmul(wmat, outu.view(B, C * k * k, H * W)), max(3, args.iters // 2))
+                us = time_fn(lambda: torch.mm(wmat, outu.view(C * k * k, B * H * W)), max(3, args.iters // 2))
                 fl = 2.0 * B * H * W * 128 * C * k * k
                 print(json.dumps({"case": "fc gemm on unfold " + case, "us": round(us, 1), "TFLOPs": round(fl / us / 1e6, 1)}), flush=True)
                 del outu, gs, gf, wmat
