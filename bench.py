@@ -144,6 +144,56 @@ def algorithmic_bytes(name, a, esz=4):
     return 0
 
 
+def pmc_traffic(entry, dims):
+    """HBM bytes per launch of the kernels behind one C-ABI call, from the committed rocprofv3 PMC
+    passes (profiles/pmc_traffic.json, made by tools/pmc_summary.py from separate --pmc FETCH_SIZE
+    / --pmc WRITE_SIZE runs of this bench; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction, so this is an upper bound).  None if no profile matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    base = entry.rsplit("_", 1)[0]
+    B, C = dims[0], dims[1]
+
+    def pick(name, want_write_bytes=None):
+        rows = table.get(name)
+        if not rows:
+            return None
+        if want_write_bytes is None or len(rows) == 1:
+            return rows[0]
+        return min(rows, key=lambda r: abs(r["WRITE_SIZE_KiB"] * 1024 - want_write_bytes))
+
+    names = None
+    if base == "gfla_block_extractor_unfold_fwd":
+        names = [("be_unfold_fwd_lds_kernel<float, %d>" % dims[6], None)]
+    elif base == "gfla_block_extractor_unfold_bwd":
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 2>" % dims[6], None)]
+    elif base == "gfla_block_extractor_bwd":
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 0>" % dims[6], None)]
+    elif base == "gfla_local_attn_aggregate_fwd":
+        names = [("agg_fwd_lds_kernel<float, %d>" % dims[6], None)]
+    elif base == "gfla_local_attn_aggregate_bwd":
+        k = dims[6]
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 1>" % k, None), ("agg_ga_lds_kernel<float, %d>" % k, None),
+                 ("agg_softmax_bwd_kernel<float, %d>" % k, None)]
+    elif base == "gfla_resample2d_fwd":
+        names = [("rs_lds_kernel<float, %d, 0>" % (dims[6] // 2), 4 * B * C * dims[4] * dims[5])]
+    elif base == "gfla_resample2d_bwd":
+        kh = dims[6] // 2
+        names = [("rs_lds_kernel<float, %d, 1>" % kh, 4 * B * C * dims[2] * dims[3]),
+                 ("rs_lds_kernel<float, %d, 2>" % kh, 4 * 3 * B * dims[4] * dims[5])]
+    if not names:
+        return None
+    total = 0
+    for name, want in names:
+        row = pick(name, want)
+        if row is None:
+            return None
+        total += row["traffic_bytes"]
+    return total
+
+
 class KernelTimer:
     """Brackets every C-ABI call with HIP events on the stream the kernels are launched on."""
 
@@ -280,7 +330,10 @@ def main():
                    "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world},
         "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],
-                     "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"], "traffic": None,
+                     "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"],
+                     "traffic": pmc_traffic(dom["entry"], dom["dims"]),
+                     "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
+                                       "of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
                      "timing": "HIP events around each C-ABI call on the launch stream, instrumented pass of the same %d steps" % args.steps},
         "kernels": rows,
     }
