@@ -52,7 +52,7 @@ template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     const T *__restrict__ attn, T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws,
-    int Hf, int Wf, int G, int ngroups, int split, int64_t u_cs, int64_t u_bs) {
+    int Hf, int Wf, int G, int ngroups, int split, int per, int margin, int64_t u_cs, int64_t u_bs) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   int bid = blockIdx.x;
@@ -63,17 +63,29 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
   const int c0 = g * G;
   const int gc = min(G, C - c0);
   const int plane_sz = Hs * Ws;
-  lds_acc_t *gplanes = reinterpret_cast<lds_acc_t *>(gfla_smem);                                   // [G][plane] double
-  A *splanes = reinterpret_cast<A *>(gfla_smem + (NEED_SRC ? sizeof(lds_acc_t) * (size_t)G * plane_sz : 0));  // [G][plane]
-  if (NEED_SRC) zero_planes<lds_acc_t>(gplanes, gc * plane_sz);
-  if (NEED_FLOW) stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, splanes, gc * plane_sz);
-  __syncthreads();
-
   const int Wo = K * Wf;
   const int HW = Hf * Wf;
-  const int per = (HW + split - 1) / split;
-  const int p_end = min(HW, (sp + 1) * per);
-  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+  const int p_begin = sp * per;
+  const int p_end = min(HW, p_begin + per);
+  if (p_begin >= p_end) return;
+  // source rows resident in LDS: the whole plane (margin < 0) or the window this band of flow rows
+  // reaches with |flow_y| <= margin
+  const Window win = make_window(p_begin / Wf, (p_end - 1) / Wf, K / 2, K - K / 2, margin, Hs);
+  const int win_sz = win.rows * Ws;
+  lds_acc_t *gplanes = reinterpret_cast<lds_acc_t *>(gfla_smem);                                          // [G][window] double
+  A *splanes = reinterpret_cast<A *>(gfla_smem + (NEED_SRC ? sizeof(lds_acc_t) * (size_t)G * win_sz : 0));  // [G][window]
+  const T *src0 = src + ((int64_t)b * C + c0) * plane_sz;
+  T *gsrc0 = NEED_SRC ? gsrc + ((int64_t)b * C + c0) * plane_sz : nullptr;
+  if (NEED_SRC) zero_planes<lds_acc_t>(gplanes, gc * win_sz);
+  if (NEED_FLOW)
+    for (int c = 0; c < gc; ++c)
+      stage_planes<T, A>(src0 + (int64_t)c * plane_sz + win.lo * Ws, splanes + (size_t)c * win_sz, win_sz);
+  __syncthreads();
+  // shifted bases: plane-relative offsets index the window
+  lds_acc_t *gplanes0 = gplanes - win.lo * Ws;
+  const A *splanes0 = splanes - win.lo * Ws;
+
+  for (int p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) {
     const int yf = p / Wf, xf = p - yf * Wf;
     const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
     const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
@@ -117,13 +129,47 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     gr.inv_kk = (A)1 / (A)(K * K);
 
     A gx_acc = 0, gy_acc = 0;
-    if (dense) {
+    // every row this pixel can touch (one row of slack covers the non-dense rounding case)
+    const bool inside = clampi(y0 - 1, 0, Hs - 1) >= win.lo && clampi(y0 + K + 1, 0, Hs - 1) < win.lo + win.rows;
+    if (!inside) {
+      // flow beyond the window's margin: this pixel alone takes the reference's decomposition on
+      // global memory (block_extractor_kernel.cu:123-168)
+      for (int c = 0; c < gc; ++c) {
+        const T *pl = src0 + (int64_t)c * plane_sz;
+        T *gp = NEED_SRC ? gsrc0 + (int64_t)c * plane_sz : nullptr;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+          const A fdy = floor_t<A>(dy);
+          const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
+          const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+          A gv[K];
+          gr.load(c, i, gv);
+#pragma unroll
+          for (int j = 0; j < K; ++j) {
+            const A xL_P = 1 - ax[j], xR_P = ax[j];
+            if (NEED_FLOW) {
+              const A vTL = Num<T>::ld(pl + yT + xL[j]), vTR = Num<T>::ld(pl + yT + xR[j]);
+              const A vBL = Num<T>::ld(pl + yB + xL[j]), vBR = Num<T>::ld(pl + yB + xR[j]);
+              gy_acc += gv[j] * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
+              gx_acc += gv[j] * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+            }
+            if (NEED_SRC) {
+              atomic_add(gp + yT + xL[j], (T)(gv[j] * xL_P * yT_P));
+              atomic_add(gp + yT + xR[j], (T)(gv[j] * xR_P * yT_P));
+              atomic_add(gp + yB + xL[j], (T)(gv[j] * xL_P * yB_P));
+              atomic_add(gp + yB + xR[j], (T)(gv[j] * xR_P * yB_P));
+            }
+          }
+        }
+      }
+    } else if (dense) {
       int col[K + 1];
 #pragma unroll
       for (int q = 0; q <= K; ++q) col[q] = clampi(x0 + q, 0, Ws - 1);
       for (int c = 0; c < gc; ++c) {
-        lds_acc_t *gp = gplanes + (size_t)c * plane_sz;
-        const A *spl = splanes + (size_t)c * plane_sz;
+        lds_acc_t *gp = gplanes0 + (size_t)c * win_sz;
+        const A *spl = splanes0 + (size_t)c * win_sz;
         A rowA[K + 1], vA[K + 1];
         int offA = clampi(y0, 0, Hs - 1) * Ws;
 #pragma unroll
@@ -180,8 +226,8 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       // a tap's floor() landed one off the dense patch (flow within rounding of an integer): the
       // reference's own tap-by-tap form, rolled
       for (int c = 0; c < gc; ++c) {
-        lds_acc_t *gp = gplanes + (size_t)c * plane_sz;
-        const A *spl = splanes + (size_t)c * plane_sz;
+        lds_acc_t *gp = gplanes0 + (size_t)c * win_sz;
+        const A *spl = splanes0 + (size_t)c * win_sz;
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
           const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
@@ -215,7 +261,10 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
   }
   if (NEED_SRC) {
     __syncthreads();
-    flush_planes<T>(gsrc + ((int64_t)b * C + c0) * plane_sz, gplanes, gc * plane_sz, split == 1);
+    // exclusive owner of the planes only when the whole plane is resident and not shared by bands
+    for (int c = 0; c < gc; ++c)
+      flush_planes<T>(gsrc0 + (int64_t)c * plane_sz + win.lo * Ws, gplanes + (size_t)c * win_sz, win_sz,
+                      split == 1 && margin < 0);
   }
 }
 
@@ -228,14 +277,17 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
   using A = typename Num<T>::acc;
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
-  PlaneGeo g = plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, true);
+  // the factored / unfold forms are only produced for planes that fit; the tensor form may window
+  PlaneGeo g = mode == kGoutTensor ? lds_geometry(Hs, Ws, bytes, B, C, Hf, Wf, K + 3)
+                                   : plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, true);
   if (g.G == 0) return GFLA_OK;
   const int64_t blocks = B * g.ngroups * g.split;
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), blk(kLdsThreads);
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
   be_bwd_lds_kernel<T, K, S, F, AT><<<grid, blk, g.lds_bytes, stream>>>(                             \
-      src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, u_cs, u_bs)
+      src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, g.per,   \
+      g.margin, u_cs, u_bs)
   if (mode == kGoutAttn) {
     if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutAttn);
     else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutAttn);

@@ -120,7 +120,7 @@ static int launch_fwd_rows(const T *src, const T *flow, T *out, int64_t B, int64
 template <typename T, int V>
 __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs,
-    int Ws, int Hf, int Wf, int k, int G, int ngroups, int split) {
+    int Ws, int Hf, int Wf, int k, int G, int ngroups, int split, int per, int margin) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   A *planes = reinterpret_cast<A *>(gfla_smem);
@@ -132,21 +132,28 @@ __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
   const int c0 = g * G;
   const int gc = min(G, C - c0);
   const int plane_sz = Hs * Ws;
-  stage_planes<T, A>(src + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
-  __syncthreads();
-
   const int Wo = k * Wf, Ho = k * Hf, WG = Wo / V;
   const int npos = Ho * WG;
-  const int per = (npos + split - 1) / split;
-  const int p_end = min(npos, (sp + 1) * per);
+  const int p_begin = sp * per;
+  const int p_end = min(npos, p_begin + per);
+  if (p_begin >= p_end) return;
+  // rows of the source plane this workgroup keeps in LDS (all of them when margin < 0)
+  const Window win = make_window((p_begin / WG) / k, ((p_end - 1) / WG) / k, k / 2, k - k / 2, margin, Hs);
+  const int win_sz = win.rows * Ws;
+  const T *gsrc0 = src + ((int64_t)b * C + c0) * plane_sz;
+  for (int c = 0; c < gc; ++c)
+    stage_planes<T, A>(gsrc0 + (int64_t)c * plane_sz + win.lo * Ws, planes + (size_t)c * win_sz, win_sz);
+  __syncthreads();
+  const A *lds0 = planes - win.lo * Ws;  // so that plane-relative offsets index the window
   const int64_t oplane_sz = (int64_t)Ho * Wo;
-  for (int pos = sp * per + threadIdx.x; pos < p_end; pos += blockDim.x) {
+  for (int pos = p_begin + threadIdx.x; pos < p_end; pos += blockDim.x) {
     const int y = pos / WG;
     const int x0 = (pos - y * WG) * V;
     const int yf = y / k;
     const int oy = (y - yf * k) - k / 2;
     int off[V][4];
     A w[V][4];
+    bool inside[V];
     const T *flow_x = flow + ((int64_t)(b * 2 + 0) * Hf + yf) * Wf;
     const T *flow_y = flow + ((int64_t)(b * 2 + 1) * Hf + yf) * Wf;
 #pragma unroll
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
       const int yB = clampi((int)(fdy + 1), 0, Hs - 1);
       const A xL_P = 1 - (dx - fdx), xR_P = dx - fdx;
       const A yT_P = 1 - (dy - fdy), yB_P = dy - fdy;
+      inside[e] = yT >= win.lo && yB < win.lo + win.rows;
       off[e][0] = yT * Ws + xL;
       off[e][1] = yT * Ws + xR;
       off[e][2] = yB * Ws + xL;
@@ -175,19 +183,28 @@ __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
       w[e][3] = xR_P * yB_P;
     }
     T *orow = out + ((int64_t)b * C + c0) * oplane_sz + (int64_t)y * Wo + x0;
-    const A *pl = planes;
+    const A *pl = lds0;
+    const T *gpl = gsrc0;
     for (int c = 0; c < gc; ++c) {
       Pack<T, V> r;
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        A s = w[e][0] * pl[off[e][0]];  // :78-84, same order of accumulation
-        s += w[e][1] * pl[off[e][1]];
-        s += w[e][2] * pl[off[e][2]];
-        s += w[e][3] * pl[off[e][3]];
+        A v0, v1, v2, v3;
+        if (inside[e]) {
+          v0 = pl[off[e][0]]; v1 = pl[off[e][1]]; v2 = pl[off[e][2]]; v3 = pl[off[e][3]];
+        } else {  // flow larger than the window's margin: this element gathers from global memory
+          v0 = Num<T>::ld(gpl + off[e][0]); v1 = Num<T>::ld(gpl + off[e][1]);
+          v2 = Num<T>::ld(gpl + off[e][2]); v3 = Num<T>::ld(gpl + off[e][3]);
+        }
+        A s = w[e][0] * v0;  // :78-84, same order of accumulation
+        s += w[e][1] * v1;
+        s += w[e][2] * v2;
+        s += w[e][3] * v3;
         r.v[e] = Num<T>::from(s);
       }
       *reinterpret_cast<Pack<T, V> *>(orow) = r;
-      pl += plane_sz;
+      pl += win_sz;
+      gpl += plane_sz;
       orow += oplane_sz;
     }
   }
@@ -199,13 +216,13 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
   using A = typename Num<T>::acc;
   const int variant = tuning(0);
   if (variant != 1) {
-    const int64_t npos = (k * Hf) * ((k * Wf) / V);
-    PlaneGeo g = plane_geometry(Hs * Ws, sizeof(A), B, C, npos, true);
+    // work items = output positions; one flow row = k output rows of (k*Wf)/V positions
+    PlaneGeo g = lds_geometry(Hs, Ws, sizeof(A), B, C, Hf, (int64_t)k * ((k * Wf) / V), k + 1);
     if (g.G > 0) {
       const int64_t blocks = B * g.ngroups * g.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       be_fwd_lds_kernel<T, V><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
-          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split);
+          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
       return launch_status();
     }
   }

@@ -32,16 +32,32 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
 struct PlaneGeo {
   int G;        // channels (planes) per workgroup; 0 = does not fit, use the global kernels
   int ngroups;  // ceil(C / G)
-  int split;    // workgroups sharing one (b, group): each takes 1/split of the positions
+  int split;    // workgroups sharing one (b, group): each takes `per` of the work items
   unsigned lds_bytes;
+  int per;      // work items (pixels / output positions) per workgroup
+  int margin;   // < 0: the whole plane is resident.  >= 0: only a ROW WINDOW of the plane is -- the
+                // rows a band of flow rows can reach when |flow_y| <= margin; lanes whose taps fall
+                // outside the window take the global-memory path for that pixel
 };
+
+// Source rows [lo, lo+rows) resident in LDS for the flow rows [yf_first, yf_last] of a workgroup whose
+// taps span yf - k_lo .. yf + k_hi before the flow is added.
+struct Window {
+  int lo, rows;
+};
+__device__ __forceinline__ Window make_window(int yf_first, int yf_last, int k_lo, int k_hi, int margin, int H) {
+  if (margin < 0) return Window{0, H};
+  const int lo = max(0, yf_first - k_lo - margin);
+  const int hi = min(H, yf_last + k_hi + 1 + margin);
+  return Window{lo, max(hi - lo, 0)};
+}
 
 // plane_elems: elements of one plane; bytes_per_elem: LDS bytes one channel needs per plane element
 // (sizeof(arithmetic type) for a gather plane, 8 for a scatter plane, their sum for both);
 // work_items: positions one (b, group) iterates over.
 inline PlaneGeo plane_geometry(int64_t plane_elems, int bytes_per_elem, int64_t B, int64_t C,
                                int64_t work_items, bool allow_split) {
-  PlaneGeo g{0, 0, 1, 0};
+  PlaneGeo g{0, 0, 1, 0, 0, -1};
   const int64_t per_channel = plane_elems * bytes_per_elem;
   if (per_channel > kLdsBudget) return g;
   int64_t G = kLdsBudget / per_channel;
@@ -58,8 +74,45 @@ inline PlaneGeo plane_geometry(int64_t plane_elems, int bytes_per_elem, int64_t 
   }
   if (tuning(5) > 0) split = tuning(5);
   g.split = split;
+  g.per = (int)ceil_div(work_items, split);
   g.lds_bytes = (unsigned)(G * per_channel);
   return g;
+}
+
+// Planes too large for LDS (e.g. 256x176): keep a row WINDOW per workgroup instead.  A workgroup
+// takes a band of `hb` flow rows (items_per_row work items each); the window holds the band plus
+// k+1 tap rows plus `margin` = hb rows of slack on either side for the flow, so flows up to ~hb
+// pixels stay in LDS and larger ones degrade gracefully (per pixel) to the global-memory path.
+// Returns G = 0 when even one row band of one channel does not fit.
+inline PlaneGeo band_geometry(int64_t H, int64_t W, int bytes_per_elem, int64_t B, int64_t C, int64_t Hf,
+                              int64_t items_per_row, int k_span) {
+  PlaneGeo g{0, 0, 1, 0, 0, -1};
+  const int64_t row_bytes = W * bytes_per_elem;
+  int64_t G = C < 4 ? C : 4;
+  int64_t cap = 0, hb = 0;
+  for (; G >= 1; G /= 2) {
+    cap = kLdsBudget / (row_bytes * G);  // window rows that fit
+    hb = (cap - k_span) / 3;             // band + 2 * margin(= band) + tap span <= cap
+    if (hb >= 2 || (G == 1 && hb >= 1)) break;
+  }
+  if (G < 1 || hb < 1) return g;
+  if (hb > Hf) hb = Hf;
+  g.G = (int)G;
+  g.ngroups = (int)ceil_div(C, G);
+  g.split = (int)ceil_div(Hf, hb);
+  g.per = (int)(hb * items_per_row);
+  g.margin = (int)((cap - k_span - hb) / 2);
+  g.lds_bytes = (unsigned)(cap * row_bytes * G);
+  return g;
+}
+
+// Either the whole plane (plane_geometry) or a row window (band_geometry).
+inline PlaneGeo lds_geometry(int64_t H, int64_t W, int bytes_per_elem, int64_t B, int64_t C, int64_t Hf,
+                             int64_t items_per_row, int k_span) {
+  PlaneGeo g = plane_geometry(H * W, bytes_per_elem, B, C, Hf * items_per_row, true);
+  if (g.G > 0) return g;
+  if (tuning(7) == 1) return g;  // windows disabled
+  return band_geometry(H, W, bytes_per_elem, B, C, Hf, items_per_row, k_span);
 }
 
 // global (n contiguous storage elements) -> LDS (arithmetic type), all threads of the block

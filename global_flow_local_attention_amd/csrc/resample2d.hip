@@ -299,7 +299,8 @@ template <typename T, int KH, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
                                                             const T *__restrict__ gout, T *__restrict__ outp,
                                                             int C, int Hi, int Wi, int H, int W, int dil,
-                                                            int trunc, int G, int ngroups, int split) {
+                                                            int trunc, int G, int ngroups, int split, int per,
+                                                            int margin) {
   using A = typename Num<T>::acc;
   using PT = typename std::conditional<MODE == 1, lds_acc_t, A>::type;  // scatter planes are double
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
@@ -312,27 +313,51 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   const int c0 = g * G;
   const int gc = min(G, C - c0);
   const int plane_sz = Hi * Wi;
-  if constexpr (MODE == 1)
-    zero_planes<PT>(planes, gc * plane_sz);
-  else
-    stage_planes<T, PT>(in1 + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz);
-  __syncthreads();
   const int HW = H * W;
-  const int per = (HW + split - 1) / split;
-  const int p_end = min(HW, (sp + 1) * per);
-  for (int p = sp * per + threadIdx.x; p < p_end; p += blockDim.x) {
+  const int p_begin = sp * per;
+  const int p_end = min(HW, p_begin + per);
+  if (p_begin >= p_end) return;
+  // rows of the input1 plane resident in LDS: all (margin < 0) or the window this band of pixel rows
+  // reaches with |dy| <= margin
+  const Window win = make_window(p_begin / W, (p_end - 1) / W, (KH - 1) * dil, KH * dil, margin, Hi);
+  const int win_sz = win.rows * Wi;
+  const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
+  if constexpr (MODE == 1) {
+    zero_planes<PT>(planes, gc * win_sz);
+  } else {
+    for (int c = 0; c < gc; ++c)
+      stage_planes<T, PT>(in1_0 + (int64_t)c * plane_sz + win.lo * Wi, planes + (size_t)c * win_sz, win_sz);
+  }
+  __syncthreads();
+  PT *planes0 = planes - win.lo * Wi;  // plane-relative offsets index the window
+  const int lo_off = win.lo * Wi, hi_off = (win.lo + win.rows) * Wi;
+  for (int p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) {
     const int y = p / W, x = p - y * W;
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
     Taps<A, KH> t;
     t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
                           MODE == 1 && trunc != 0);
+    // outermost taps bound the rows this pixel touches; beyond the window it uses global memory
+    const bool inside = t.yT[KH - 1] >= lo_off && t.yB[KH - 1] < hi_off;
     if constexpr (MODE == 0) {
-      rs_fwd_pixel<T, A, KH, A>(t, planes, plane_sz, outp + ((int64_t)b * C + c0) * HW + p, HW, gc);
+      T *o = outp + ((int64_t)b * C + c0) * HW + p;
+      if (inside)
+        rs_fwd_pixel<T, A, KH, A>(t, planes0, win_sz, o, HW, gc);
+      else
+        rs_fwd_pixel<T, T, KH, A>(t, in1_0, plane_sz, o, HW, gc);
     } else if constexpr (MODE == 1) {
-      rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, gout + ((int64_t)b * C + c0) * HW + p, HW, planes, plane_sz, gc);
+      const T *go = gout + ((int64_t)b * C + c0) * HW + p;
+      if (inside)
+        rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, go, HW, planes0, win_sz, gc);
+      else
+        rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc);
     } else {
       A rx, ry, rs;
-      rs_bwd2_pixel<T, A, KH, A>(t, planes, plane_sz, gout + ((int64_t)b * C + c0) * HW + p, HW, gc, rx, ry, rs);
+      const T *go = gout + ((int64_t)b * C + c0) * HW + p;
+      if (inside)
+        rs_bwd2_pixel<T, A, KH, A>(t, planes0, win_sz, go, HW, gc, rx, ry, rs);
+      else
+        rs_bwd2_pixel<T, T, KH, A>(t, in1_0, plane_sz, go, HW, gc, rx, ry, rs);
       T *o = outp + (int64_t)b * 3 * HW + p;
       atomic_add(o, (T)rx);
       atomic_add(o + HW, (T)ry);
@@ -341,7 +366,9 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   }
   if constexpr (MODE == 1) {
     __syncthreads();
-    flush_planes<T>(outp + ((int64_t)b * C + c0) * plane_sz, planes, gc * plane_sz, split == 1);
+    for (int c = 0; c < gc; ++c)
+      flush_planes<T>(outp + ((int64_t)b * C + c0 + c) * plane_sz + win.lo * Wi, planes + (size_t)c * win_sz, win_sz,
+                      split == 1 && margin < 0);
   }
 }
 
@@ -387,12 +414,12 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   if (tuning(6) != 1) {
-    PlaneGeo pg = plane_geometry(Hi * Wi, sizeof(A), B, C, H * W, true);
+    PlaneGeo pg = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1);
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 0><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                                in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split));
+                                in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
       return launch_status();
     }
   }
@@ -411,14 +438,14 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
   if (!gout) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
-  PlaneGeo pg1 = plane_geometry(Hi * Wi, sizeof(lds_acc_t), B, C, H * W, true);  // double scatter planes
-  PlaneGeo pg2 = plane_geometry(Hi * Wi, sizeof(A), B, C, H * W, true);          // gather planes
+  PlaneGeo pg1 = lds_geometry(Hi, Wi, sizeof(lds_acc_t), B, C, H, W, (k - 1) * dil + 1);  // double scatter planes
+  PlaneGeo pg2 = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1);          // gather planes
   if (tuning(6) != 1 && pg1.G > 0 && pg2.G > 0) {
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 1><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(
-                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split));
+                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
@@ -426,7 +453,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
       const int64_t blocks = B * pg2.ngroups * pg2.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 2><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(
-                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split));
+                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
       st = launch_status();
     }
     return st;

@@ -33,10 +33,10 @@ def kernel_variant(request, gfla):
     """Every test runs twice: default dispatch (planes in LDS where they fit) and with the
     global-memory kernels forced (tuning keys 0,2,3,6 of include/gfla_hip.h)."""
     force = 1 if request.param == "global" else 0
-    for key in (0, 2, 3, 6):
+    for key in (0, 2, 3, 6, 7):
         gfla.set_tuning(key, force)
     yield request.param
-    for key in (0, 2, 3, 6):
+    for key in (0, 2, 3, 6, 7):
         gfla.set_tuning(key, 0)
 
 
@@ -327,6 +327,42 @@ def test_extractor_attn_fused_equals_unfused_and_oracle(gfla, oracle, k, C, soft
                                          fc[2].weight.detach().cpu(), fc[2].bias.detach().cpu(), k, 0.1)
         assert_close(out_u.detach().cpu(), want, 2e-5, "unfused vs CPU oracle")
         assert_close(out_f.detach().cpu(), want, 2e-5, "fused vs CPU oracle")
+
+
+# ------------------------------------------------------ planes larger than LDS: row windows + outliers
+@pytest.mark.parametrize("kind,scale", [("smooth", 1.0), ("wild", 1.0), ("wild", 6.0)])
+@pytest.mark.parametrize("k", [3, 5])
+def test_windowed_planes_with_outlier_flows(gfla, oracle, kind, scale, k):
+    # 200x120 floats = 96 KB per plane: does not fit the 64 KB LDS budget, so the kernels keep a row
+    # window per band of flow rows; flows beyond the window margin (scale 6 -> +-50 px) must take the
+    # per-pixel global path and still match.
+    B, C, H, W = 1, 3, 200, 120
+    s = randn((B, C, H, W), seed=60)
+    f = (make_flow(kind, B, H, W, seed=61) * scale).contiguous()
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, fd)
+    assert_close(out.cpu(), oracle.block_extractor_fwd(s, f, k), F32_FWD, "windowed fwd")
+    g = randn(tuple(out.shape), seed=62)
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(s, f, g, k)
+    assert_close(sd.grad.cpu(), gs, F32_GRAD, "windowed grad_source")
+    assert_close(fd.grad.cpu(), gf, F32_GRAD, "windowed grad_flow")
+
+
+@pytest.mark.parametrize("scale", [1.0, 6.0])
+def test_windowed_resample2d(gfla, oracle, scale):
+    B, C, H, W = 1, 5, 200, 120
+    i1 = randn((B, C, H, W), seed=63)
+    fl = (make_flow("wild", B, H, W, seed=64) * scale).contiguous()
+    i1d, fld = i1.to(DEV).requires_grad_(), fl.to(DEV).requires_grad_()
+    out = gfla.Resample2d(4, 1, 2)(i1d, fld)
+    i2 = torch.cat((fl, torch.full((B, 1, H, W), 2.0)), 1).contiguous()
+    assert_close(out.cpu(), oracle.resample2d_fwd(i1, i2, 4, 1), 4e-6, "windowed resample fwd")
+    g = randn(tuple(out.shape), seed=65)
+    out.backward(g.to(DEV))
+    g1, g2 = oracle.resample2d_bwd(i1, i2, g, 4, 1)
+    assert_close(i1d.grad.cpu(), g1, F32_GRAD, "windowed resample grad_input1")
+    assert_close(fld.grad.cpu(), g2[:, :2], 1e-4, "windowed resample grad_flow")
 
 
 # ------------------------------------------------------------------------------- BASELINE sizes
