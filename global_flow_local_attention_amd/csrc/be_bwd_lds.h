@@ -48,7 +48,7 @@ struct GoutRow {
   }
 };
 
-template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE>
+template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     const T *__restrict__ attn, T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
   if (p_begin >= p_end) return;
   // source rows resident in LDS: the whole plane (margin < 0) or the window this band of flow rows
   // reaches with |flow_y| <= margin
-  const Window win = make_window(p_begin / Wf, (p_end - 1) / Wf, K / 2, K - K / 2, margin, Hs);
+  const Window win = make_window(p_begin / Wf, (p_end - 1) / Wf, K / 2, K - K / 2, WIN ? margin : -1, Hs);
   const int win_sz = win.rows * Ws;
   lds_acc_t *gplanes = reinterpret_cast<lds_acc_t *>(gfla_smem);                                          // [G][window] double
   A *splanes = reinterpret_cast<A *>(gfla_smem + (NEED_SRC ? sizeof(lds_acc_t) * (size_t)G * win_sz : 0));  // [G][window]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
 
     A gx_acc = 0, gy_acc = 0;
     // every row this pixel can touch (one row of slack covers the non-dense rounding case)
-    const bool inside = clampi(y0 - 1, 0, Hs - 1) >= win.lo && clampi(y0 + K + 1, 0, Hs - 1) < win.lo + win.rows;
+    const bool inside = !WIN || (clampi(y0 - 1, 0, Hs - 1) >= win.lo && clampi(y0 + K + 1, 0, Hs - 1) < win.lo + win.rows);
     if (!inside) {
       // flow beyond the window's margin: this pixel alone takes the reference's decomposition on
       // global memory (block_extractor_kernel.cu:123-168)
@@ -285,7 +285,12 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), blk(kLdsThreads);
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
-  be_bwd_lds_kernel<T, K, S, F, AT><<<grid, blk, g.lds_bytes, stream>>>(                             \
+  if (AT == kGoutTensor && g.margin >= 0)                                                            \
+    be_bwd_lds_kernel<T, K, S, F, kGoutTensor, true><<<grid, blk, g.lds_bytes, stream>>>(            \
+        src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split,   \
+        g.per, g.margin, u_cs, u_bs);                                                                \
+  else                                                                                               \
+    be_bwd_lds_kernel<T, K, S, F, AT, false><<<grid, blk, g.lds_bytes, stream>>>(                    \
       src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, g.per,   \
       g.margin, u_cs, u_bs)
   if (mode == kGoutAttn) {

@@ -117,7 +117,7 @@ static int launch_fwd_rows(const T *src, const T *flow, T *out, int64_t B, int64
 // output, one 16-byte store per channel.  HBM sees only the minimum traffic: source once,
 // output once.
 // ----------------------------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs,
     int Ws, int Hf, int Wf, int k, int G, int ngroups, int split, int per, int margin) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
   const int p_end = min(npos, p_begin + per);
   if (p_begin >= p_end) return;
   // rows of the source plane this workgroup keeps in LDS (all of them when margin < 0)
-  const Window win = make_window((p_begin / WG) / k, ((p_end - 1) / WG) / k, k / 2, k - k / 2, margin, Hs);
+  const Window win = make_window((p_begin / WG) / k, ((p_end - 1) / WG) / k, k / 2, k - k / 2, WIN ? margin : -1, Hs);
   const int win_sz = win.rows * Ws;
   const T *gsrc0 = src + ((int64_t)b * C + c0) * plane_sz;
   for (int c = 0; c < gc; ++c)
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kLdsThreads) void be_fwd_lds_kernel(
       const int yB = clampi((int)(fdy + 1), 0, Hs - 1);
       const A xL_P = 1 - (dx - fdx), xR_P = dx - fdx;
       const A yT_P = 1 - (dy - fdy), yB_P = dy - fdy;
-      inside[e] = yT >= win.lo && yB < win.lo + win.rows;
+      inside[e] = !WIN || (yT >= win.lo && yB < win.lo + win.rows);
       off[e][0] = yT * Ws + xL;
       off[e][1] = yT * Ws + xR;
       off[e][2] = yB * Ws + xL;
@@ -221,8 +221,12 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
     if (g.G > 0) {
       const int64_t blocks = B * g.ngroups * g.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      be_fwd_lds_kernel<T, V><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
-          src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
+      if (g.margin < 0)
+        be_fwd_lds_kernel<T, V, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+            src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
+      else
+        be_fwd_lds_kernel<T, V, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+            src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
       return launch_status();
     }
   }

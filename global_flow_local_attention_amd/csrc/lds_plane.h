@@ -93,7 +93,8 @@ inline PlaneGeo band_geometry(int64_t H, int64_t W, int bytes_per_elem, int64_t 
   for (; G >= 1; G /= 2) {
     cap = kLdsBudget / (row_bytes * G);  // window rows that fit
     hb = (cap - k_span) / 3;             // band + 2 * margin(= band) + tap span <= cap
-    if (hb >= 2 || (G == 1 && hb >= 1)) break;
+    // fewer channels per workgroup rather than a margin real flows (a few pixels) overflow
+    if ((hb >= 2 && (cap - k_span - hb) / 2 >= 6) || (G == 1 && hb >= 1)) break;
   }
   if (G < 1 || hb < 1) return g;
   if (hb > Hf) hb = Hf;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ i
 // ---- LDS-plane kernels: workgroup <-> (b, group of G channels[, 1/split of the pixels]) ----------
 // MODE 0 forward (source planes staged), 1 d/d input1 (gradient planes accumulated in LDS, flushed
 // once), 2 d/d input2 (source planes staged, three atomics per lane and group).
-template <typename T, int KH, int MODE>
+template <typename T, int KH, int MODE, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
                                                             const T *__restrict__ gout, T *__restrict__ outp,
                                                             int C, int Hi, int Wi, int H, int W, int dil,
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   if (p_begin >= p_end) return;
   // rows of the input1 plane resident in LDS: all (margin < 0) or the window this band of pixel rows
   // reaches with |dy| <= margin
-  const Window win = make_window(p_begin / W, (p_end - 1) / W, (KH - 1) * dil, KH * dil, margin, Hi);
+  const Window win = make_window(p_begin / W, (p_end - 1) / W, (KH - 1) * dil, KH * dil, WIN ? margin : -1, Hi);
   const int win_sz = win.rows * Wi;
   const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
   if constexpr (MODE == 1) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
                           MODE == 1 && trunc != 0);
     // outermost taps bound the rows this pixel touches; beyond the window it uses global memory
-    const bool inside = t.yT[KH - 1] >= lo_off && t.yB[KH - 1] < hi_off;
+    const bool inside = !WIN || (t.yT[KH - 1] >= lo_off && t.yB[KH - 1] < hi_off);
     if constexpr (MODE == 0) {
       T *o = outp + ((int64_t)b * C + c0) * HW + p;
       if (inside)
@@ -418,8 +418,8 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 0><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
-                                in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg.margin < 0) rs_lds_kernel<T, KH, 0, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin);
+                                else rs_lds_kernel<T, KH, 0, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
       return launch_status();
     }
   }
@@ -444,16 +444,16 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 1><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(
-                                in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) rs_lds_kernel<T, KH, 1, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin);
+                                else rs_lds_kernel<T, KH, 1, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
     if (gin2) {
       const int64_t blocks = B * pg2.ngroups * pg2.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, rs_lds_kernel<T, KH, 2><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(
-                                in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) rs_lds_kernel<T, KH, 2, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin);
+                                else rs_lds_kernel<T, KH, 2, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
       st = launch_status();
     }
     return st;
