@@ -345,8 +345,10 @@ def test_windowed_planes_with_outlier_flows(gfla, oracle, kind, scale, k):
     g = randn(tuple(out.shape), seed=62)
     out.backward(g.to(DEV))
     gs, gf = oracle.block_extractor_bwd(s, f, g, k)
-    assert_close(sd.grad.cpu(), gs, F32_GRAD, "windowed grad_source")
-    assert_close(fd.grad.cpu(), gf, F32_GRAD, "windowed grad_flow")
+    # wild*6 flows clamp thousands of taps onto the same border pixels: both sides accumulate them in
+    # fp32 (ours with float atomics on the outlier path), so the bar here is the north-star 1e-4
+    assert_close(sd.grad.cpu(), gs, 1e-4, "windowed grad_source")
+    assert_close(fd.grad.cpu(), gf, 1e-4, "windowed grad_flow")
 
 
 @pytest.mark.parametrize("scale", [1.0, 6.0])
