@@ -104,6 +104,13 @@ def algorithmic_bytes(name, a, esz=4):
         base, a = "gfla_block_extractor_fwd", a[:10]
     if base == "gfla_block_extractor_unfold_bwd":
         base, a = "gfla_block_extractor_bwd", a[:12]
+    if base == "gfla_local_attn_source_bwd":  # (src, flow, gunf, attn, gout, gs, gf, B, C, Hs, Ws, H, W, k, layout)
+        B, C, Hs, Ws, H, W, k = a[7:14]
+        n = B * C * Hs * Ws + 2 * B * H * W
+        n += B * C * k * k * H * W if a[2] is not None else 0
+        n += (B * k * k * H * W + B * C * H * W) if a[3] is not None else 0
+        n += (B * C * Hs * Ws if a[5] is not None else 0) + (2 * B * H * W if a[6] is not None else 0)
+        return esz * n
     if base == "gfla_block_extractor_fwd":
         B, C, Hs, Ws, Hf, Wf, k = a[3:10]
         return esz * (B * C * Hs * Ws + 2 * B * Hf * Wf + B * C * k * k * Hf * Wf)
@@ -144,7 +151,7 @@ def algorithmic_bytes(name, a, esz=4):
     return 0
 
 
-def pmc_traffic(entry, dims):
+def pmc_traffic(entry, dims, ptrs=""):
     """HBM bytes per launch of the kernels behind one C-ABI call, from the committed rocprofv3 PMC
     passes (profiles/pmc_traffic.json, made by tools/pmc_summary.py from separate --pmc FETCH_SIZE
     / --pmc WRITE_SIZE runs of this bench; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
@@ -157,7 +164,7 @@ def pmc_traffic(entry, dims):
     B, C = dims[0], dims[1]
 
     def pick(name, want_write_bytes=None):
-        rows = table.get(name)
+        rows = [r for key, rs in table.items() if key.startswith(name) for r in rs]
         if not rows:
             return None
         if want_write_bytes is None or len(rows) == 1:
@@ -168,21 +175,24 @@ def pmc_traffic(entry, dims):
     if base == "gfla_block_extractor_unfold_fwd":
         names = [("be_unfold_fwd_lds_kernel<float, %d>" % dims[6], None)]
     elif base == "gfla_block_extractor_unfold_bwd":
-        names = [("be_bwd_lds_kernel<float, %d, true, true, 2>" % dims[6], None)]
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 2" % dims[6], None)]
     elif base == "gfla_block_extractor_bwd":
-        names = [("be_bwd_lds_kernel<float, %d, true, true, 0>" % dims[6], None)]
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 0" % dims[6], None)]
+    elif base == "gfla_local_attn_source_bwd":
+        names = [("be_bwd_lds_kernel<float, %d, true, true, 3" % dims[6], None)]
     elif base == "gfla_local_attn_aggregate_fwd":
         names = [("agg_fwd_lds_kernel<float, %d>" % dims[6], None)]
     elif base == "gfla_local_attn_aggregate_bwd":
         k = dims[6]
-        names = [("be_bwd_lds_kernel<float, %d, true, true, 1>" % k, None), ("agg_ga_lds_kernel<float, %d>" % k, None),
-                 ("agg_softmax_bwd_kernel<float, %d>" % k, None)]
+        names = [("agg_ga_lds_kernel<float, %d>" % k, None), ("agg_softmax_bwd_kernel<float, %d>" % k, None)]
+        if ptrs[4:6] != "00":  # grad_source / grad_flow computed here (not parked for the fused pass)
+            names.append(("be_bwd_lds_kernel<float, %d, true, true, 1" % k, None))
     elif base == "gfla_resample2d_fwd":
-        names = [("rs_lds_kernel<float, %d, 0>" % (dims[6] // 2), 4 * B * C * dims[4] * dims[5])]
+        names = [("rs_lds_kernel<float, %d, 0" % (dims[6] // 2), 4 * B * C * dims[4] * dims[5])]
     elif base == "gfla_resample2d_bwd":
         kh = dims[6] // 2
-        names = [("rs_lds_kernel<float, %d, 1>" % kh, 4 * B * C * dims[2] * dims[3]),
-                 ("rs_lds_kernel<float, %d, 2>" % kh, 4 * 3 * B * dims[4] * dims[5])]
+        names = [("rs_lds_kernel<float, %d, 1" % kh, 4 * B * C * dims[2] * dims[3]),
+                 ("rs_lds_kernel<float, %d, 2" % kh, 4 * 3 * B * dims[4] * dims[5])]
     if not names:
         return None
     total = 0
@@ -225,15 +235,17 @@ class KernelTimer:
         torch.cuda.synchronize()
         agg = {}
         for name, args, e0, e1 in self.records:
-            key = (name,) + tuple(x for x in args if isinstance(x, int))
-            ent = agg.setdefault(key, {"name": name, "calls": 0, "ms": 0.0, "bytes": algorithmic_bytes(name, args)})
+            ptrs = "".join("0" if x is None else "1" for x in args if not isinstance(x, int))
+            key = (name, ptrs) + tuple(x for x in args if isinstance(x, int))
+            ent = agg.setdefault(key, {"name": name, "ptrs": ptrs, "calls": 0, "ms": 0.0,
+                                       "bytes": algorithmic_bytes(name, args)})
             ent["calls"] += 1
             ent["ms"] += e0.elapsed_time(e1)
         rows = []
         for key, ent in agg.items():
             avg_ms = ent["ms"] / ent["calls"]
             gbs = ent["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            rows.append({"entry": ent["name"], "dims": list(key[1:]), "calls": ent["calls"],
+            rows.append({"entry": ent["name"], "dims": list(key[2:]), "ptrs": ent["ptrs"], "calls": ent["calls"],
                          "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ent["ms"], 3),
                          "alg_MB": round(ent["bytes"] / 1e6, 3), "GBps": round(gbs, 1),
                          "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
@@ -331,7 +343,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],
                      "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"],
-                     "traffic": pmc_traffic(dom["entry"], dom["dims"]),
+                     "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"]),
                      "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
                                        "of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
                      "timing": "HIP events around each C-ABI call on the launch stream, instrumented pass of the same %d steps" % args.steps},

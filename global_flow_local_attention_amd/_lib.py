@@ -28,9 +28,10 @@ _SIGNATURES = {
     "gfla_resample2d_bwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _int, _ptr],
     "gfla_local_attn_aggregate_fwd": [_ptr] * 5 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_local_attn_source_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
 }
 _FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
-                  "gfla_local_attn_aggregate_bwd"}
+                  "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}
 
 
 def exported_symbols():

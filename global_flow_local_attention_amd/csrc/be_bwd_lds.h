@@ -18,7 +18,10 @@ namespace gfla {
 // MODE 0: gout is the reference-layout tensor (B,C,K*Hf,K*Wf)
 // MODE 1: gout is (B,C,Hf,Wf) and the gradient is attn[b,ij,p] * gout[b,c,p] / K^2 (never materialised)
 // MODE 2: gout is in "unfold" layout (B, C*K*K, Hf, Wf), channel index c*K*K + i*K + j
-constexpr int kGoutTensor = 0, kGoutAttn = 1, kGoutUnfold = 2;
+// MODE 3: the SUM of an unfold-layout gradient (gout) and a factored one (attn, gout2): both gradient
+//         streams that reach block_source inside ExtractorAttn -- through the FC layer and through
+//         the attention-weighted aggregation -- scattered in ONE pass over the taps.
+constexpr int kGoutTensor = 0, kGoutAttn = 1, kGoutUnfold = 2, kGoutUnfoldAttn = 3;
 template <typename T, int K, int MODE>
 struct GoutRow {
   using A = typename Num<T>::acc;
@@ -26,13 +29,20 @@ struct GoutRow {
   // attention form: attn_p = &attn[b, 0, p] (channel pitch HW), go_p = &gout[b, c0, p] (pitch HW)
   const T *base;
   const T *attn_p;
+  const T *base2;  // MODE 3: &gout2[b, c0, p]
   int64_t cstride;
   int pitch;
   int HW;
   A inv_kk;
 
   __device__ __forceinline__ void load(int c, int i, A (&g)[K]) const {
-    if constexpr (MODE == kGoutAttn) {
+    if constexpr (MODE == kGoutUnfoldAttn) {
+      const A go = Num<T>::ld(base2 + (int64_t)c * HW) * inv_kk;
+      const T *r = base + ((int64_t)c * K * K + i * K) * cstride;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        g[j] = Num<T>::ld(r + (int64_t)j * cstride) + Num<T>::ld(attn_p + (int64_t)(i * K + j) * HW) * go;
+    } else if constexpr (MODE == kGoutAttn) {
       const A go = Num<T>::ld(base + (int64_t)c * cstride) * inv_kk;
 #pragma unroll
       for (int j = 0; j < K; ++j) g[j] = Num<T>::ld(attn_p + (int64_t)(i * K + j) * HW) * go;
@@ -51,8 +61,9 @@ struct GoutRow {
 template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    const T *__restrict__ attn, T *__restrict__ gsrc, T *__restrict__ gflow, int C, int Hs, int Ws,
-    int Hf, int Wf, int G, int ngroups, int split, int per, int margin, int64_t u_cs, int64_t u_bs) {
+    const T *__restrict__ attn, const T *__restrict__ gout2, T *__restrict__ gsrc, T *__restrict__ gflow,
+    int C, int Hs, int Ws, int Hf, int Wf, int G, int ngroups, int split, int per, int margin, int64_t u_cs,
+    int64_t u_bs) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   int bid = blockIdx.x;
@@ -109,7 +120,14 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       ax[t] = dx - fdx;
     }
     GoutRow<T, K, MODE> gr;
-    if constexpr (MODE == kGoutAttn) {
+    gr.base2 = nullptr;
+    if constexpr (MODE == kGoutUnfoldAttn) {
+      gr.base = gout + (int64_t)b * u_bs + (int64_t)c0 * K * K * u_cs + p;
+      gr.attn_p = attn + (int64_t)b * K * K * HW + p;
+      gr.base2 = gout2 + ((int64_t)b * C + c0) * HW + p;
+      gr.cstride = u_cs;
+      gr.pitch = 0;
+    } else if constexpr (MODE == kGoutAttn) {
       gr.base = gout + ((int64_t)b * C + c0) * HW + p;
       gr.attn_p = attn + (int64_t)b * K * K * HW + p;
       gr.cstride = HW;
@@ -273,7 +291,8 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
 template <typename T, int K>
 static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gout, const T *attn, T *gsrc,
                              T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
-                             hipStream_t stream, bool *done, int64_t u_cs = 0, int64_t u_bs = 0) {
+                             hipStream_t stream, bool *done, int64_t u_cs = 0, int64_t u_bs = 0,
+                             const T *gout2 = nullptr) {
   using A = typename Num<T>::acc;
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
@@ -287,13 +306,17 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
   if (AT == kGoutTensor && g.margin >= 0)                                                            \
     be_bwd_lds_kernel<T, K, S, F, kGoutTensor, true><<<grid, blk, g.lds_bytes, stream>>>(            \
-        src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split,   \
-        g.per, g.margin, u_cs, u_bs);                                                                \
+        src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups,     \
+        g.split, g.per, g.margin, u_cs, u_bs);                                                       \
   else                                                                                               \
     be_bwd_lds_kernel<T, K, S, F, AT, false><<<grid, blk, g.lds_bytes, stream>>>(                    \
-      src, flow, gout, attn, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, g.per,   \
-      g.margin, u_cs, u_bs)
-  if (mode == kGoutAttn) {
+      src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split,   \
+      g.per, g.margin, u_cs, u_bs)
+  if (mode == kGoutUnfoldAttn) {
+    if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutUnfoldAttn);
+    else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutUnfoldAttn);
+    else GFLA_BE_BWD_LAUNCH(false, true, kGoutUnfoldAttn);
+  } else if (mode == kGoutAttn) {
     if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutAttn);
     else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutAttn);
     else GFLA_BE_BWD_LAUNCH(false, true, kGoutAttn);

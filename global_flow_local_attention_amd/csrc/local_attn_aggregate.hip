@@ -631,6 +631,31 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
   return launch_status();
 }
 
+// Backward of everything in ExtractorAttn that flows into block_source(source, flow): the gradient of
+// the unfold-layout FC operand (grad_unfold, may be NULL) plus the attention-weighted aggregation's
+// (attn, grad_out; may be NULL), scattered into grad_source / grad_flow in one pass.
+template <typename T>
+static int local_attn_source_bwd(const T *src, const T *flow, const T *gunf, const T *attn, const T *gout,
+                                 T *gsrc, T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                 int64_t W, int k, int layout, gfla_stream_t stream_) {
+  using A = typename Num<T>::acc;
+  if (!src || !flow || (!gunf && !(attn && gout)) || ((attn == nullptr) != (gout == nullptr))) return GFLA_ERR_NULL_POINTER;
+  int st = agg_check(B, C, Hs, Ws, H, W, k);
+  if (st != GFLA_OK) return st;
+  if (Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) > kLdsBudget) return GFLA_ERR_UNSUPPORTED;
+  if (!gsrc && !gflow) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t HW = H * W;
+  const int64_t cs = layout == 1 ? B * HW : HW;
+  const int64_t bs = layout == 1 ? HW : C * k * k * HW;
+  const int mode = gunf ? (attn ? kGoutUnfoldAttn : kGoutUnfold) : kGoutAttn;
+  bool done = false;
+  GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(mode, src, flow, gunf ? gunf : gout, attn, gsrc, gflow, B, C, Hs, Ws, H, W,
+                                                stream, &done, cs, bs, gout));
+  if (st == GFLA_OK && !done) st = GFLA_ERR_UNSUPPORTED;
+  return st;
+}
+
 }  // namespace gfla
 
 using gfla::bf16_t;
@@ -663,5 +688,15 @@ int gfla_local_attn_aggregate_bwd_f64(const double *s, const double *f, const do
                                       int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm,
                                       gfla_stream_t st) {
   return gfla::aggregate_bwd<double>(s, f, a, go, gs, gf, gl, B, C, Hs, Ws, H, W, k, sm, st);
+}
+int gfla_local_attn_source_bwd_f32(const float *s, const float *f, const float *gu, const float *a, const float *go,
+                                   float *gs, float *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                   int64_t W, int k, int layout, gfla_stream_t st) {
+  return gfla::local_attn_source_bwd<float>(s, f, gu, a, go, gs, gf, B, C, Hs, Ws, H, W, k, layout, st);
+}
+int gfla_local_attn_source_bwd_f64(const double *s, const double *f, const double *gu, const double *a,
+                                   const double *go, double *gs, double *gf, int64_t B, int64_t C, int64_t Hs,
+                                   int64_t Ws, int64_t H, int64_t W, int k, int layout, gfla_stream_t st) {
+  return gfla::local_attn_source_bwd<double>(s, f, gu, a, go, gs, gf, B, C, Hs, Ws, H, W, k, layout, st);
 }
 }

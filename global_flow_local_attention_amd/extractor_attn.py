@@ -28,13 +28,30 @@ from .local_attn_reshape import LocalAttnReshape
 _FUSED_MAX_K = 5  # kernel sizes the fused tail is instantiated for
 
 
+class _SourceGradLink(object):
+    """Joins the two backward nodes that scatter into (source, flow) inside one ExtractorAttn call.
+    The aggregation's backward runs first (its grad_logits is what eventually produces the FC
+    operand's gradient), so it parks (attn, grad_out) here instead of scattering; the unfold node's
+    backward then scatters both gradient streams in one kernel pass."""
+
+    def __init__(self):
+        self.pending = None       # (attn, grad_out) parked by the aggregation's backward
+        self.unfold_alive = False  # an unfold node that will consume `pending` is in the graph
+
+    def __del__(self):
+        if self.pending is not None:  # never consumed: a gradient contribution would be lost
+            import warnings
+            warnings.warn("ExtractorAttn: parked aggregation gradient was never scattered "
+                          "(backward through the FC operand did not run)")
+
+
 class LocalAttnAggregateFunction(Function):
     """out = avg_pool2d(LocalAttnReshape(softmax(logits)) * BlockExtractor(source, flow), k, k)
     without materialising anything of size (B,C,kH,kW).  Returns (out, attn) where attn is the
     post-softmax (B,k*k,H,W) map (what hook_attn_param exposes as attn_param_)."""
 
     @staticmethod
-    def forward(ctx, source, flow_field, logits, kernel_size, apply_softmax):
+    def forward(ctx, source, flow_field, logits, kernel_size, apply_softmax, link=None):
         assert source.is_contiguous() and flow_field.is_contiguous() and logits.is_contiguous()
         _lib.require_gpu(source, flow_field, logits)
         b, c, hs, ws = source.size()
@@ -53,6 +70,7 @@ class LocalAttnAggregateFunction(Function):
         ctx.save_for_backward(source, flow_field, attn)
         ctx.kernel_size = k
         ctx.apply_softmax = bool(apply_softmax)
+        ctx.link = link
         ctx.mark_non_differentiable(attn)
         return out, attn
 
@@ -63,6 +81,11 @@ class LocalAttnAggregateFunction(Function):
         b, c, hs, ws = source.size()
         _, _, h, w = flow_field.size()
         ns, nf, nl = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        link = ctx.link
+        if link is not None and link.unfold_alive and nl and (ns or nf):
+            # park the (source, flow) contribution; the unfold node scatters it together with its own
+            link.pending = (attn, grad_out)
+            ns = nf = False
         gs = torch.zeros_like(source) if ns else None
         gf = torch.zeros_like(flow_field) if nf else None
         gl = torch.zeros_like(attn) if nl else None
@@ -71,7 +94,7 @@ class LocalAttnAggregateFunction(Function):
                       source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(attn), _lib.ptr(grad_out),
                       _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl),
                       b, c, hs, ws, h, w, ctx.kernel_size, 1 if ctx.apply_softmax else 0)
-        return gs, gf, gl, None, None
+        return gs, gf, gl, None, None, None
 
 
 class BlockExtractorUnfoldFunction(Function):
@@ -80,7 +103,7 @@ class BlockExtractorUnfoldFunction(Function):
     batch_inner=True returns (C*k*k, B, H, W) instead: one GEMM operand for the whole batch."""
 
     @staticmethod
-    def forward(ctx, source, flow_field, kernel_size, batch_inner=False):
+    def forward(ctx, source, flow_field, kernel_size, batch_inner=False, link=None):
         assert source.is_contiguous() and flow_field.is_contiguous()
         _lib.require_gpu(source, flow_field)
         b, c, hs, ws = source.size()
@@ -95,6 +118,9 @@ class BlockExtractorUnfoldFunction(Function):
         ctx.save_for_backward(source, flow_field)
         ctx.kernel_size = k
         ctx.layout = layout
+        ctx.link = link
+        if link is not None:
+            link.unfold_alive = True
         return out
 
     @staticmethod
@@ -106,20 +132,30 @@ class BlockExtractorUnfoldFunction(Function):
         ns, nf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gs = torch.zeros_like(source) if ns else None
         gf = torch.zeros_like(flow_field) if nf else None
+        link = ctx.link
+        parked = None
+        if link is not None:
+            parked, link.pending, link.unfold_alive = link.pending, None, False
         if ns or nf:
-            _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
-                      source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
-                      b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
-        return gs, gf, None, None
+            if parked is not None:  # FC-operand gradient + attention-aggregation gradient in one pass
+                attn, g_small = parked
+                _lib.call("gfla_local_attn_source_bwd_" + _lib.suffix(source, "local_attn_source backward"), source,
+                          _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(attn), _lib.ptr(g_small),
+                          _lib.ptr(gs), _lib.ptr(gf), b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
+            else:
+                _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
+                          source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
+                          b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
+        return gs, gf, None, None, None
 
 
-def _source_half_fc(self, source_c, flow_c, conv0, c, k):
+def _source_half_fc(self, source_c, flow_c, conv0, c, k, link=None):
     """conv_{k, stride k}(block_source, W[:, C:]) (base_function.py:800,805-807).  When the source
     planes fit in LDS the extractor writes its samples directly as the GEMM operand (unfold layout)
     and the convolution is one batched fp32 GEMM; otherwise the reference layout + a strided conv."""
     if getattr(self, "unfold_gemm", True) and _lib.unfold_supported(source_c.size(2), source_c.size(3), k,
                                                                      source_c.element_size()):
-        unf = BlockExtractorUnfoldFunction.apply(source_c, flow_c, k, True)    # (C*k*k, B, H, W)
+        unf = BlockExtractorUnfoldFunction.apply(source_c, flow_c, k, True, link)  # (C*k*k, B, H, W)
         kk_c, b, h, w = unf.shape
         w_s = conv0.weight[:, c:].reshape(conv0.out_channels, kk_c)           # (128, C*k*k), index c*k*k+i*k+j
         hid = torch.mm(w_s, unf.view(kk_c, b * h * w))                        # ONE GEMM for the whole batch
@@ -143,13 +179,14 @@ def _fused_attention(self, source, target, flow_field):
     lo, hi = k // 2, k - 1 - k // 2
     target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
     hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
-    hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k)
+    link = _SourceGradLink() if getattr(self, "fuse_source_backward", True) else None
+    hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
     logits = conv1(act(hidden))
     if isinstance(last, nn.Softmax) and last.dim == 1:
-        result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True)
+        result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True, link)
     else:  # softmax=None builds the block with the plain nonlinearity instead (:794)
         weights = last(logits).contiguous()
-        result, _ = LocalAttnAggregateFunction.apply(source_c, flow_c, weights, k, False)
+        result, _ = LocalAttnAggregateFunction.apply(source_c, flow_c, weights, k, False, link)
         attn = weights
     return attn, result
 

@@ -204,6 +204,23 @@ GFLA_DECL_AGGREGATE_BWD(f32, float)
 GFLA_DECL_AGGREGATE_BWD(f64, double)
 #undef GFLA_DECL_AGGREGATE_BWD
 
+/* ---- everything in ExtractorAttn that flows back into block_source(source, flow), in ONE pass ----------
+ * block_source receives two gradient streams (base_function.py:805-809): through the first FC layer
+ * (grad_unfold, in the unfold layout above; may be NULL) and through the attention-weighted aggregation
+ * (attn (B,k*k,H,W) post-softmax and grad_out (B,C,H,W): attn[b,ij,p]*grad_out[b,c,p]/k^2, never
+ * materialised; both may be NULL together).  Their sum is scattered into grad_source / grad_flow
+ * (accumulated; pass zeroed buffers; either may be NULL).  The reference runs the block_extractor
+ * backward kernel twice for this (once per stream, plus the reshape/multiply/avg-pool backward).      */
+#define GFLA_DECL_SOURCE_BWD(SFX, T)                                                               \
+  int gfla_local_attn_source_bwd_##SFX(const T *source, const T *flow, const T *grad_unfold,       \
+                                       const T *attn, const T *grad_out, T *grad_source,           \
+                                       T *grad_flow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, \
+                                       int64_t H, int64_t W, int kernel_size, int layout,          \
+                                       gfla_stream_t stream);
+GFLA_DECL_SOURCE_BWD(f32, float)
+GFLA_DECL_SOURCE_BWD(f64, double)
+#undef GFLA_DECL_SOURCE_BWD
+
 #ifdef __cplusplus
 }
 #endif

@@ -302,13 +302,23 @@ def test_extractor_attn_fused_equals_unfused_and_oracle(gfla, oracle, k, C, soft
     for a in args:
         a.grad = None
     m.zero_grad()
-    m.unfold_gemm = True   # default: extractor writes the GEMM operand, FC = batched GEMM
+    m.unfold_gemm = True   # extractor writes the GEMM operand, FC = one GEMM ...
+    m.fuse_source_backward = False  # ... but the two gradient streams into (source, flow) scatter separately
+    attn_s, out_s = m.hook_attn_param(*args)
+    (out_s.square().sum()).backward()
+    grads_s = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    for a in args:
+        a.grad = None
+    m.zero_grad()
+    m.fuse_source_backward = True   # default: one scatter pass for both streams
     attn_f, out_f = m.hook_attn_param(*args)
     (out_f.square().sum()).backward()
     grads_f = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
     assert_close(out_c.detach().cpu(), out_f.detach().cpu(), 2e-5, "conv vs GEMM formulation of the FC")
     for gc_, gf_ in zip(grads_c, grads_f):
         assert_close(gc_.cpu(), gf_.cpu(), 2e-4, "conv vs GEMM grads")
+    for gs_, gf_ in zip(grads_s, grads_f):
+        assert_close(gs_.cpu(), gf_.cpu(), 2e-5, "separate vs fused scatter of the two gradient streams")
     for a in args:
         a.grad = None
     m.zero_grad()
