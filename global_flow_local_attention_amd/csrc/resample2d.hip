@@ -50,6 +50,16 @@ struct Taps {
   A xLp[KH], xRp[KH], yTp[KH], yBp[KH];  // Gaussian weights
   A sum;
   A sigma;
+  int ix0, iy0;  // (int)floor(x + dx), (int)floor(y + dy)
+
+  // The 2*KH tap rows / columns as flat lists ordered by position when dilation == 1:
+  // index r < KH -> the "top"/"left" tap KH-1-r (above/left of the sample), r >= KH -> "bottom"/"right" tap r-KH.
+  __device__ __forceinline__ int row_off(int r) const { return r < KH ? yT[KH - 1 - r] : yB[r - KH]; }
+  __device__ __forceinline__ A row_w(int r) const { return r < KH ? yTp[KH - 1 - r] : yBp[r - KH]; }
+  __device__ __forceinline__ A row_d(int r) const { return r < KH ? yTd[KH - 1 - r] : yBd[r - KH]; }
+  __device__ __forceinline__ int col_off(int q) const { return q < KH ? xL[KH - 1 - q] : xR[q - KH]; }
+  __device__ __forceinline__ A col_w(int q) const { return q < KH ? xLp[KH - 1 - q] : xRp[q - KH]; }
+  __device__ __forceinline__ A col_d(int q) const { return q < KH ? xLd[KH - 1 - q] : xRd[q - KH]; }
 
   // floor_alpha: fractional part from floor (forward, input2 gradient) or from int() truncation
   // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
@@ -59,6 +69,8 @@ struct Taps {
     sigma = sg;
     const A xf = (A)x + dx, yf = (A)y + dy;  // :52-53
     const A fxf = floor_t<A>(xf), fyf = floor_t<A>(yf);
+    ix0 = (int)fxf;
+    iy0 = (int)fyf;
     const A alpha = trunc_alpha ? xf - (A)(int)xf : xf - fxf;
     const A beta = trunc_alpha ? yf - (A)(int)yf : yf - fyf;
     sum = 0;
@@ -109,113 +121,145 @@ struct LdsPlane {
 };
 
 // ---- per-pixel bodies, shared by the global-memory and the LDS-plane kernels ------------------
+// The tap weights are an outer product w[r][q] = wy[r] * wx[q] of 2*KH row and 2*KH column weights
+// (the reference's (fy,fx) x {T,B} x {L,R} loop enumerates exactly these pairs), so every sum over
+// the taps is evaluated separably: 2*KH row/column weights in registers instead of (2*KH)^2 products.
+
 // forward: `nch` channels, planes `plane_sz` apart starting at `plane`, outputs `ostride` apart.
 template <typename T, typename PT, int KH, typename A>
 __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__restrict__ plane, int64_t plane_sz,
                                              T *__restrict__ o, int64_t ostride, int nch) {
+  constexpr int N = 2 * KH;
+  int ro[N], co[N];
+  A wy[N], wx[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    ro[r] = t.row_off(r);
+    co[r] = t.col_off(r);
+    wy[r] = t.row_w(r);
+    wx[r] = t.col_w(r);
+  }
   for (int c = 0; c < nch; ++c) {
-    A val = 0;
+    A val = 0;  // resample2d_kernel.cu:85-88: sum_r wy[r] * sum_q wx[q] * v[r][q]
 #pragma unroll
-    for (int fy = 0; fy < KH; ++fy)
+    for (int r = 0; r < N; ++r) {
+      A rowacc = 0;
 #pragma unroll
-      for (int fx = 0; fx < KH; ++fx) {  // resample2d_kernel.cu:85-88
-        val += (t.yTp[fy] * t.xLp[fx]) * Num<PT>::ld(plane + t.yT[fy] + t.xL[fx]);
-        val += (t.yTp[fy] * t.xRp[fx]) * Num<PT>::ld(plane + t.yT[fy] + t.xR[fx]);
-        val += (t.yBp[fy] * t.xLp[fx]) * Num<PT>::ld(plane + t.yB[fy] + t.xL[fx]);
-        val += (t.yBp[fy] * t.xRp[fx]) * Num<PT>::ld(plane + t.yB[fy] + t.xR[fx]);
-      }
+      for (int q = 0; q < N; ++q) rowacc += wx[q] * Num<PT>::ld(plane + ro[r] + co[q]);
+      val += wy[r] * rowacc;
+    }
     *o = Num<T>::from((A)safe_div<A>(val, t.sum));  // :93
     plane += plane_sz;
     o += ostride;
   }
 }
 
-// d/d input1: scatter SAFE_DIV(w, sum) * grad_out into the gradient planes (:195-198)
-template <typename T, typename PT, int KH, typename A, typename Where>
+// d/d input1: scatter SAFE_DIV(w, sum) * grad_out into the gradient planes (:195-198).
+// MERGE (LDS planes, dilation 1): the 2*KH columns of a lane are consecutive, and the next pixel's run
+// is usually shifted by one column -> diagonal_merge leaves ~1 atomic per row and lane instead of 2*KH.
+template <typename T, typename PT, int KH, typename A, typename Where, bool MERGE>
 __device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__restrict__ g, int64_t gstride,
-                                              PT *__restrict__ gplane, int64_t plane_sz, int nch) {
-  A q[KH][KH][4];
+                                              PT *__restrict__ gplane, int64_t plane_sz, int nch, int dil, int Wi) {
+  constexpr int N = 2 * KH;
+  int ro[N], co[N];
+  A qy[N], wx[N];
 #pragma unroll
-  for (int fy = 0; fy < KH; ++fy)
-#pragma unroll
-    for (int fx = 0; fx < KH; ++fx) {
-      q[fy][fx][0] = (A)safe_div<A>(t.yTp[fy] * t.xLp[fx], t.sum);
-      q[fy][fx][1] = (A)safe_div<A>(t.yTp[fy] * t.xRp[fx], t.sum);
-      q[fy][fx][2] = (A)safe_div<A>(t.yBp[fy] * t.xLp[fx], t.sum);
-      q[fy][fx][3] = (A)safe_div<A>(t.yBp[fy] * t.xRp[fx], t.sum);
-    }
+  for (int r = 0; r < N; ++r) {
+    ro[r] = t.row_off(r);
+    co[r] = t.col_off(r);
+    qy[r] = (A)safe_div<A>(t.row_w(r), t.sum);
+    wx[r] = t.col_w(r);
+  }
+  bool merge_prev = false, merge_next = false;
+  if (MERGE) {
+    const int xbase = t.ix0 - (KH - 1);
+    diagonal_flags(dil == 1 && xbase >= 0 && xbase + N - 1 <= Wi - 1, xbase, t.iy0, merge_prev, merge_next);
+  }
   for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
 #pragma unroll
-    for (int fy = 0; fy < KH; ++fy)
+    for (int r = 0; r < N; ++r) {
+      const A gr_ = go * qy[r];
+      A vals[N];
 #pragma unroll
-      for (int fx = 0; fx < KH; ++fx) {
-        Where::add(gplane + t.yT[fy] + t.xL[fx], q[fy][fx][0] * go);
-        Where::add(gplane + t.yT[fy] + t.xR[fx], q[fy][fx][1] * go);
-        Where::add(gplane + t.yB[fy] + t.xL[fx], q[fy][fx][2] * go);
-        Where::add(gplane + t.yB[fy] + t.xR[fx], q[fy][fx][3] * go);
-      }
+      for (int q = 0; q < N; ++q) vals[q] = gr_ * wx[q];
+      if (MERGE) diagonal_merge<N, A>(vals, merge_prev, merge_next);
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        if (!MERGE || vals[q] != 0) Where::add(gplane + ro[r] + co[q], vals[q]);
+    }
     gplane += plane_sz;
     g += gstride;
   }
 }
 
 // d/d input2 = d/d(dx, dy, sigma) for `nch` channels; returns the three partial results (linear in
-// the channel sums, so channel chunks combine by addition).
+// the channel sums, so channel chunks combine by addition).  With T_rq = wy[r] wx[q] g v[r][q]:
+//   S = sum T;  d/dx = sum_q ax[q] C_q,  d/dy = sum_r ay[r] R_r,  d/dsigma = sum_r bs_y[r] R_r + sum_q bs_x[q] C_q
+// where R_r / C_q are the row / column sums of T accumulated over the channels (8 accumulators for k=4).
 template <typename T, typename PT, int KH, typename A>
 __device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__restrict__ plane, int64_t plane_sz,
                                               const T *__restrict__ g, int64_t gstride, int nch, A &rx, A &ry,
                                               A &rs) {
+  constexpr int N = 2 * KH;
   const A sg = t.sigma;
   // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (resample2d_kernel.cu:273-292)
   const A d2 = -sg * sg, d3 = sg * sg * sg;
   const A inv2 = (d2 == 0) ? (A)(1.0 / kEps) : (A)1 / d2;
   const A inv3 = (d3 == 0) ? (A)(1.0 / kEps) : (A)1 / d3;
-  // per-tap weight and the three derivative coefficients; taps ordered TL,TR,BL,BR
-  A wt[KH][KH][4], cx[KH][KH][4], cy[KH][KH][4], cs[KH][KH][4];
-  A sgx = 0, sgy = 0, sgs = 0;  // "sumgrad", counted once (the reference counts it C times and
-                                // divides by C, :277,318)
+  int ro[N], co[N];
+  A wy[N], wx[N];
 #pragma unroll
-  for (int fy = 0; fy < KH; ++fy)
+  for (int r = 0; r < N; ++r) {
+    ro[r] = t.row_off(r);
+    co[r] = t.col_off(r);
+    wy[r] = t.row_w(r);
+    wx[r] = t.col_w(r);
+  }
+  A Racc[N], Cacc[N];
 #pragma unroll
-    for (int fx = 0; fx < KH; ++fx) {
-      const A xd[2] = {t.xLd[fx], t.xRd[fx]}, xp[2] = {t.xLp[fx], t.xRp[fx]};
-      const A yd[2] = {t.yTd[fy], t.yBd[fy]}, yp[2] = {t.yTp[fy], t.yBp[fy]};
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int q = r * 2 + s;
-          const A w = yp[r] * xp[s];
-          wt[fy][fx][q] = w;
-          cx[fy][fx][q] = (s == 0 ? xd[s] : -xd[s]) * w * inv2;        // :273-277
-          cy[fy][fx][q] = (r == 0 ? yd[r] : -yd[r]) * w * inv2;        // :280-284
-          cs[fy][fx][q] = (yd[r] * yd[r] + xd[s] * xd[s]) * w * inv3;  // :287-291
-          sgx += cx[fy][fx][q];
-          sgy += cy[fy][fx][q];
-          sgs += cs[fy][fx][q];
-        }
-    }
-  A g1x = 0, g1y = 0, g1s = 0, S = 0;
+  for (int r = 0; r < N; ++r) Racc[r] = Cacc[r] = 0;
   for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
+    A cs[N];
 #pragma unroll
-    for (int fy = 0; fy < KH; ++fy)
+    for (int q = 0; q < N; ++q) cs[q] = 0;
 #pragma unroll
-      for (int fx = 0; fx < KH; ++fx) {
-        const A pv[4] = {go * Num<PT>::ld(plane + t.yT[fy] + t.xL[fx]), go * Num<PT>::ld(plane + t.yT[fy] + t.xR[fx]),
-                         go * Num<PT>::ld(plane + t.yB[fy] + t.xL[fx]), go * Num<PT>::ld(plane + t.yB[fy] + t.xR[fx])};
+    for (int r = 0; r < N; ++r) {
+      A rsum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          g1x += cx[fy][fx][q] * pv[q];
-          g1y += cy[fy][fx][q] * pv[q];
-          g1s += cs[fy][fx][q] * pv[q];
-          S += wt[fy][fx][q] * pv[q];
-        }
+      for (int q = 0; q < N; ++q) {
+        const A v = Num<PT>::ld(plane + ro[r] + co[q]);
+        rsum += wx[q] * v;
+        cs[q] += wy[r] * v;
       }
+      Racc[r] += go * rsum;
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) Cacc[q] += go * cs[q];
     plane += plane_sz;
     g += gstride;
   }
+  // fold the row / column weights back in and apply the derivative coefficients (:273-292);
+  // "L"/"T" taps (index < KH) enter d/dx, d/dy with +, "R"/"B" taps with -
+  A S = 0, g1x = 0, g1y = 0, g1s = 0, Wy = 0, Wx = 0, sx1 = 0, sy1 = 0, ssx = 0, ssy = 0;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    const A R = wy[r] * Racc[r], Cq = wx[r] * Cacc[r];
+    const A yd = t.row_d(r), xd = t.col_d(r);
+    const A ay = (r < KH ? yd : -yd) * inv2, ax = (r < KH ? xd : -xd) * inv2;
+    S += R;
+    g1y += ay * R;
+    g1x += ax * Cq;
+    g1s += (yd * yd * inv3) * R + (xd * xd * inv3) * Cq;
+    Wy += wy[r];
+    Wx += wx[r];
+    sy1 += ay * wy[r];
+    sx1 += ax * wx[r];
+    ssy += (yd * yd * inv3) * wy[r];
+    ssx += (xd * xd * inv3) * wx[r];
+  }
+  const A sgx = sx1 * Wy, sgy = sy1 * Wx, sgs = ssy * Wx + ssx * Wy;  // "sumgrad", counted once (:277,318)
   // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S
   const A sum = t.sum, sum2 = t.sum * t.sum;
   const A is = (sum == 0) ? (A)(1.0 / kEps) : (A)1 / sum;
@@ -258,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ i
   t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
   const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
   const int64_t plane_sz = (int64_t)Hi * Wi;
-  rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
-                                          gin1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, c1 - c0);
+  rs_bwd1_pixel<T, T, KH, A, GlobalPlane, false>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
+                                                 gin1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, c1 - c0, dil, Wi);
 }
 
 template <typename T, int KH>
@@ -348,9 +392,9 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     } else if constexpr (MODE == 1) {
       const T *go = gout + ((int64_t)b * C + c0) * HW + p;
       if (inside)
-        rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, go, HW, planes0, win_sz, gc);
+        rs_bwd1_pixel<T, PT, KH, A, LdsPlane, true>(t, go, HW, planes0, win_sz, gc, dil, Wi);
       else
-        rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc);
+        rs_bwd1_pixel<T, T, KH, A, GlobalPlane, false>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc, dil, Wi);
     } else {
       A rx, ry, rs;
       const T *go = gout + ((int64_t)b * C + c0) * HW + p;
