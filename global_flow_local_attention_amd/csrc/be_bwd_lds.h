@@ -185,10 +185,6 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       int col[K + 1];
 #pragma unroll
       for (int q = 0; q <= K; ++q) col[q] = clampi(x0 + q, 0, Ws - 1);
-      // neighbouring lanes whose patches are shifted by exactly one column share K of their K+1
-      // addresses per patch row: merge along the diagonal before the LDS atomics
-      bool merge_prev = false, merge_next = false;
-      if (NEED_SRC) diagonal_flags(x0 >= 0 && x0 + K <= Ws - 1, x0, y0, merge_prev, merge_next);
       for (int c = 0; c < gc; ++c) {
         lds_acc_t *gp = gplanes0 + (size_t)c * win_sz;
         const A *spl = splanes0 + (size_t)c * win_sz;
@@ -227,7 +223,6 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
             }
           }
           if (NEED_SRC) {
-            diagonal_merge<K + 1, A>(rowA, merge_prev, merge_next);
 #pragma unroll
             for (int q = 0; q <= K; ++q)
               if (rowA[q] != 0) lds_add(gp + offA + col[q], (lds_acc_t)rowA[q]);
@@ -240,7 +235,6 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
           offA = offB;
         }
         if (NEED_SRC) {
-          diagonal_merge<K + 1, A>(rowA, merge_prev, merge_next);
 #pragma unroll
           for (int q = 0; q <= K; ++q)
             if (rowA[q] != 0) lds_add(gp + offA + col[q], (lds_acc_t)rowA[q]);

@@ -29,36 +29,9 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Lanes of a wave own consecutive pixels.  vals[s], s = 0..N-1, of a lane are bound for N consecutive
-// columns xbase+s of one plane row.  When the previous lane's run starts exactly one column to the
-// left (merge_prev), its slot s+1 and this lane's slot s hit the same address: the value is passed
-// down the diagonal (one ds_bpermute per slot) so that only ONE lane issues the ds_add_f64 for that
-// address instead of up to N lanes.  With smooth flows this removes about two thirds of the LDS
-// atomics, the throughput limit of every scatter kernel here.  Must be called convergently by all
-// lanes that take part; merge_next must be the next lane's merge_prev (false for the last lane).
-template <int N, typename A>
-__device__ __forceinline__ void diagonal_merge(A (&vals)[N], bool merge_prev, bool merge_next) {
-#pragma unroll
-  for (int s = N - 1; s >= 1; --s) {
-    const A recv = __shfl_up(vals[s], 1);
-    if (merge_prev) vals[s - 1] += recv;
-    if (merge_next) vals[s] = 0;
-  }
-}
-
-// merge_prev / merge_next for the calling lanes (call inside the branch whose lanes will merge).
-// `ok`: this lane's run is unclamped and eligible; (xbase, ybase) identify where its run starts.
-__device__ __forceinline__ void diagonal_flags(bool ok, int xbase, int ybase, bool &merge_prev, bool &merge_next) {
-  const unsigned long long act = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  const bool prev_active = lane > 0 && ((act >> (lane - 1)) & 1ull);
-  const bool next_active = lane < 63 && ((act >> (lane + 1)) & 1ull);
-  const int px = __shfl_up(xbase, 1), py = __shfl_up(ybase, 1), pok = __shfl_up((int)ok, 1);
-  merge_prev = prev_active && ok && pok && px + 1 == xbase && py == ybase;
-  const int nm = __shfl_down((int)merge_prev, 1);
-  merge_next = next_active && nm;
-}
-
+// (Tried and rejected, round 1: merging neighbouring lanes' overlapping patch columns with a chain of
+// ds_bpermute before the atomics.  It removed ~60 % of the ds_add_f64 but the K dependent shuffle rounds
+// per patch row are latency-bound: be_bwd 461 -> 517 us, resample2d d/d input1 528 -> 587 us.)
 struct PlaneGeo {
   int G;        // channels (planes) per workgroup; 0 = does not fit, use the global kernels
   int ngroups;  // ceil(C / G)

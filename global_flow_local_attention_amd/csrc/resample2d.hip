@@ -155,11 +155,9 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
 }
 
 // d/d input1: scatter SAFE_DIV(w, sum) * grad_out into the gradient planes (:195-198).
-// MERGE (LDS planes, dilation 1): the 2*KH columns of a lane are consecutive, and the next pixel's run
-// is usually shifted by one column -> diagonal_merge leaves ~1 atomic per row and lane instead of 2*KH.
-template <typename T, typename PT, int KH, typename A, typename Where, bool MERGE>
+template <typename T, typename PT, int KH, typename A, typename Where>
 __device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__restrict__ g, int64_t gstride,
-                                              PT *__restrict__ gplane, int64_t plane_sz, int nch, int dil, int Wi) {
+                                              PT *__restrict__ gplane, int64_t plane_sz, int nch) {
   constexpr int N = 2 * KH;
   int ro[N], co[N];
   A qy[N], wx[N];
@@ -170,23 +168,13 @@ __device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__r
     qy[r] = (A)safe_div<A>(t.row_w(r), t.sum);
     wx[r] = t.col_w(r);
   }
-  bool merge_prev = false, merge_next = false;
-  if (MERGE) {
-    const int xbase = t.ix0 - (KH - 1);
-    diagonal_flags(dil == 1 && xbase >= 0 && xbase + N - 1 <= Wi - 1, xbase, t.iy0, merge_prev, merge_next);
-  }
   for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
 #pragma unroll
     for (int r = 0; r < N; ++r) {
       const A gr_ = go * qy[r];
-      A vals[N];
 #pragma unroll
-      for (int q = 0; q < N; ++q) vals[q] = gr_ * wx[q];
-      if (MERGE) diagonal_merge<N, A>(vals, merge_prev, merge_next);
-#pragma unroll
-      for (int q = 0; q < N; ++q)
-        if (!MERGE || vals[q] != 0) Where::add(gplane + ro[r] + co[q], vals[q]);
+      for (int q = 0; q < N; ++q) Where::add(gplane + ro[r] + co[q], gr_ * wx[q]);
     }
     gplane += plane_sz;
     g += gstride;
@@ -302,8 +290,8 @@ __global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ i
   t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
   const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
   const int64_t plane_sz = (int64_t)Hi * Wi;
-  rs_bwd1_pixel<T, T, KH, A, GlobalPlane, false>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
-                                                 gin1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, c1 - c0, dil, Wi);
+  rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
+                                          gin1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, c1 - c0);
 }
 
 template <typename T, int KH>
@@ -392,9 +380,9 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     } else if constexpr (MODE == 1) {
       const T *go = gout + ((int64_t)b * C + c0) * HW + p;
       if (inside)
-        rs_bwd1_pixel<T, PT, KH, A, LdsPlane, true>(t, go, HW, planes0, win_sz, gc, dil, Wi);
+        rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, go, HW, planes0, win_sz, gc);
       else
-        rs_bwd1_pixel<T, T, KH, A, GlobalPlane, false>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc, dil, Wi);
+        rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc);
     } else {
       A rx, ry, rs;
       const T *go = gout + ((int64_t)b * C + c0) * HW + p;
