@@ -73,7 +73,7 @@ class HotPath:
             tgt = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
             flow = smooth_flow(B, H, W, device, gen).requires_grad_()
             self.inputs.append((src, tgt, flow))
-        self.resample = None
+        self.upstream = None
         for (name, C, H, W) in VGG:
             feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
             self.vgg.append(feat)
@@ -82,19 +82,20 @@ class HotPath:
         return [p for m in self.attn for p in m.parameters()]
 
     def step(self, resample, allreduce=True):
-        loss = 0
-        for mod, (src, tgt, flow) in zip(self.attn, self.inputs):
-            out = mod(src, tgt, flow)
-            loss = loss + out.square().mean()
-        for feat, (_, _, flow) in zip(self.vgg, self.inputs):
-            warped = resample(feat, flow)
-            loss = loss + warped.square().mean()
+        """Forward through both attention layers and both resample sites, then backward from fixed
+        upstream gradients (what the rest of the generator / the losses would send back) -- no
+        synthetic loss kernels inside the timed region."""
+        outs = [mod(src, tgt, flow) for mod, (src, tgt, flow) in zip(self.attn, self.inputs)]
+        outs += [resample(feat, flow) for feat, (_, _, flow) in zip(self.vgg, self.inputs)]
+        if self.upstream is None:
+            gen = torch.Generator(device=outs[0].device).manual_seed(4321)
+            self.upstream = [torch.randn(o.shape, device=o.device, generator=gen) / o[0].numel() for o in outs]
         for t in [x for tup in self.inputs for x in tup] + self.vgg + self.params():
             t.grad = None
-        loss.backward()
+        torch.autograd.backward(outs, self.upstream)
         if allreduce:
             gdist.allreduce_grads(self.params())
-        return loss
+        return outs
 
 
 # ---- algorithmic bytes per C-ABI call (SURVEY.md section 8d; 4 bytes per fp32 element) -------
