@@ -25,6 +25,8 @@ class BlockExtractorFunction(Function):
         ctx.kernel_size = kernel_size
         # the kernel writes every element, so no zero fill (the reference zero-fills, :21)
         output = flow_field.new_empty((bs, ds, kernel_size * hf, kernel_size * wf))
+        if output.numel() == 0 or source.numel() == 0:  # empty batch / channels: nothing to launch
+            return output.zero_()
         _lib.call("gfla_block_extractor_fwd_" + _lib.suffix(source, "block_extractor"), source,
                   _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(output),
                   bs, ds, hs, ws, hf, wf, int(kernel_size))
@@ -39,7 +41,7 @@ class BlockExtractorFunction(Function):
         need_src, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_source = torch.zeros_like(source) if need_src else None
         grad_flow_field = torch.zeros_like(flow_field) if need_flow else None
-        if need_src or need_flow:
+        if (need_src or need_flow) and grad_output.numel() > 0 and source.numel() > 0:
             _lib.call("gfla_block_extractor_bwd_" + _lib.suffix(source, "block_extractor backward"), source,
                       _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_output),
                       _lib.ptr(grad_source), _lib.ptr(grad_flow_field),

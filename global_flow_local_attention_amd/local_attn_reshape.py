@@ -17,6 +17,8 @@ class LocalAttnReshapeFunction(Function):
         ctx.kernel_size = kernel_size
         ctx.in_shape = (bs, ds, hs, ws)
         output = inputs.new_empty((bs, 1, kernel_size * hs, kernel_size * ws))
+        if output.numel() == 0:
+            return output
         _lib.call("gfla_local_attn_reshape_fwd_" + _lib.suffix(inputs, "local_attn_reshape"), inputs,
                   _lib.ptr(inputs), _lib.ptr(output), bs, hs, ws, int(kernel_size))
         return output
@@ -26,6 +28,8 @@ class LocalAttnReshapeFunction(Function):
         grad_output = grad_output.contiguous()
         bs, ds, hs, ws = ctx.in_shape
         grad_inputs = grad_output.new_empty(ctx.in_shape)  # fully overwritten (a bijection)
+        if grad_inputs.numel() == 0:
+            return grad_inputs, None
         _lib.call("gfla_local_attn_reshape_bwd_" + _lib.suffix(grad_output, "local_attn_reshape"), grad_output,
                   _lib.ptr(grad_output), _lib.ptr(grad_inputs), bs, hs, ws, int(ctx.kernel_size))
         return grad_inputs, None

@@ -30,6 +30,8 @@ class Resample2dFunction(Function):
         if b1 != b:
             raise ValueError("resample2d: input1 batch %d != input2 batch %d" % (b1, b))
         output = input1.new_empty((b, d, h, w))
+        if output.numel() == 0 or input1.numel() == 0:
+            return output.zero_()
         _lib.call("gfla_resample2d_fwd_" + _lib.suffix(input1, "resample2d"), input1,
                   _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(output),
                   b, d, hi, wi, h, w, int(kernel_size), int(dilation))
@@ -44,7 +46,7 @@ class Resample2dFunction(Function):
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_input1 = torch.zeros_like(input1) if need1 else None
         grad_input2 = torch.zeros_like(input2) if need2 else None
-        if need1 or need2:
+        if (need1 or need2) and grad_output.numel() > 0 and input1.numel() > 0:
             _lib.call("gfla_resample2d_bwd_" + _lib.suffix(input1, "resample2d backward"), input1,
                       _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_output),
                       _lib.ptr(grad_input1), _lib.ptr(grad_input2),

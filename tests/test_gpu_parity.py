@@ -170,6 +170,66 @@ def test_unfold_supported_query(gfla):
     assert not _lib.unfold_supported(32, 32, 7, 4)
 
 
+def test_empty_inputs(gfla):
+    # zero-sized batch / channel dims: the reference launches zero blocks; we return empty tensors
+    out = gfla.BlockExtractor(3)(torch.zeros(0, 4, 6, 5, device=DEV), torch.zeros(0, 2, 6, 5, device=DEV))
+    assert out.shape == (0, 4, 18, 15)
+    s = torch.zeros(2, 0, 6, 5, device=DEV, requires_grad=True)
+    f = torch.zeros(2, 2, 6, 5, device=DEV, requires_grad=True)
+    out = gfla.BlockExtractor(3)(s, f)
+    assert out.shape == (2, 0, 18, 15)
+    out.sum().backward()
+    assert f.grad.abs().sum().item() == 0
+    assert gfla.LocalAttnReshape()(torch.zeros(0, 9, 4, 4, device=DEV), 3).shape == (0, 1, 12, 12)
+    assert gfla.Resample2d(4, 1, 2)(torch.zeros(0, 3, 4, 4, device=DEV), torch.zeros(0, 2, 4, 4, device=DEV)).shape == (0, 3, 4, 4)
+
+
+def test_more_than_2_to_31_output_elements(gfla, oracle):
+    # The reference indexes with a 32-bit `int index` (block_extractor_kernel.cu:33) and overflows past
+    # 2^31 elements; here offsets are 64-bit.  (B,C,k) chosen so the output has 2.31e9 elements (9.2 GB).
+    B, C, H, W, k = 256, 128, 64, 44, 5
+    assert B * C * k * H * k * W > 2 ** 31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 14 * 2 ** 30:
+        pytest.skip("needs ~11 GB of free HBM")
+    s = torch.randn(B, C, H, W, device=DEV)
+    f = make_flow("smooth", B, H, W, seed=70).to(DEV)
+    out = gfla.BlockExtractor(k)(s, f)
+    for b in (0, B // 2, B - 1):   # samples below, across and above the 2^31 boundary
+        want = oracle.block_extractor_fwd(s[b:b + 1].cpu(), f[b:b + 1].cpu(), k)
+        assert_close(out[b:b + 1].cpu(), want, F32_FWD, "sample %d" % b)
+    out0 = gfla.BlockExtractor(k)(s, torch.zeros_like(f))
+    assert torch.equal(out0[:, :, k // 2::k, k // 2::k], s)
+    del out, out0
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_bf16_forward_ops(gfla, oracle, k):
+    # config 5: bf16 features.  bf16-rounded inputs through the fp32 oracle, 2^-8 relative.
+    B, C, H, W = 2, 8, 16, 12
+    s = randn((B, C, H, W), seed=71).bfloat16()
+    f = make_flow("coherent", B, H, W, seed=72).bfloat16()
+    lg = randn((B, k * k, H, W), seed=73).bfloat16()
+    sf, ff, lf = s.float(), f.float(), lg.float()
+    bs = oracle.block_extractor_fwd(sf, ff, k)
+
+    def close(got, want, what):
+        assert got.dtype == torch.bfloat16
+        assert max_abs(got.float().cpu(), want) <= 2 ** -7 * max(1.0, want.abs().max().item()), what
+
+    unf = gfla.BlockExtractorUnfoldFunction.apply(s.to(DEV), f.to(DEV), k)
+    close(unf, _to_unfold(bs, k), "unfold bf16")
+    a = torch.softmax(lf, 1)
+    want = F.avg_pool2d(F.pixel_shuffle(a, k) * bs, k, k)
+    out, attn = gfla.LocalAttnAggregateFunction.apply(s.to(DEV), f.to(DEV), lg.to(DEV), k, True)
+    close(out, want, "aggregate bf16")
+    close(attn, a, "attn bf16")
+    i2 = torch.cat((ff, torch.full((B, 1, H, W), 2.0)), 1).contiguous()
+    rs = gfla.Resample2d(4, 1, 2)(s.to(DEV), f.to(DEV))
+    close(rs, oracle.resample2d_fwd(sf, i2, 4, 1), "resample2d bf16")
+
+
 # --------------------------------------------------------------------------- local_attn_reshape
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
 @pytest.mark.parametrize("k", [1, 2, 3, 5])
