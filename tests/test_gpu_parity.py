@@ -437,6 +437,39 @@ def test_windowed_resample2d(gfla, oracle, scale):
     assert_close(fld.grad.cpu(), g2[:, :2], 1e-4, "windowed resample grad_flow")
 
 
+@pytest.mark.parametrize("kz", [3, 5])
+def test_affine_regularization_loss_collapsed_vs_op_by_op(gfla, kz):
+    # external_function.py:31-77 through BlockExtractor/LocalAttnReshape (Hs != Hf, C = 1, constant flow)
+    # against the collapsed quadratic form, values and gradients w.r.t. the flow field
+    flow = make_flow("coherent", 3, 32, 22, seed=80).to(DEV)
+    f1, f2 = flow.clone().requires_grad_(), flow.clone().requires_grad_()
+    l1 = gfla.AffineRegularizationLoss(kz, collapsed=True)(f1)
+    l2 = gfla.AffineRegularizationLoss(kz, collapsed=False)(f2)
+    assert abs(l1.item() - l2.item()) <= 2e-4 * max(1.0, abs(l2.item()))
+    l1.backward()
+    l2.backward()
+    assert_close(f1.grad.cpu(), f2.grad.cpu(), 2e-4, "d loss / d flow")
+    multi = gfla.MultiAffineRegularizationLoss({'2': 5, '3': 3})
+    fl = [make_flow("coherent", 2, 32, 22, seed=81).to(DEV), make_flow("coherent", 2, 64, 44, seed=82).to(DEV)]
+    assert torch.isfinite(multi(fl))
+
+
+def test_hipgraph_captured_inference_matches_eager(gfla, kernel_variant):
+    if kernel_variant != "lds":
+        pytest.skip("one variant is enough")
+    torch.manual_seed(90)
+    m = gfla.ExtractorAttn(32, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV).eval()
+    mk = lambda seed: (randn((1, 32, 32, 22), seed=seed).to(DEV), randn((1, 32, 32, 22), seed=seed + 1).to(DEV),
+                       make_flow("coherent", 1, 32, 22, seed=seed + 2).to(DEV))
+    g = gfla.graphed_inference(m, mk(91))
+    for seed in (91, 95, 99):                      # replay with new inputs of the same shape
+        inp = mk(seed)
+        with torch.no_grad():
+            want = m(*inp)
+        got = g(*inp)
+        assert_close(got, want, 1e-6, "graph replay vs eager")
+
+
 # ------------------------------------------------------------------------------- BASELINE sizes
 @pytest.mark.parametrize("k", [3, 5])
 def test_config2_block_extractor_full_size(gfla, oracle, k):

@@ -150,3 +150,24 @@ def test_fc_split_identity(oracle):
     lo, hi = k // 2, k - 1 - k // 2
     split = F.conv2d(F.pad(t, (lo, hi, lo, hi), mode="replicate"), w[:, :C], b) + F.conv2d(bs, w[:, C:], None, stride=k)
     assert max_abs(full, split) < 1e-12
+
+
+@pytest.mark.parametrize("kz", [3, 5])
+def test_affine_regularization_collapses_to_a_quadratic_form(oracle, kz):
+    # external_function.py:61-69 op by op (oracle kernels) == mean(u^T M u) (losses.py)
+    from global_flow_local_attention_amd.losses import AffineRegularizationLoss, affine_projector
+    flow = make_flow("coherent", 2, 12, 10, torch.float64, seed=40)
+    loss_mod = AffineRegularizationLoss(kz)            # collapsed: pure torch, runs on the CPU
+    got = loss_mod(flow)
+    grid = loss_mod.flow2grid(flow)
+    weights = affine_projector(kz).view(kz * kz, 1, kz, kz)
+    want = 0
+    for ax in (0, 1):
+        g = grid[:, ax:ax + 1].contiguous()
+        results = F.conv2d(g, weights)
+        b, c, h, w = results.shape
+        kernels_new = oracle.local_attn_reshape_fwd(results.contiguous(), kz)
+        f = torch.zeros(b, 2, h, w, dtype=torch.float64) + float(int(kz / 2))
+        grid_h = oracle.block_extractor_fwd(g, f, kz)
+        want = want + F.avg_pool2d(grid_h * kernels_new, kz, kz).mean() * kz ** 2
+    assert abs(got.item() - want.item()) <= 1e-10 * max(1.0, abs(want.item()))

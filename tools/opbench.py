@@ -207,6 +207,18 @@ def main():
                 emit("rs_bwd(in2 only) " + case, "gfla_resample2d_bwd_f32", ("ptr",) * 3 + (None, "ptr", B, C, H, W, H, W, 4, 1, 1), time_fn(fn2, max(3, args.iters // 2)))
         torch.cuda.empty_cache()
 
+    if want("graph"):
+        import time
+        for (C, H, W, k) in ((256, 32, 22, 3), (128, 64, 44, 5)):
+            m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV).eval()
+            inp = (torch.randn(1, C, H, W, device=DEV), torch.randn(1, C, H, W, device=DEV), flow_of("smooth", 1, H, W))
+            with torch.no_grad():
+                eager = time_fn(lambda: m(*inp), 50)
+            g = gfla.graphed_inference(m, inp)
+            graph = time_fn(lambda: g.graph.replay(), 50)
+            print(json.dumps({"case": "ExtractorAttn B1 C%d %dx%d k%d inference" % (C, H, W, k), "eager_us": round(eager, 1),
+                              "hipgraph_us": round(graph, 1), "speedup": round(eager / graph, 2)}), flush=True)
+
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "a") as f:
