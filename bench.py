@@ -192,8 +192,11 @@ def pmc_traffic(entry, dims, ptrs=""):
         names = [("rs_lds_kernel<float, %d, 0" % (dims[6] // 2), 4 * B * C * dims[4] * dims[5])]
     elif base == "gfla_resample2d_bwd":
         kh = dims[6] // 2
-        names = [("rs_lds_kernel<float, %d, 1" % kh, 4 * B * C * dims[2] * dims[3]),
-                 ("rs_lds_kernel<float, %d, 2" % kh, 4 * 3 * B * dims[4] * dims[5])]
+        names = []
+        if ptrs[3:4] == "1":
+            names.append(("rs_lds_kernel<float, %d, 1" % kh, 4 * B * C * dims[2] * dims[3]))
+        if ptrs[4:5] == "1":
+            names.append(("rs_lds_kernel<float, %d, 2" % kh, 4 * 3 * B * dims[4] * dims[5]))
     if not names:
         return None
     total = 0

@@ -47,10 +47,16 @@ class Resample2dFunction(Function):
         grad_input1 = torch.zeros_like(input1) if need1 else None
         grad_input2 = torch.zeros_like(input2) if need2 else None
         if (need1 or need2) and grad_output.numel() > 0 and input1.numel() > 0:
-            _lib.call("gfla_resample2d_bwd_" + _lib.suffix(input1, "resample2d backward"), input1,
-                      _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_output),
-                      _lib.ptr(grad_input1), _lib.ptr(grad_input2),
-                      b, d, hi, wi, h, w, int(ctx.kernel_size), int(ctx.dilation), 1 if TRUNC_COMPAT else 0)
+            # the two gradients are two independent kernels (scatter into input1 / reduction for
+            # (dx, dy, sigma)); one C-ABI call each keeps them separately visible to profilers
+            name = "gfla_resample2d_bwd_" + _lib.suffix(input1, "resample2d backward")
+            trunc = 1 if TRUNC_COMPAT else 0
+            if need1:
+                _lib.call(name, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_output),
+                          _lib.ptr(grad_input1), None, b, d, hi, wi, h, w, int(ctx.kernel_size), int(ctx.dilation), trunc)
+            if need2:
+                _lib.call(name, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_output),
+                          None, _lib.ptr(grad_input2), b, d, hi, wi, h, w, int(ctx.kernel_size), int(ctx.dilation), trunc)
         return grad_input1, grad_input2, None, None
 
 
