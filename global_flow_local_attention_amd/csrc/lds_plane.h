@@ -31,7 +31,10 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
 
 // (Tried and rejected, round 1: merging neighbouring lanes' overlapping patch columns with a chain of
 // ds_bpermute before the atomics.  It removed ~60 % of the ds_add_f64 but the K dependent shuffle rounds
-// per patch row are latency-bound: be_bwd 461 -> 517 us, resample2d d/d input1 528 -> 587 us.)
+// per patch row are latency-bound: be_bwd 461 -> 517 us, resample2d d/d input1 528 -> 587 us.
+// Also rejected: scattering two vertically adjacent pixels as one (K+2)x(K+1) patch (-42 % atomics when
+// the pair lines up) -- with smooth random flows most waves hold both paired and unpaired lanes, so the
+// wave executes both code paths: be_bwd 457 -> 909 us (profiles/r1_s16_vertical_pairing_rejected_*).)
 struct PlaneGeo {
   int G;        // channels (planes) per workgroup; 0 = does not fit, use the global kernels
   int ngroups;  // ceil(C / G)
