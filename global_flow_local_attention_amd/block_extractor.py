@@ -1,60 +1,76 @@
-"""BlockExtractor -- same surface as the reference's model/networks/block_extractor/block_extractor.py
-(BlockExtractorFunction :5-42, BlockExtractor :45-54), backed by the gfx950 kernels."""
+"""BlockExtractor on gfx950.
+
+Public surface identical to the reference's model/networks/block_extractor/block_extractor.py
+(`BlockExtractorFunction.apply(source, flow_field, kernel_size)` returning gradients
+`(grad_source, grad_flow_field, None)`, :5-42; `BlockExtractor(kernel_size=3).forward(source,
+flow_field)`, :45-54) so the reference's network code consumes it unchanged; the body is a ctypes
+call into libgfla_hip.so instead of the `block_extractor_cuda` pybind module.
+"""
 import torch
+from torch import nn
 from torch.autograd import Function
-from torch.nn.modules.module import Module
 
 from . import _lib
+
+_ENTRY_FWD = "gfla_block_extractor_fwd_"
+_ENTRY_BWD = "gfla_block_extractor_bwd_"
+
+
+def _geometry(source, flow_field):
+    """(B, C, Hs, Ws, Hf, Wf) after the checks the reference makes (contiguity, two flow channels)
+    plus the ones it leaves out (matching batch and dtype; :15 is commented out there)."""
+    assert source.is_contiguous()
+    assert flow_field.is_contiguous()
+    _lib.require_gpu(source, flow_field)
+    B, C, Hs, Ws = source.shape
+    Bf, two, Hf, Wf = flow_field.shape
+    assert two == 2
+    if Bf != B:
+        raise ValueError("block_extractor: source batch %d != flow batch %d" % (B, Bf))
+    if flow_field.dtype != source.dtype:
+        raise TypeError("block_extractor: source is %s but flow_field is %s" % (source.dtype, flow_field.dtype))
+    return B, C, Hs, Ws, Hf, Wf
 
 
 class BlockExtractorFunction(Function):
 
     @staticmethod
     def forward(ctx, source, flow_field, kernel_size):
-        assert source.is_contiguous()
-        assert flow_field.is_contiguous()
-        _lib.require_gpu(source, flow_field)
-        bs, ds, hs, ws = source.size()
-        bf, df, hf, wf = flow_field.size()
-        assert df == 2
-        if bf != bs:
-            raise ValueError("block_extractor: source batch %d != flow batch %d" % (bs, bf))
-        if flow_field.dtype != source.dtype:
-            raise TypeError("block_extractor: source is %s but flow_field is %s" % (source.dtype, flow_field.dtype))
+        B, C, Hs, Ws, Hf, Wf = _geometry(source, flow_field)
+        k = int(kernel_size)
+        ctx.kernel_size = k
         ctx.save_for_backward(source, flow_field)
-        ctx.kernel_size = kernel_size
-        # the kernel writes every element, so no zero fill (the reference zero-fills, :21)
-        output = flow_field.new_empty((bs, ds, kernel_size * hf, kernel_size * wf))
-        if output.numel() == 0 or source.numel() == 0:  # empty batch / channels: nothing to launch
-            return output.zero_()
-        _lib.call("gfla_block_extractor_fwd_" + _lib.suffix(source, "block_extractor"), source,
-                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(output),
-                  bs, ds, hs, ws, hf, wf, int(kernel_size))
-        return output
+        # every element is written by the kernel: no zero fill (the reference zero-fills, :21)
+        patches = flow_field.new_empty((B, C, k * Hf, k * Wf))
+        if patches.numel() == 0 or source.numel() == 0:  # empty batch / channels: nothing to launch
+            return patches.zero_()
+        _lib.call(_ENTRY_FWD + _lib.suffix(source, "block_extractor"), source,
+                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(patches), B, C, Hs, Ws, Hf, Wf, k)
+        return patches
 
     @staticmethod
-    def backward(ctx, grad_output):
-        grad_output = grad_output.contiguous()  # the reference drops this result (:32-33)
+    def backward(ctx, grad_patches):
         source, flow_field = ctx.saved_tensors
-        bs, ds, hs, ws = source.size()
-        _, _, hf, wf = flow_field.size()
-        need_src, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        grad_source = torch.zeros_like(source) if need_src else None
-        grad_flow_field = torch.zeros_like(flow_field) if need_flow else None
-        if (need_src or need_flow) and grad_output.numel() > 0 and source.numel() > 0:
-            _lib.call("gfla_block_extractor_bwd_" + _lib.suffix(source, "block_extractor backward"), source,
-                      _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_output),
-                      _lib.ptr(grad_source), _lib.ptr(grad_flow_field),
-                      bs, ds, hs, ws, hf, wf, int(ctx.kernel_size))
-        return grad_source, grad_flow_field, None
+        want_source, want_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_source = torch.zeros_like(source) if want_source else None
+        g_flow = torch.zeros_like(flow_field) if want_flow else None
+        grad_patches = grad_patches.contiguous()  # the reference drops this result (:32-33)
+        if (want_source or want_flow) and grad_patches.numel() > 0 and source.numel() > 0:
+            B, C, Hs, Ws = source.shape
+            Hf, Wf = flow_field.shape[2:]
+            _lib.call(_ENTRY_BWD + _lib.suffix(source, "block_extractor backward"), source,
+                      _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_patches),
+                      _lib.ptr(g_source), _lib.ptr(g_flow), B, C, Hs, Ws, Hf, Wf, ctx.kernel_size)
+        return g_source, g_flow, None
 
 
-class BlockExtractor(Module):
+class BlockExtractor(nn.Module):
+    """k x k bilinear patch around (x, y) + flow for every flow pixel: (B,C,Hs,Ws), (B,2,Hf,Wf) ->
+    (B,C,k*Hf,k*Wf)."""
+
     def __init__(self, kernel_size=3):
         super(BlockExtractor, self).__init__()
         self.kernel_size = kernel_size
 
     def forward(self, source, flow_field):
-        source_c = source.contiguous()
-        flow_field_c = flow_field.contiguous()
-        return BlockExtractorFunction.apply(source_c, flow_field_c, self.kernel_size)
+        return BlockExtractorFunction.apply(source.contiguous(), flow_field.contiguous(), self.kernel_size)

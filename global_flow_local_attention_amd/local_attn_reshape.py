@@ -1,44 +1,59 @@
-"""LocalAttnReshape -- same surface as the reference's
-model/networks/local_attn_reshape/local_attn_reshape.py (Function :5-37, Module :40-46)."""
+"""LocalAttnReshape on gfx950: (B, k*k, H, W) -> (B, 1, k*H, k*W) depth-to-space.
+
+The k*k attention weights the FC head of ExtractorAttn predicts for every pixel are laid out as a
+k x k tile per pixel so they can be multiplied with the extracted patches:
+
+    tiled[b, 0, y*k + i, x*k + j] = inputs[b, i*k + j, y, x]          (== F.pixel_shuffle(inputs, k))
+
+Public surface identical to the reference's model/networks/local_attn_reshape/local_attn_reshape.py
+(`LocalAttnReshapeFunction.apply(inputs, kernel_size)` with gradients `(grad_inputs, None)`, :5-37;
+`LocalAttnReshape().forward(inputs, kernel_size=3)`, :40-46).  Both directions are pure permutations
+executed as gathers by libgfla_hip.so (bit-exact; the reference's backward uses atomics on what is a
+bijection).
+"""
+from torch import nn
 from torch.autograd import Function
-from torch.nn.modules.module import Module
 
 from . import _lib
 
+_FWD = "gfla_local_attn_reshape_fwd_"
+_BWD = "gfla_local_attn_reshape_bwd_"
+
+
+def _launch(entry, src, dst, B, H, W, k):
+    """One permutation launch on src's device and current stream; empty tensors launch nothing."""
+    if dst.numel():
+        _lib.call(entry + _lib.suffix(src, "local_attn_reshape"), src, _lib.ptr(src), _lib.ptr(dst), B, H, W, k)
+    return dst
+
 
 class LocalAttnReshapeFunction(Function):
+    """autograd wrapper; `kernel_size` is a plain int and receives no gradient."""
 
     @staticmethod
     def forward(ctx, inputs, kernel_size):
+        k = int(kernel_size)
         assert inputs.is_contiguous()
         _lib.require_gpu(inputs)
-        bs, ds, hs, ws = inputs.size()
-        assert ds == kernel_size * kernel_size
-        ctx.kernel_size = kernel_size
-        ctx.in_shape = (bs, ds, hs, ws)
-        output = inputs.new_empty((bs, 1, kernel_size * hs, kernel_size * ws))
-        if output.numel() == 0:
-            return output
-        _lib.call("gfla_local_attn_reshape_fwd_" + _lib.suffix(inputs, "local_attn_reshape"), inputs,
-                  _lib.ptr(inputs), _lib.ptr(output), bs, hs, ws, int(kernel_size))
-        return output
+        B, KK, H, W = inputs.shape
+        assert KK == k * k  # as local_attn_reshape.py:13
+        ctx.kernel_size = k
+        ctx.in_shape = (B, KK, H, W)
+        return _launch(_FWD, inputs, inputs.new_empty((B, 1, k * H, k * W)), B, H, W, k)
 
     @staticmethod
-    def backward(ctx, grad_output):
-        grad_output = grad_output.contiguous()
-        bs, ds, hs, ws = ctx.in_shape
-        grad_inputs = grad_output.new_empty(ctx.in_shape)  # fully overwritten (a bijection)
-        if grad_inputs.numel() == 0:
-            return grad_inputs, None
-        _lib.call("gfla_local_attn_reshape_bwd_" + _lib.suffix(grad_output, "local_attn_reshape"), grad_output,
-                  _lib.ptr(grad_output), _lib.ptr(grad_inputs), bs, hs, ws, int(ctx.kernel_size))
-        return grad_inputs, None
+    def backward(ctx, grad_tiled):
+        B, _, H, W = ctx.in_shape
+        grad_tiled = grad_tiled.contiguous()
+        # the inverse permutation writes every element once: no zero fill, no accumulation
+        return _launch(_BWD, grad_tiled, grad_tiled.new_empty(ctx.in_shape), B, H, W, ctx.kernel_size), None
 
 
-class LocalAttnReshape(Module):
+class LocalAttnReshape(nn.Module):
+    """Parameter-free module; the tile size is an argument of forward(), as in the reference."""
+
     def __init__(self):
         super(LocalAttnReshape, self).__init__()
 
     def forward(self, inputs, kernel_size=3):
-        inputs_c = inputs.contiguous()
-        return LocalAttnReshapeFunction.apply(inputs_c, kernel_size)
+        return LocalAttnReshapeFunction.apply(inputs.contiguous(), kernel_size)
