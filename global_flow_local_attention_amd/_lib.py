@@ -30,6 +30,11 @@ _SIGNATURES = {
     "gfla_local_attn_aggregate_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_source_bwd": [_ptr] * 7 + [_i64] * 6 + [_int, _int, _ptr],
 }
+# entry points that exist in one precision only: full symbol name -> argument types
+_SINGLE = {
+    "gfla_max_cosine_fwd_f32": [_ptr] * 5 + [_i64] * 4 + [ctypes.c_double, _ptr],
+    "gfla_max_cosine_workspace_bytes": [_i64] * 3,
+}
 _FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
                   "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}
 
@@ -42,7 +47,7 @@ def exported_symbols():
             if sfx == "bf16" and base in _FWD_ONLY_BF16:
                 continue
             names.append("%s_%s" % (base, sfx))
-    return names
+    return names + list(_SINGLE)
 
 
 def build(force=False):
@@ -73,6 +78,10 @@ def lib():
                 fn = getattr(handle, "%s_%s" % (base, sfx))
                 fn.argtypes = args
                 fn.restype = _int
+        for name, args in _SINGLE.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = _i64 if name.endswith("_bytes") else _int
         _lib = handle
     return _lib
 

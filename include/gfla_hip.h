@@ -221,6 +221,21 @@ GFLA_DECL_SOURCE_BWD(f32, float)
 GFLA_DECL_SOURCE_BWD(f64, double)
 #undef GFLA_DECL_SOURCE_BWD
 
+/* ---- best-match cosine similarity of the sampling-correctness loss ----------------
+ * Replaces, in PerceptualCorrectness.calculate_loss (external_function.py:255-268),
+ *   source_norm = source / (||source||_c + eps); target_norm = target / (||target||_c + eps)
+ *   correction = bmm(source_norm^T, target_norm)          [B, Ns, Nt], materialised by the reference
+ *   correction_max, max_indices = max(correction, dim=1)
+ * source (B,C,Ns), target (B,C,Nt): contiguous views of the NCHW feature maps.  out_max (B,Nt) and
+ * out_idx (B,Nt; int32 row of the maximum, may be NULL) are fully overwritten.  `workspace` is caller-
+ * provided scratch of gfla_max_cosine_workspace_bytes(B, Ns, Nt) bytes, 16-byte aligned (the inverse
+ * norms and the packed running maxima live there).  fp32 only (exact-f32 MFMA); the [Ns,Nt] matrix is
+ * never written.  NaN similarities are ignored by the max (the reference's torch.max propagates them). */
+int64_t gfla_max_cosine_workspace_bytes(int64_t B, int64_t Ns, int64_t Nt);
+int gfla_max_cosine_fwd_f32(const float *source, const float *target, void *workspace, float *out_max,
+                            int32_t *out_idx, int64_t B, int64_t C, int64_t Ns, int64_t Nt, double eps,
+                            gfla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

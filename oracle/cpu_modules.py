@@ -82,3 +82,38 @@ class ExtractorAttnCPU(nn.Module):
         attn = self.fully_connect_layer(torch.cat((block_target, block_source), 1))
         attn = _LocalAttnReshapeCPU.apply(attn, k)
         return F.avg_pool2d(attn * block_source, k, k)
+
+
+def max_cosine_cpu(source, target, eps=1e-8):
+    """external_function.py:255-268 on host tensors: source (B,C,Ns), target (B,C,Nt) ->
+    (best (B,Nt), index (B,Nt)).  Materialises the [B,Ns,Nt] similarity matrix like the reference."""
+    source_all = source.transpose(1, 2)                                        # [b Ns C]
+    source_norm = source_all / (source_all.norm(dim=2, keepdim=True) + eps)
+    target_norm = target / (target.norm(dim=1, keepdim=True) + eps)
+    correction = torch.bmm(source_norm, target_norm)                           # [b Ns Nt]
+    return torch.max(correction, dim=1)
+
+
+class PerceptualCorrectnessCPU(nn.Module):
+    """external_function.py:246-279 (calculate_loss) op by op on the host, with the CPU Resample2d."""
+
+    def __init__(self):
+        super().__init__()
+        self.eps = 1e-8
+        self.resample = Resample2dCPU(4, 1, sigma=2)
+        self.target_vgg, self.source_vgg = {}, {}
+
+    def calculate_loss(self, flow, layer, mask=None):
+        target_vgg, source_vgg = self.target_vgg[layer], self.source_vgg[layer]
+        b, c, h, w = target_vgg.shape
+        flow = F.interpolate(flow, [h, w])
+        target_all = target_vgg.view(b, c, -1)
+        correction_max, _ = max_cosine_cpu(source_vgg.view(b, c, -1), target_all, self.eps)
+        input_sample = self.resample(source_vgg, flow).view(b, c, -1)
+        correction_sample = F.cosine_similarity(input_sample, target_all)
+        loss_map = torch.exp(-correction_sample / (correction_max + self.eps))
+        e1 = torch.exp(torch.tensor(-1.0)).type_as(loss_map)
+        if mask is None:
+            return torch.mean(loss_map) - e1
+        mask = F.interpolate(mask, size=(h, w)).view(-1, h * w)
+        return torch.sum(mask * (loss_map - e1)) / (torch.sum(mask) + self.eps)

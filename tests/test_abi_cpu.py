@@ -14,7 +14,7 @@ def _declared_symbols():
     """Expand the GFLA_DECL_* macros of the header by hand: every `gfla_<name>_##SFX` under a
     macro that is instantiated with (sfx, type)."""
     text = open(os.path.join(ROOT, "include", "gfla_hip.h")).read()
-    names = set(re.findall(r"^(?:int|const char \*)\s*(gfla_\w+)\(", text, flags=re.M))
+    names = set(re.findall(r"^(?:int|int64_t|const char \*)\s*(gfla_\w+)\(", text, flags=re.M))
     for macro, body in re.findall(r"#define (GFLA_DECL_\w+)\(SFX, T\)(.*?)\n(?=GFLA_DECL)", text, flags=re.S):
         bases = re.findall(r"(gfla_\w+?)_##SFX", body)
         for sfx in re.findall(macro + r"\((\w+), \w+\)", text):
