@@ -11,7 +11,7 @@ from .resample2d import Resample2d, Resample2dFunction  # noqa: F401
 from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn,  # noqa: F401
                              LocalAttnAggregateFunction, patch_reference_extractor_attn)
 from .losses import AffineRegularizationLoss, MultiAffineRegularizationLoss  # noqa: F401
-from .correctness import MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401
+from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401
 from .graphs import GraphedCall, graphed_inference  # noqa: F401
 from .install import install  # noqa: F401
 

@@ -34,6 +34,8 @@ _SIGNATURES = {
 _SINGLE = {
     "gfla_max_cosine_fwd_f32": [_ptr] * 5 + [_i64] * 4 + [ctypes.c_double, _ptr],
     "gfla_max_cosine_workspace_bytes": [_i64] * 3,
+    "gfla_correctness_map_fwd_f32": [_ptr] * 5 + [_i64] * 3 + [ctypes.c_double] * 2 + [_ptr],
+    "gfla_correctness_map_bwd_f32": [_ptr] * 9 + [_i64] * 3 + [ctypes.c_double] * 2 + [_ptr],
 }
 _FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
                   "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}

@@ -67,6 +67,44 @@ class MaxCosineFunction(Function):
         return (grads.pop(0) if need_s else None), (grads.pop(0) if need_t else None), None
 
 
+class CorrectnessMapFunction(Function):
+    """(warped (B,C,N), target (B,C,N), best (B,N), eps) -> exp(-cosine_similarity(warped, target) / (best + eps)),
+    external_function.py:275-276, as one pass forward and one backward."""
+
+    COS_EPS = 1e-8  # F.cosine_similarity's default
+
+    @staticmethod
+    def forward(ctx, warped, target, best, eps):
+        _lib.require_gpu(warped, target, best)
+        for x in (warped, target, best):
+            if x.dtype != torch.float32:
+                raise TypeError("correctness map: float32 only (got %s)" % x.dtype)
+            assert x.is_contiguous()
+        B, C, N = warped.shape
+        assert target.shape == warped.shape and best.shape == (B, N)
+        loss_map = warped.new_empty(B, N)
+        stats = warped.new_empty(B, N, 3)
+        _lib.call("gfla_correctness_map_fwd_f32", warped, _lib.ptr(warped), _lib.ptr(target), _lib.ptr(best),
+                  _lib.ptr(loss_map), _lib.ptr(stats), B, C, N, CorrectnessMapFunction.COS_EPS, float(eps))
+        ctx.eps = eps
+        ctx.save_for_backward(warped, target, best, stats, loss_map)
+        return loss_map
+
+    @staticmethod
+    def backward(ctx, grad_map):
+        warped, target, best, stats, loss_map = ctx.saved_tensors
+        B, C, N = warped.shape
+        need = ctx.needs_input_grad
+        g_warped = torch.empty_like(warped) if need[0] else None
+        g_target = torch.empty_like(target) if need[1] else None
+        g_best = torch.empty_like(best) if need[2] else None
+        if any(need[:3]):
+            _lib.call("gfla_correctness_map_bwd_f32", warped, _lib.ptr(warped), _lib.ptr(target), _lib.ptr(best),
+                      _lib.ptr(stats), _lib.ptr(loss_map), _lib.ptr(grad_map.contiguous()), _lib.ptr(g_warped),
+                      _lib.ptr(g_target), _lib.ptr(g_best), B, C, N, CorrectnessMapFunction.COS_EPS, float(ctx.eps))
+        return g_warped, g_target, g_best, None
+
+
 def max_cosine_similarity(source, target, eps=1e-8, return_index=False):
     """Best cosine match over all source positions for every target position.
 
@@ -100,6 +138,7 @@ class PerceptualCorrectness(nn.Module):
         # grid_sample convention of `bilinear_warp`: the reference targets PyTorch 1.0.0 (README.md:93),
         # whose grid_sample had no align_corners argument and behaved as align_corners=True
         self.align_corners = True
+        self.fused = True   # False: cosine_similarity / exp through torch ops, as the reference writes them
 
     def __call__(self, target, source, flow_list, used_layers, mask=None, use_bilinear_sampling=False):
         if self.vgg is None:
@@ -123,8 +162,12 @@ class PerceptualCorrectness(nn.Module):
             warped = self.bilinear_warp(source_feat, flow)
         else:
             warped = self.resample(source_feat, flow).view(b, c, -1)                  # :273
-        sampled = F.cosine_similarity(warped, target_feat.view(b, c, -1))             # :275
-        loss_map = torch.exp(-sampled / (best + self.eps))
+        if self.fused and warped.dtype == torch.float32:
+            loss_map = CorrectnessMapFunction.apply(warped.contiguous(), target_feat.reshape(b, c, -1).contiguous(),
+                                                    best, self.eps)                   # :275-276
+        else:
+            sampled = F.cosine_similarity(warped, target_feat.view(b, c, -1))
+            loss_map = torch.exp(-sampled / (best + self.eps))
         floor = torch.exp(torch.tensor(-1.0)).type_as(loss_map)
         if mask is None:
             return torch.mean(loss_map) - floor

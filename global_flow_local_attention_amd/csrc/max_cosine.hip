@@ -275,14 +275,15 @@ static int max_cosine(const float *source, const float *target, void *workspace,
   if (B == 0 || Nt == 0) return GFLA_OK;
   if (Ns > 0x7fffff00LL || Nt > 0x7fffff00LL || C > 0x7fffff00LL || B > 65535) return GFLA_ERR_UNSUPPORTED;
   const int64_t tilesN = ceil_div(Nt, kTN), nM = ceil_div(Ns, kTM);
-  // several units per workgroup slot (2 per CU) so that the last round of units is nearly full
+  // several units per workgroup slot (2 per CU) so that the tail of the launch is short
   int64_t splitM = 1;
   const int64_t slots = 2 * kNumCU;
   if (tuning(5) > 0)
     splitM = tuning(5);
   else
-    while (B * tilesN * splitM < 4 * slots && splitM * 2 <= nM) splitM *= 2;
+    splitM = ceil_div(8 * slots, B * tilesN);  // workgroups start as slots free up: many short units pack best
   if (splitM > nM) splitM = nM;
+  if (splitM < 1) splitM = 1;
   const int64_t total = B * tilesN * splitM;
   if (total > 0x7ffffff0LL) return GFLA_ERR_UNSUPPORTED;
   hipStream_t stream = static_cast<hipStream_t>(stream_);

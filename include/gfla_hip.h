@@ -236,6 +236,20 @@ int gfla_max_cosine_fwd_f32(const float *source, const float *target, void *work
                             int32_t *out_idx, int64_t B, int64_t C, int64_t Ns, int64_t Nt, double eps,
                             gfla_stream_t stream);
 
+/* ---- per-position map of the sampling-correctness loss (external_function.py:275-276) -----------------
+ *   loss_map[b,n] = exp(-cosine_similarity(warped[b,:,n], target[b,:,n]) / (best[b,n] + eps))
+ * warped, target (B,C,N) contiguous; best (B,N) = gfla_max_cosine_fwd's out_max; eps_cos = the eps of
+ * F.cosine_similarity (1e-8), eps = the loss's own (1e-8).  forward overwrites loss_map (B,N) and
+ * stats (B,N,3) = (cos, |warped|, |target|), which backward reads back.  backward overwrites any of
+ * grad_warped (B,C,N), grad_target (B,C,N), grad_best (B,N) that is not NULL, given grad_map (B,N).    */
+int gfla_correctness_map_fwd_f32(const float *warped, const float *target, const float *best,
+                                 float *loss_map, float *stats, int64_t B, int64_t C, int64_t N,
+                                 double eps_cos, double eps, gfla_stream_t stream);
+int gfla_correctness_map_bwd_f32(const float *warped, const float *target, const float *best,
+                                 const float *stats, const float *loss_map, const float *grad_map,
+                                 float *grad_warped, float *grad_target, float *grad_best, int64_t B,
+                                 int64_t C, int64_t N, double eps_cos, double eps, gfla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

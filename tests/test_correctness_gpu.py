@@ -102,11 +102,42 @@ def test_max_cosine_gradients(gfla):
     assert_close(t.grad.cpu(), tgt.grad, 1e-5, "grad target")
 
 
+@pytest.mark.parametrize("B,C,N", [(2, 12, 70), (1, 64, 64), (3, 7, 129), (2, 256, 704)])
+def test_correctness_map_fused_vs_torch(gfla, B, C, N):
+    """exp(-cosine_similarity(x, t) / (best + eps)) and its three gradients against torch in fp64 on the host,
+    including a zero vector and one shorter than cosine_similarity's eps"""
+    x, t = features((B, C, N), 21), features((B, C, N), 22)
+    x[0, :, 3] = 0
+    t[0, :, 5] = 0
+    x[0, :, 7] *= 1e-10
+    best = (randn((B, N), seed=23).abs() * 0.5 + 0.2).contiguous()
+    up = randn((B, N), seed=24)
+    ref = [v.double().requires_grad_() for v in (x, t, best)]
+    want = torch.exp(-torch.nn.functional.cosine_similarity(ref[0], ref[1]) / (ref[2] + 1e-8))
+    (want * up.double()).sum().backward()
+    dev = [v.to(DEV).requires_grad_() for v in (x, t, best)]
+    got = gfla.CorrectnessMapFunction.apply(dev[0], dev[1], dev[2], 1e-8)
+    (got * up.to(DEV)).sum().backward()
+    assert_close(got.detach().cpu(), want.detach(), 2e-6, "loss map")
+    for d, r, what in zip(dev, ref, ("grad warped", "grad target", "grad best")):
+        ok = torch.ones_like(r.grad, dtype=torch.bool)
+        if what != "grad best":
+            ok[0, :, 7] = False     # |x| = 1e-10: fp32 underflows the squared norm; checked separately below
+        assert_close(d.grad.cpu()[ok], r.grad[ok], 1e-5, what)
+    assert torch.isfinite(dev[0].grad).all() and torch.isfinite(dev[1].grad).all()
+    # only some gradients requested
+    only = [x.to(DEV).requires_grad_(), t.to(DEV), best.to(DEV)]
+    gfla.CorrectnessMapFunction.apply(*only, 1e-8).sum().backward()
+    assert only[0].grad is not None and only[1].grad is None
+
+
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", CASES)
-def test_correctness_loss_vs_reference_golden(gfla, name):
+def test_correctness_loss_vs_reference_golden(gfla, name, fused):
     g = case(np.load(PATH), name, DEV)
     src, tgt, flow = (g[k].clone().requires_grad_() for k in ("src", "tgt", "flow"))
     mod = gfla.PerceptualCorrectness()
+    mod.fused = fused
     mod.target_vgg, mod.source_vgg = {"f": tgt}, {"f": src}
     best, index = gfla.max_cosine_similarity(src, tgt, return_index=True)
     assert_close(best.detach(), g["best"], 2e-6, "best")

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--only", default="", help="substring of the shape name")
+    ap.add_argument("--loss", action="store_true", help="also time PerceptualCorrectness.calculate_loss")
     ap.add_argument("--tuning", default="", help="key=value,... passed to gfla.set_tuning")
     a = ap.parse_args()
     for kv in filter(None, a.tuning.split(",")):
@@ -65,6 +66,20 @@ def main():
             except RuntimeError as e:  # the [B,N,N] matrix may not fit
                 row["torch_bmm_max_us"] = "failed: %s" % str(e)[:60]
         print(json.dumps(row), flush=True)
+        if a.loss:   # the whole calculate_loss (resample -> map -> mean), fused map vs torch ops, fwd + bwd
+            H, W = {704: (32, 22), 2816: (64, 44), 1024: (32, 32), 4096: (64, 64), 11264: (128, 88)}[N]
+            flow = (torch.randn(B, 2, H, W, device="cuda", generator=g) * 2).requires_grad_()
+            mod = gfla.PerceptualCorrectness()
+            mod.target_vgg, mod.source_vgg = {"f": t.view(B, C, H, W)}, {"f": s.view(B, C, H, W)}
+            out = {"shape": name, "what": "calculate_loss fwd+bwd (flow gradient only)"}
+            for fused in (True, False):
+                mod.fused = fused
+
+                def step():
+                    flow.grad = None
+                    mod.calculate_loss(flow, "f").backward()
+                out["fused_us" if fused else "torch_ops_us"] = round(timed(step, a.iters), 1)
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
