@@ -296,7 +296,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
-    rank, world, local = gdist.init_from_env()
+    # GFLA_DIST_BACKEND / GFLA_DEVICE: test hooks (e.g. two gloo ranks sharing the one GPU of a test box)
+    rank, world, local = gdist.init_from_env(os.environ.get("GFLA_DIST_BACKEND"))
+    local = int(os.environ.get("GFLA_DEVICE", local))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     device = torch.device("cuda", local)
