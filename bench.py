@@ -291,6 +291,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave the FC-layer GEMMs to hipBLASLt's default heuristics (no TunableOp)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -305,6 +307,10 @@ def main():
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True  # as the reference does (options/base_options.py:83)
 
+    # FC layers = library GEMMs; let torch pick the fastest rocBLAS/hipBLASLt solution per shape.  The tuning
+    # happens inside the priming step below (a few seconds per new shape), never in the timed region.
+    gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
+        os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop.csv"))
     hp = HotPath(args.batch, device, seed=100 + rank)
     resample = gfla.Resample2d(4, 1, 2)
 
@@ -346,7 +352,9 @@ def main():
                                "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. FC convs, "
                                "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)",
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world},
+                   "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world,
+                   "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape, tuned in the priming step)"
+                               if gemm_tuning else "hipBLASLt default heuristics"},
         "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],
                      "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"],

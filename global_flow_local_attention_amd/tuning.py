@@ -1,0 +1,36 @@
+"""Library-GEMM selection for the FC layers of ExtractorAttn.
+
+The first FC layer runs as plain fp32 GEMMs through torch (`extractor_attn._source_half_fc`): skinny ones,
+M = 128 hidden channels against K = C*k^2 and N = B*H*W.  The default heuristics of hipBLASLt pick
+75-106 TF/s solutions for them on MI355X; PyTorch's TunableOp, which times every rocBLAS / hipBLASLt
+solution once per new shape and remembers the winner, finds 105-126 TF/s ones
+(profiles/r1_tunableop_fc_gemms.txt).  This module only switches that mechanism on; the GEMMs stay library
+GEMMs.  Tuning costs a few seconds per new GEMM shape the first time it is seen (in a warm-up step) and is
+cached in `filename` (validated by torch against the torch / ROCm / hipBLASLt versions that produced it).
+"""
+import os
+
+import torch
+
+
+def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tune=True):
+    """Turn TunableOp on for this process.  filename: results cache (read if present, written at exit; torch
+    appends the device ordinal).  tune=False only replays a cache.  Returns False when torch has no
+    TunableOp (nothing changes then)."""
+    tunable = getattr(torch.cuda, "tunable", None)
+    if tunable is None or not torch.cuda.is_available():
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune))
+    tunable.set_max_tuning_duration(int(max_duration_ms))
+    tunable.set_max_tuning_iterations(int(max_iterations))
+    if filename:
+        d = os.path.dirname(os.path.abspath(filename))
+        os.makedirs(d, exist_ok=True)
+        tunable.set_filename(filename)
+    return True
+
+
+def gemm_tuning_results():
+    tunable = getattr(torch.cuda, "tunable", None)
+    return list(tunable.get_results()) if tunable is not None and tunable.is_enabled() else []
