@@ -164,6 +164,26 @@ def _source_half_fc(self, source_c, flow_c, conv0, c, k, link=None):
     return F.conv2d(block_source, conv0.weight[:, c:], None, stride=k)
 
 
+class _ReplicatePad(Function):
+    """F.pad(x, pad, mode='replicate') whose backward is one gather pass (gfla_replicate_pad_bwd) instead of
+    torch's atomicAdd-per-element kernel."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad, ctx.shape = pad, x.shape
+        return F.pad(x, pad, mode="replicate")
+
+    @staticmethod
+    def backward(ctx, grad_padded):
+        B, C, H, W = ctx.shape
+        grad_padded = grad_padded.contiguous()
+        grad = grad_padded.new_empty(ctx.shape)
+        left, right, top, bottom = ctx.pad
+        _lib.call("gfla_replicate_pad_bwd_" + _lib.suffix(grad, "replicate pad"), grad, _lib.ptr(grad_padded),
+                  _lib.ptr(grad), B * C, H, W, left, right, top, bottom)
+        return grad, None
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
@@ -177,7 +197,10 @@ def _fused_attention(self, source, target, flow_field):
     # stride-1 convolution of the padded target and block_target is never built; block_source's half
     # runs on the extractor's output (see _source_half_fc).
     lo, hi = k // 2, k - 1 - k // 2
-    target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
+    if target.dtype in (torch.float32, torch.float64):
+        target_p = _ReplicatePad.apply(target, (lo, hi, lo, hi))
+    else:
+        target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
     hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
     link = _SourceGradLink() if getattr(self, "fuse_source_backward", True) else None
     hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)

@@ -221,6 +221,18 @@ GFLA_DECL_SOURCE_BWD(f32, float)
 GFLA_DECL_SOURCE_BWD(f64, double)
 #undef GFLA_DECL_SOURCE_BWD
 
+/* ---- gradient of the replicate padding in front of the target half of ExtractorAttn's first FC layer ---
+ * block_target = extractor(target, zero flow) (base_function.py:806) is the replicate-padded unfold of
+ * target; its half of the FC layer runs as a stride-1 convolution of the padded target.  Given the gradient
+ * w.r.t. the padded tensor (planes, H+top+bottom, W+left+right), overwrites grad_in (planes, H, W): border
+ * strips are folded onto the edge pixels (a gather, no atomics).                                          */
+int gfla_replicate_pad_bwd_f32(const float *grad_padded, float *grad_in, int64_t planes, int64_t H,
+                               int64_t W, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                               gfla_stream_t stream);
+int gfla_replicate_pad_bwd_f64(const double *grad_padded, double *grad_in, int64_t planes, int64_t H,
+                               int64_t W, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                               gfla_stream_t stream);
+
 /* ---- best-match cosine similarity of the sampling-correctness loss ----------------
  * Replaces, in PerceptualCorrectness.calculate_loss (external_function.py:255-268),
  *   source_norm = source / (||source||_c + eps); target_norm = target / (||target||_c + eps)

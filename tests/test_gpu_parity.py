@@ -573,3 +573,24 @@ def test_golden_vectors(gfla):
     assert torch.equal(gfla.LocalAttnReshapeFunction.apply(t("lar_in"), 3).cpu(), torch.from_numpy(z["lar_out"]))
     out = gfla.Resample2dFunction.apply(t("rs_in1"), t("rs_in2"), 4, 1)
     assert_close(out.cpu(), torch.from_numpy(z["rs_out"]), 4e-6, "golden resample2d")
+
+
+# ------------------------------------------------------------------------- replicate-pad gradient
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape,pad", [((2, 3, 7, 5), (2, 2, 2, 2)), ((1, 4, 6, 9), (1, 2, 1, 2)),
+                                       ((2, 2, 1, 4), (2, 1, 3, 0)), ((1, 1, 5, 1), (0, 3, 2, 2)),
+                                       ((3, 8, 32, 22), (1, 1, 1, 1))])
+def test_replicate_pad_gradient_matches_torch(gfla, kernel_variant, dtype, shape, pad):
+    if kernel_variant != "lds":
+        pytest.skip("no kernel variants")
+    from global_flow_local_attention_amd.extractor_attn import _ReplicatePad
+    x = randn(shape, dtype, seed=71)
+    a = x.to(DEV).requires_grad_()
+    b = x.to(DEV).requires_grad_()
+    ya = _ReplicatePad.apply(a, pad)
+    yb = F.pad(b, pad, mode="replicate")
+    assert torch.equal(ya, yb)
+    up = randn(tuple(yb.shape), dtype, seed=72).to(DEV)
+    ya.backward(up)
+    yb.backward(up)
+    assert_close(a.grad, b.grad, 1e-6 if dtype == torch.float32 else 1e-13, "replicate pad grad")
