@@ -594,3 +594,43 @@ def test_replicate_pad_gradient_matches_torch(gfla, kernel_variant, dtype, shape
     ya.backward(up)
     yb.backward(up)
     assert_close(a.grad, b.grad, 1e-6 if dtype == torch.float32 else 1e-13, "replicate pad grad")
+
+
+# ------------------------------------------------------------------------- non-finite flow values
+@pytest.mark.parametrize("k", [3, 5])
+def test_non_finite_flows_stay_in_bounds(gfla, oracle, k):
+    """NaN / inf / 1e30 flow entries must neither crash nor disturb other pixels: indices are clamped after the
+    float->int conversion (which saturates on the GPU as it does in the reference's CUDA), so the only
+    affected outputs are the taps of the poisoned pixels themselves."""
+    B, C, H, W = 2, 8, 20, 14
+    s, f = randn((B, C, H, W), seed=80), make_flow("coherent", B, H, W, seed=81)
+    bad = f.clone()
+    poison = [(0, 3, 4, float("nan")), (0, 7, 9, float("inf")), (1, 11, 2, -float("inf")), (1, 15, 13, 1e30),
+              (1, 0, 0, -1e30)]
+    for b, y, x, v in poison:
+        bad[b, :, y, x] = v
+    clean = torch.ones(B, 1, H, W, dtype=torch.bool)
+    for b, y, x, _ in poison:
+        clean[b, 0, y, x] = False
+    sd = s.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, bad.to(DEV))
+    want = oracle.block_extractor_fwd(s, f, k)
+    mask = clean.repeat_interleave(k, 2).repeat_interleave(k, 3).expand(-1, C, -1, -1)
+    assert_close(out.detach().cpu()[mask], want[mask], F32_FWD, "clean pixels, extractor")
+    up = torch.where(mask, randn(tuple(out.shape), seed=82), torch.zeros(())).to(DEV)
+    out.backward(up)                      # poisoned pixels receive zero upstream gradient
+    gs, _ = oracle.block_extractor_bwd(s, f, up.cpu(), k)
+    got = sd.grad.cpu()
+    # a NaN/inf weight times a zero gradient is NaN (in the reference's atomicAdd as well): only the few
+    # source positions the poisoned pixels' clamped taps land on may be non-finite, all others must agree
+    finite = torch.isfinite(got)
+    assert (~finite).sum().item() <= len(poison) * 4 * k * k * C
+    assert_close(got[finite], gs[finite], F32_GRAD, "grad source away from the poisoned taps")
+    r = gfla.Resample2d(4, 1, 2)(s.to(DEV), bad.to(DEV))
+    rw = oracle.resample2d_module_fwd(s, f, 4, 1, 2.0)
+    m2 = clean.expand(-1, C, -1, -1)
+    assert_close(r.cpu()[m2], rw[m2], F32_FWD, "clean pixels, resample2d")
+    att = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    res = att(s.to(DEV), s.flip(0).to(DEV).contiguous(), bad.to(DEV))
+    assert res.shape == (B, C, H, W)
+    torch.cuda.synchronize()
