@@ -2,8 +2,8 @@
 #include "gfla_common.h"
 
 namespace gfla {
-static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
+static int g_tuning[16] = {0};
+int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
 }  // namespace gfla
 
 extern "C" {
@@ -21,7 +21,7 @@ const char *gfla_status_string(int status) {
 }
 
 int gfla_set_tuning(int key, int value) {
-  if (key < 0 || key >= 8) return 0;
+  if (key < 0 || key >= 16) return 0;
   int old = gfla::g_tuning[key];
   gfla::g_tuning[key] = value;
   return old;

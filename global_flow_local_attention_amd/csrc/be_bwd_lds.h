@@ -297,19 +297,19 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
   // the factored / unfold forms are only produced for planes that fit; the tensor form may window
-  PlaneGeo g = mode == kGoutTensor ? lds_geometry(Hs, Ws, bytes, B, C, Hf, Wf, K + 3)
-                                   : plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, true);
+  PlaneGeo g = mode == kGoutTensor ? lds_geometry(Hs, Ws, bytes, B, C, Hf, Wf, K + 3, 1)
+                                   : plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, true, 1);
   if (g.G == 0) return GFLA_OK;
   const int64_t blocks = B * g.ngroups * g.split;
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), blk(kLdsThreads);
 #define GFLA_BE_BWD_LAUNCH(S, F, AT)                                                                 \
   if (AT == kGoutTensor && g.margin >= 0)                                                            \
-    be_bwd_lds_kernel<T, K, S, F, kGoutTensor, true><<<grid, blk, g.lds_bytes, stream>>>(            \
+    launch_lds(be_bwd_lds_kernel<T, K, S, F, kGoutTensor, true>, grid, blk, g.lds_bytes, stream,             \
         src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups,     \
         g.split, g.per, g.margin, u_cs, u_bs);                                                       \
   else                                                                                               \
-    be_bwd_lds_kernel<T, K, S, F, AT, false><<<grid, blk, g.lds_bytes, stream>>>(                    \
+    launch_lds(be_bwd_lds_kernel<T, K, S, F, AT, false>, grid, blk, g.lds_bytes, stream,                     \
       src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split,   \
       g.per, g.margin, u_cs, u_bs)
   if (mode == kGoutUnfoldAttn) {

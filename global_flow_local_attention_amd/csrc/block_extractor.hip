@@ -217,15 +217,15 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
   const int variant = tuning(0);
   if (variant != 1) {
     // work items = output positions; one flow row = k output rows of (k*Wf)/V positions
-    PlaneGeo g = lds_geometry(Hs, Ws, sizeof(A), B, C, Hf, (int64_t)k * ((k * Wf) / V), k + 1);
+    PlaneGeo g = lds_geometry(Hs, Ws, sizeof(A), B, C, Hf, (int64_t)k * ((k * Wf) / V), k + 1, 1);
     if (g.G > 0) {
       const int64_t blocks = B * g.ngroups * g.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       if (g.margin < 0)
-        be_fwd_lds_kernel<T, V, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+        launch_lds(be_fwd_lds_kernel<T, V, false>, dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream, 
             src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
       else
-        be_fwd_lds_kernel<T, V, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+        launch_lds(be_fwd_lds_kernel<T, V, true>, dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream, 
             src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k, g.G, g.ngroups, g.split, g.per, g.margin);
       return launch_status();
     }
@@ -573,7 +573,7 @@ static int block_extractor_unfold_fwd(const T *src, const T *flow, T *out, int64
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   int64_t cs, bs;
   unfold_strides(layout, B, C, (int64_t)(Hf * Wf), k, &cs, &bs);
-  GFLA_BE_K_SWITCH(k, be_unfold_fwd_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream>>>(
+  GFLA_BE_K_SWITCH(k, launch_lds(be_unfold_fwd_lds_kernel<T, K>, dim3((unsigned)blocks), dim3(kLdsThreads), g.lds_bytes, stream, 
                           src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, cs, bs));
   return launch_status();
 }
@@ -631,7 +631,7 @@ int gfla_block_extractor_bwd_f64(const double *s, const double *f, const double 
 }
 int gfla_unfold_supported(int64_t Hs, int64_t Ws, int k, int elem_size) {
   const int acc = elem_size == 8 ? 8 : 4;
-  return (k >= 1 && k <= 5 && Hs > 0 && Ws > 0 && Hs * Ws * (int64_t)(8 + acc) <= gfla::kLdsBudget) ? 1 : 0;
+  return (k >= 1 && k <= 5 && Hs > 0 && Ws > 0 && Hs * Ws * (int64_t)(8 + acc) <= gfla::lds_budget()) ? 1 : 0;
 }
 int gfla_block_extractor_unfold_fwd_f32(const float *s, const float *f, float *o, int64_t B, int64_t C,
                                         int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, int layout,

@@ -16,7 +16,13 @@
 
 namespace gfla {
 
-constexpr int kLdsBudget = 64 * 1024;  // per workgroup: two workgroups of 512 threads per CU
+constexpr int kLdsBudgetDefault = 64 * 1024;  // per workgroup: two workgroups of 512 threads per CU
+// tuning key 10 (KB) overrides it; more than 64 KB needs the kernel attribute raised (launch_lds below)
+inline int64_t lds_budget() {
+  const int kb = tuning(10);
+  return kb >= 16 && kb <= 160 ? (int64_t)kb * 1024 : kLdsBudgetDefault;
+}
+#define kLdsBudget (::gfla::lds_budget())
 constexpr int kLdsThreads = 512;
 
 // LDS atomic add without return value.  Measured on MI355X (profiles/r1_ubench_lds_atomics.txt):
@@ -61,16 +67,37 @@ __device__ __forceinline__ Window make_window(int yf_first, int yf_last, int k_l
 // plane_elems: elements of one plane; bytes_per_elem: LDS bytes one channel needs per plane element
 // (sizeof(arithmetic type) for a gather plane, 8 for a scatter plane, their sum for both);
 // work_items: positions one (b, group) iterates over.
+// chunk = 0: as many planes as fit (halved while the launch has < 2 workgroups per CU).
+// chunk >= 1 (gather kernels; the kernel processes channels `chunk` at a time): G is chosen to minimise
+//   rounds(G) * (chunk * ceil(G / chunk) + 3),   rounds = ceil(B * ceil(C / G) / (2 workgroups * 256 CUs)),
+// i.e. launches whose last round of workgroups is nearly empty and channel slots that are computed but
+// not used are avoided; the 3 stands for the per-pixel setup a workgroup pays once for its G channels.
+// Measured on MI355X at the bench shapes (profiles/r1_g_sweep.txt): aggregate fwd L2 177 -> 116 us (G 5 -> 4),
+// resample fwd relu4_1 58 -> 42 us (G 23 -> 16), relu3_1 90 -> 80 (5 -> 4).
 inline PlaneGeo plane_geometry(int64_t plane_elems, int bytes_per_elem, int64_t B, int64_t C,
-                               int64_t work_items, bool allow_split) {
+                               int64_t work_items, bool allow_split, int chunk = 0) {
   PlaneGeo g{0, 0, 1, 0, 0, -1};
   const int64_t per_channel = plane_elems * bytes_per_elem;
   if (per_channel > kLdsBudget) return g;
   int64_t G = kLdsBudget / per_channel;
   if (G > C) G = C;
-  if (tuning(4) > 0 && tuning(4) < G) G = tuning(4);
-  // keep >= 2 workgroups per CU in flight when the batch is small
-  while (G > 1 && B * ceil_div(C, G) < 2 * kNumCU) G = (G + 1) / 2;
+  if (tuning(4) > 0) {
+    if (tuning(4) < G) G = tuning(4);
+  } else if (chunk > 0) {
+    int64_t best = G, best_cost = -1;
+    for (int64_t cand = G; cand >= 1; --cand) {
+      const int64_t rounds = ceil_div(B * ceil_div(C, cand), 2 * kNumCU);
+      const int64_t cost = rounds * (ceil_div(cand, chunk) * chunk + 3);
+      if (best_cost < 0 || cost < best_cost) {
+        best = cand;
+        best_cost = cost;
+      }
+    }
+    G = best;
+  } else {
+    // keep >= 2 workgroups per CU in flight when the batch is small
+    while (G > 1 && B * ceil_div(C, G) < 2 * kNumCU) G = (G + 1) / 2;
+  }
   g.G = (int)G;
   g.ngroups = (int)ceil_div(C, G);
   int split = 1;
@@ -115,11 +142,21 @@ inline PlaneGeo band_geometry(int64_t H, int64_t W, int bytes_per_elem, int64_t 
 
 // Either the whole plane (plane_geometry) or a row window (band_geometry).
 inline PlaneGeo lds_geometry(int64_t H, int64_t W, int bytes_per_elem, int64_t B, int64_t C, int64_t Hf,
-                             int64_t items_per_row, int k_span) {
-  PlaneGeo g = plane_geometry(H * W, bytes_per_elem, B, C, Hf * items_per_row, true);
+                             int64_t items_per_row, int k_span, int chunk = 0) {
+  PlaneGeo g = plane_geometry(H * W, bytes_per_elem, B, C, Hf * items_per_row, true, chunk);
   if (g.G > 0) return g;
   if (tuning(7) == 1) return g;  // windows disabled
   return band_geometry(H, W, bytes_per_elem, B, C, Hf, items_per_row, k_span);
+}
+
+// Launch a kernel with `lds` bytes of dynamic LDS; above 64 KB the per-kernel limit has to be raised first.
+template <typename... KArgs, typename... Args>
+inline void launch_lds(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream,
+                       Args... args) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  kernel<<<grid, block, lds, stream>>>(args...);
 }
 
 // global (n contiguous storage elements) -> LDS (arithmetic type), all threads of the block

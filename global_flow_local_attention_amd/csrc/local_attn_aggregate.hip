@@ -566,11 +566,11 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   if (tuning(3) != 1) {
-    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), B, C, H * W, true);
+    PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), B, C, H * W, true, kAggChunk);
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_K_SWITCH(k, agg_fwd_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(
+      GFLA_K_SWITCH(k, launch_lds(agg_fwd_lds_kernel<T, K>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, 
                            src, flow, logits, out, attn_out, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, pg.G, pg.ngroups, pg.split));
       return launch_status();
     }

@@ -446,12 +446,12 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   if (tuning(6) != 1) {
-    PlaneGeo pg = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1);
+    PlaneGeo pg = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1, 1);
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg.margin < 0) rs_lds_kernel<T, KH, 0, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin);
-                                else rs_lds_kernel<T, KH, 0, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream>>>(in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg.margin < 0) launch_lds(rs_lds_kernel<T, KH, 0, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin);
+                                else launch_lds(rs_lds_kernel<T, KH, 0, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
       return launch_status();
     }
   }
@@ -476,16 +476,16 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) rs_lds_kernel<T, KH, 1, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin);
-                                else rs_lds_kernel<T, KH, 1, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream>>>(in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) launch_lds(rs_lds_kernel<T, KH, 1, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin);
+                                else launch_lds(rs_lds_kernel<T, KH, 1, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
     if (gin2) {
       const int64_t blocks = B * pg2.ngroups * pg2.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) rs_lds_kernel<T, KH, 2, false><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin);
-                                else rs_lds_kernel<T, KH, 2, true><<<dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) launch_lds(rs_lds_kernel<T, KH, 2, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin);
+                                else launch_lds(rs_lds_kernel<T, KH, 2, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
       st = launch_status();
     }
     return st;

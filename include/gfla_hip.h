@@ -59,7 +59,8 @@ const char *gfla_status_string(int status);
  *   key 4: cap on G, the channel planes one workgroup keeps in LDS (0 auto)
  *   key 5: split, workgroups sharing one (b, channel group) (0 auto)
  *   key 6: resample2d fwd/bwd        0 auto, 1 force global kernels
- *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)  */
+ *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)
+ *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)                                     */
 int gfla_set_tuning(int key, int value);
 
 /* ---- block_extractor ---------------------------------------------------------------------
