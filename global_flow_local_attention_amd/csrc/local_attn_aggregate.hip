@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
 // that share each element.  One coalesced atomic per (ij, super-group) publishes the sums; the
 // softmax Jacobian needs the totals over ALL channels and is applied by agg_softmax_bwd_kernel.
 template <typename T, int K>
-__global__ __launch_bounds__(256) void agg_ga_lds_kernel(
+__global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     T *__restrict__ glogits, int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles) {
   using A = typename Num<T>::acc;
@@ -420,12 +420,19 @@ __global__ __launch_bounds__(256) void agg_ga_lds_kernel(
   const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + pc);
   PatchTaps<A, K> tp;
   tp.init(fx0, fy0, xf, yf, Hs, Ws);
-  int col[K + 1];
+  // Dense case: every tap (i, j) mixes the four patch elements (i..i+1, j..j+1) with weights that do not
+  // depend on the channel, so  ga_ij = sum_ab w_ab(i,j) * P[i+a][j+b]  with  P[r][q] = sum_c g_c v_c[r][q].
+  // Only the (K+1)^2 sums P are accumulated per channel ((K+1)^2 FMAs instead of 5 K^2); the 4-term mix
+  // happens once per pixel at the end.
+  int col[K + 1], rowoff[K + 1];
 #pragma unroll
-  for (int q = 0; q <= K; ++q) col[q] = clampi(tp.x0 + q, 0, Ws - 1);
-  A ga[KK];
+  for (int q = 0; q <= K; ++q) {
+    col[q] = clampi(tp.x0 + q, 0, Ws - 1);
+    rowoff[q] = clampi(tp.y0 + q, 0, Hs - 1) * Ws;
+  }
+  A P[(K + 1) * (K + 1)];
 #pragma unroll
-  for (int t = 0; t < KK; ++t) ga[t] = 0;
+  for (int t = 0; t < (K + 1) * (K + 1); ++t) P[t] = 0;
   const A inv_kk = (A)1 / (A)KK;
   const int cs0 = sg * CS;
   const int cs1 = min(C, cs0 + CS);
@@ -441,31 +448,10 @@ __global__ __launch_bounds__(256) void agg_ga_lds_kernel(
       for (int c = 0; c < gc; ++c) {
         const A go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
         const A *pl = planes + (size_t)c * plane_sz;
-        A vA[K + 1];
-        {
-          const int off = clampi(tp.y0, 0, Hs - 1) * Ws;
 #pragma unroll
-          for (int q = 0; q <= K; ++q) vA[q] = pl[off + col[q]];
-        }
+        for (int r = 0; r <= K; ++r)
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-          const int off = clampi(tp.y0 + i + 1, 0, Hs - 1) * Ws;
-          A vB[K + 1];
-#pragma unroll
-          for (int q = 0; q <= K; ++q) vB[q] = pl[off + col[q]];
-          const A yT_P = 1 - tp.ay[i], yB_P = tp.ay[i];
-#pragma unroll
-          for (int j = 0; j < K; ++j) {
-            const A xL_P = 1 - tp.ax[j], xR_P = tp.ax[j];
-            A bs = (xL_P * yT_P) * vA[j];  // block_extractor_kernel.cu:78-84
-            bs += (xR_P * yT_P) * vA[j + 1];
-            bs += (xL_P * yB_P) * vB[j];
-            bs += (xR_P * yB_P) * vB[j + 1];
-            ga[i * K + j] += go * bs;
-          }
-#pragma unroll
-          for (int q = 0; q <= K; ++q) vA[q] = vB[q];
-        }
+          for (int q = 0; q <= K; ++q) P[r * (K + 1) + q] += go * pl[rowoff[r] + col[q]];
       }
     } else {
       // rare (a tap within rounding of an integer): tap by tap, published directly
@@ -496,7 +482,18 @@ __global__ __launch_bounds__(256) void agg_ga_lds_kernel(
   }
   if (active && tp.dense) {
 #pragma unroll
-    for (int t = 0; t < KK; ++t) atomic_add(gl + (int64_t)t * HW, (T)ga[t]);
+    for (int i = 0; i < K; ++i) {
+      const A yT_P = 1 - tp.ay[i], yB_P = tp.ay[i];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const A xL_P = 1 - tp.ax[j], xR_P = tp.ax[j];
+        A ga = (xL_P * yT_P) * P[i * (K + 1) + j];  // block_extractor_kernel.cu:78-84
+        ga += (xR_P * yT_P) * P[i * (K + 1) + j + 1];
+        ga += (xL_P * yB_P) * P[(i + 1) * (K + 1) + j];
+        ga += (xR_P * yB_P) * P[(i + 1) * (K + 1) + j + 1];
+        atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga);
+      }
+    }
   }
 }
 
@@ -601,7 +598,7 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
     }
     // (2) d/d a_ij, then (3) the softmax Jacobian in place
     if (glogits) {
-      const int threads = 256;
+      const int threads = 512;
       const int64_t ntiles = ceil_div(H * W, threads);
       int64_t G = kLdsBudget / (Hs * Ws * (int64_t)sizeof(A));
       if (G > C) G = C;
