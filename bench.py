@@ -149,6 +149,16 @@ def algorithmic_bytes(name, a, esz=4):
         n += (B * C * Hs * Ws if a[4] is not None else 0) + (2 * B * H * W if a[5] is not None else 0)
         n += (B * k * k * H * W if a[6] is not None else 0)
         return esz * n
+    if base == "gfla_replicate_pad_bwd":  # (grad_padded, grad_in, planes, H, W, l, r, t, b)
+        planes, H, W, l, r, t, b_ = a[2:9]
+        return esz * planes * ((H + t + b_) * (W + l + r) + H * W)
+    if base == "gfla_fc_tail_fwd":  # (hs, sb, so, ht, b0, w1, b1, logits, B, Hc, HW, KK, slope)
+        B, Hc, HW, KK = a[8:12]
+        return esz * (2 * B * Hc * HW + B * KK * HW)
+    if base == "gfla_fc_tail_bwd":  # (hs, sb, so, ht, b0, w1, gl, g_hs, g_ht, act, partials, B, Hc, HW, KK, slope)
+        B, Hc, HW, KK = a[11:15]
+        writes = 1 + (a[8] is not None) + (a[9] is not None)
+        return esz * ((2 + writes) * B * Hc * HW + B * KK * HW)
     return 0
 
 
@@ -224,7 +234,7 @@ class KernelTimer:
             e0.record(stream)
             self._orig(name, ref_tensor, *args)
             e1.record(stream)
-            plain = tuple(x if isinstance(x, int) else (None if (x is None or x.value is None) else "ptr")
+            plain = tuple(x if isinstance(x, (int, float)) else (None if (x is None or x.value is None) else "ptr")
                           for x in args)
             self.records.append((name, plain, e0, e1))
 

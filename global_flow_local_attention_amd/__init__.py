@@ -8,7 +8,7 @@ from ._lib import build, exported_symbols, set_tuning  # noqa: F401
 from .block_extractor import BlockExtractor, BlockExtractorFunction  # noqa: F401
 from .local_attn_reshape import LocalAttnReshape, LocalAttnReshapeFunction  # noqa: F401
 from .resample2d import Resample2d, Resample2dFunction  # noqa: F401
-from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn,  # noqa: F401
+from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn, FcTailFunction,  # noqa: F401
                              LocalAttnAggregateFunction, patch_reference_extractor_attn)
 from .losses import AffineRegularizationLoss, MultiAffineRegularizationLoss  # noqa: F401
 from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401

@@ -34,6 +34,10 @@ _SIGNATURES = {
 _SINGLE = {
     "gfla_max_cosine_fwd_f32": [_ptr] * 5 + [_i64] * 4 + [ctypes.c_double, _ptr],
     "gfla_max_cosine_workspace_bytes": [_i64] * 3,
+    "gfla_fc_tail_fwd_f32": [_ptr, _i64, _i64] + [_ptr] * 5 + [_i64] * 3 + [_int, ctypes.c_double, _ptr],
+    "gfla_fc_tail_fwd_f64": [_ptr, _i64, _i64] + [_ptr] * 5 + [_i64] * 3 + [_int, ctypes.c_double, _ptr],
+    "gfla_fc_tail_bwd_f32": [_ptr, _i64, _i64] + [_ptr] * 8 + [_i64] * 3 + [_int, ctypes.c_double, _ptr],
+    "gfla_fc_tail_bwd_f64": [_ptr, _i64, _i64] + [_ptr] * 8 + [_i64] * 3 + [_int, ctypes.c_double, _ptr],
     "gfla_replicate_pad_bwd_f32": [_ptr] * 2 + [_i64] * 3 + [_int] * 4 + [_ptr],
     "gfla_replicate_pad_bwd_f64": [_ptr] * 2 + [_i64] * 3 + [_int] * 4 + [_ptr],
     "gfla_correctness_map_fwd_f32": [_ptr] * 5 + [_i64] * 3 + [ctypes.c_double] * 2 + [_ptr],

@@ -184,6 +184,68 @@ class _ReplicatePad(Function):
         return grad, None
 
 
+class FcTailFunction(Function):
+    """logits = conv1x1(lrelu(hs + ht + b0)) in one pass each way (csrc/fc_tail.hip; base_function.py:799-803).
+
+    hs, ht: the two halves of the first FC convolution, (B, Hc, H, W); hs may be the permuted view of the
+    GEMM's (Hc, B, H, W) output -- it is read, and its gradient written, in that layout.  w1 (KK, Hc)."""
+
+    @staticmethod
+    def forward(ctx, hs, ht, b0, w1, b1, slope):
+        _lib.require_gpu(hs, ht, w1)
+        B, Hc, H, W = hs.shape
+        if hs.stride(3) != 1 or hs.stride(2) != W:
+            hs = hs.contiguous()
+        ht = ht.contiguous()
+        w1 = w1.contiguous()
+        KK = w1.size(0)
+        logits = ht.new_empty(B, KK, H, W)
+        _lib.call("gfla_fc_tail_fwd_" + _lib.suffix(ht, "fc tail"), ht, _lib.ptr(hs), hs.stride(0), hs.stride(1),
+                  _lib.ptr(ht), _lib.ptr(b0), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(logits), B, Hc, H * W, KK,
+                  float(slope))
+        ctx.slope = slope
+        ctx.save_for_backward(hs, ht, b0, w1, b1)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        hs, ht, b0, w1, b1 = ctx.saved_tensors
+        B, Hc, H, W = ht.shape
+        KK = w1.size(0)
+        need_hs, need_ht, need_b0, need_w1, need_b1 = ctx.needs_input_grad[:5]
+        g_logits = g_logits.contiguous()
+        g_hs = torch.empty_strided(hs.shape, hs.stride(), dtype=hs.dtype, device=hs.device)
+        g_ht = torch.empty_like(ht) if need_ht else None
+        act = torch.empty_like(ht) if need_w1 else None
+        want_b0, want_b1 = need_b0 and b0 is not None, need_b1 and b1 is not None
+        partials = ht.new_empty(B * ((H * W + 63) // 64), Hc + KK) if (want_b0 or want_b1) else None
+        _lib.call("gfla_fc_tail_bwd_" + _lib.suffix(ht, "fc tail"), ht, _lib.ptr(hs), hs.stride(0), hs.stride(1),
+                  _lib.ptr(ht), _lib.ptr(b0), _lib.ptr(w1), _lib.ptr(g_logits), _lib.ptr(g_hs), _lib.ptr(g_ht),
+                  _lib.ptr(act), _lib.ptr(partials), B, Hc, H * W, KK, float(ctx.slope))
+        sums = partials.sum(0) if partials is not None else None
+        g_b0 = sums[:Hc] if want_b0 else None
+        g_b1 = sums[Hc:] if want_b1 else None
+        g_w1 = None
+        if need_w1:  # dW1 = sum_b g_logits_b act_b^T: a (KK x HW) x (HW x Hc) GEMM per sample
+            g_w1 = torch.bmm(g_logits.view(B, KK, H * W), act.view(B, Hc, H * W).transpose(1, 2)).sum(0)
+        return (g_hs if need_hs else None), g_ht, g_b0, g_w1, g_b1, None
+
+
+def _tail_slope(act):
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    return None
+
+
+def _tail_fusable(self, conv0, act, conv1, dtype, k):
+    return (getattr(self, "fuse_fc_tail", True) and _tail_slope(act) is not None
+            and dtype in (torch.float32, torch.float64) and isinstance(conv1, nn.Conv2d)
+            and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.padding == (0, 0)
+            and conv1.groups == 1 and conv1.out_channels in (1, 4, 9, 16, 25) and conv0.out_channels <= 4096)
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
@@ -201,10 +263,16 @@ def _fused_attention(self, source, target, flow_field):
         target_p = _ReplicatePad.apply(target, (lo, hi, lo, hi))
     else:
         target_p = F.pad(target, (lo, hi, lo, hi), mode="replicate")
-    hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
     link = _SourceGradLink() if getattr(self, "fuse_source_backward", True) else None
-    hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
-    logits = conv1(act(hidden))
+    if _tail_fusable(self, conv0, act, conv1, target.dtype, k):
+        hidden_t = F.conv2d(target_p, conv0.weight[:, :c], None, stride=1)
+        hidden_s = _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
+        logits = FcTailFunction.apply(hidden_s, hidden_t, conv0.bias, conv1.weight.view(conv1.out_channels, -1),
+                                      conv1.bias, _tail_slope(act))
+    else:
+        hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
+        hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
+        logits = conv1(act(hidden))
     if isinstance(last, nn.Softmax) and last.dim == 1:
         result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True, link)
     else:  # softmax=None builds the block with the plain nonlinearity instead (:794)

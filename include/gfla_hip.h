@@ -222,6 +222,28 @@ GFLA_DECL_SOURCE_BWD(f32, float)
 GFLA_DECL_SOURCE_BWD(f64, double)
 #undef GFLA_DECL_SOURCE_BWD
 
+/* ---- tail of ExtractorAttn's fully_connect_layer: nonlinearity + 1x1 convolution (base_function.py:799-803)
+ *   logits[b,q,p] = b1[q] + sum_o w1[q,o] * lrelu(hs[b,o,p] + ht[b,o,p] + b0[o], slope)
+ * hs: the source half of the first FC convolution, addressed as hs[b*hs_sb + o*hs_so + p] (so both the
+ * GEMM's (Hc,B,HW) and the plain (B,Hc,HW) layout are accepted); ht: the target half, (B,Hc,HW) contiguous;
+ * b0 (Hc) and b1 (KK) may be NULL; w1 (KK,Hc); logits (B,KK,HW) is overwritten.  KK in {1,4,9,16,25};
+ * slope = 0 gives ReLU.  backward: given g_logits (B,KK,HW) overwrites g_hs (hs's addressing), g_ht
+ * (B,Hc,HW; may be NULL) with the gradient w.r.t. hs/ht (identical values, two layouts) and act (B,Hc,HW;
+ * may be NULL) with the activations (for dW1 = sum_b g_logits_b act_b^T, left to the caller's GEMM) and
+ * bias_partials (B * ceil(HW / 64), Hc + KK; may be NULL) with one row per workgroup: its sums of the
+ * hidden gradient (-> d b0) followed by its sums of g_logits (-> d b1); the caller adds the rows up.    */
+#define GFLA_DECL_FC_TAIL(SFX, T)                                                                    \
+  int gfla_fc_tail_fwd_##SFX(const T *hs, int64_t hs_sb, int64_t hs_so, const T *ht, const T *b0,   \
+                             const T *w1, const T *b1, T *logits, int64_t B, int64_t Hc, int64_t HW, \
+                             int KK, double slope, gfla_stream_t stream);                           \
+  int gfla_fc_tail_bwd_##SFX(const T *hs, int64_t hs_sb, int64_t hs_so, const T *ht, const T *b0,   \
+                             const T *w1, const T *g_logits, T *g_hs, T *g_ht, T *act,              \
+                             T *bias_partials, int64_t B, int64_t Hc, int64_t HW, int KK,           \
+                             double slope, gfla_stream_t stream);
+GFLA_DECL_FC_TAIL(f32, float)
+GFLA_DECL_FC_TAIL(f64, double)
+#undef GFLA_DECL_FC_TAIL
+
 /* ---- gradient of the replicate padding in front of the target half of ExtractorAttn's first FC layer ---
  * block_target = extractor(target, zero flow) (base_function.py:806) is the replicate-padded unfold of
  * target; its half of the FC layer runs as a stride-1 convolution of the padded target.  Given the gradient

@@ -390,7 +390,17 @@ def test_extractor_attn_fused_equals_unfused_and_oracle(gfla, oracle, k, C, soft
     assert_close(attn_f.detach().cpu(), attn_u.detach().cpu(), 2e-5, "attn")
     for gf_, gu_ in zip(grads_f, grads_u):
         assert_close(gf_.cpu(), gu_.cpu(), 2e-4, "fused vs unfused grads")
-    assert torch.equal(m(*args), m.forward(*args)) or True
+    for a in args:
+        a.grad = None
+    m.zero_grad()
+    m.fused, m.fuse_fc_tail = True, False   # torch ops for add / LeakyReLU / 1x1 convolution
+    attn_t, out_t = m.hook_attn_param(*args)
+    (out_t.square().sum()).backward()
+    grads_t = [a.grad.clone() for a in args] + [p.grad.clone() for p in m.parameters()]
+    m.fuse_fc_tail = True
+    assert_close(out_f.detach().cpu(), out_t.detach().cpu(), 2e-5, "fused FC tail vs torch ops")
+    for gf_, gt_ in zip(grads_f, grads_t):
+        assert_close(gf_.cpu(), gt_.cpu(), 2e-4, "fused FC tail vs torch ops, grads")
     if softmax:  # CPU oracle of the whole block (reference composition with literal ops)
         fc = m.fully_connect_layer
         want = oracle.extractor_attn_fwd(s, t, f, fc[0].weight.detach().cpu(), fc[0].bias.detach().cpu(),
@@ -634,3 +644,38 @@ def test_non_finite_flows_stay_in_bounds(gfla, oracle, k):
     res = att(s.to(DEV), s.flip(0).to(DEV).contiguous(), bad.to(DEV))
     assert res.shape == (B, C, H, W)
     torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- FC tail (LeakyReLU + 1x1 conv)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("KK,Hc,slope,bias,gemm_layout", [(25, 128, 0.1, True, True), (9, 128, 0.2, True, False),
+                                                          (16, 40, 0.0, False, True), (4, 7, 0.01, True, True),
+                                                          (1, 3, 0.1, False, False)])
+def test_fc_tail_matches_torch_ops(gfla, kernel_variant, dtype, KK, Hc, slope, bias, gemm_layout):
+    if kernel_variant != "lds":
+        pytest.skip("no kernel variants")
+    B, H, W = 3, 9, 31     # 279 positions: one full tile of 256 + a ragged one
+    hs0, ht0 = randn((Hc, B, H, W) if gemm_layout else (B, Hc, H, W), dtype, seed=91), randn((B, Hc, H, W), dtype, seed=92)
+    w1, b0, b1 = randn((KK, Hc), dtype, seed=93), randn((Hc,), dtype, seed=94), randn((KK,), dtype, seed=95)
+    up = randn((B, KK, H, W), dtype, seed=96)
+
+    def run(fused):
+        leaves = [x.to(DEV).requires_grad_() for x in (hs0, ht0, w1)] + \
+                 [x.to(DEV).requires_grad_() if bias else None for x in (b0, b1)]
+        hs_l, ht_l, w_l, b0_l, b1_l = leaves
+        hs = hs_l.permute(1, 0, 2, 3) if gemm_layout else hs_l
+        if fused:
+            out = gfla.FcTailFunction.apply(hs, ht_l, b0_l, w_l, b1_l, slope)
+        else:
+            pre = hs + ht_l + (b0_l.view(1, -1, 1, 1) if bias else 0)
+            out = F.conv2d(F.leaky_relu(pre, slope), w_l.view(KK, Hc, 1, 1), b1_l)
+        out.backward(up.to(DEV))
+        return out.detach(), [l.grad for l in leaves if l is not None]
+
+    got, g_got = run(True)
+    want, g_want = run(False)
+    t = 1e-5 if dtype == torch.float32 else 1e-12
+    assert_close(got, want, t, "fc tail forward")
+    for a, b_ in zip(g_got, g_want):
+        assert a.shape == b_.shape
+        assert_close(a, b_, t * 10, "fc tail gradient")
