@@ -240,10 +240,14 @@ def _tail_slope(act):
 
 
 def _tail_fusable(self, conv0, act, conv1, dtype, k):
-    return (getattr(self, "fuse_fc_tail", True) and _tail_slope(act) is not None
+    if not (getattr(self, "fuse_fc_tail", True) and _tail_slope(act) is not None
             and dtype in (torch.float32, torch.float64) and isinstance(conv1, nn.Conv2d)
             and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.padding == (0, 0)
-            and conv1.groups == 1 and conv1.out_channels in (1, 4, 9, 16, 25) and conv0.out_channels <= 4096)
+            and conv1.dilation == (1, 1) and conv1.groups == 1 and conv1.out_channels in (1, 4, 9, 16, 25)):
+        return False
+    # the kernels keep W1 (and the forward's partial sums) in LDS: 64 KB per workgroup (csrc/fc_tail.hip)
+    hc, kk, esz = conv0.out_channels, conv1.out_channels, 4 if dtype == torch.float32 else 8
+    return conv1.in_channels == hc and max(hc * kk + hc, 4 * kk * 64) * esz <= 64 * 1024
 
 
 def _fused_attention(self, source, target, flow_field):

@@ -20,14 +20,22 @@ def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tu
     tunable = getattr(torch.cuda, "tunable", None)
     if tunable is None or not torch.cuda.is_available():
         return False
-    tunable.enable(True)
-    tunable.tuning_enable(bool(tune))
-    tunable.set_max_tuning_duration(int(max_duration_ms))
-    tunable.set_max_tuning_iterations(int(max_iterations))
-    if filename:
-        d = os.path.dirname(os.path.abspath(filename))
-        os.makedirs(d, exist_ok=True)
-        tunable.set_filename(filename)
+    try:
+        tunable.enable(True)
+        tunable.tuning_enable(bool(tune))
+        tunable.set_max_tuning_duration(int(max_duration_ms))
+        tunable.set_max_tuning_iterations(int(max_iterations))
+        if filename:
+            os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+            tunable.set_filename(filename)
+    except Exception as e:  # an optional speed-up must never take the caller down
+        import warnings
+        warnings.warn("TunableOp could not be enabled (%s); GEMMs stay on the default heuristics" % e)
+        try:
+            tunable.enable(False)
+        except Exception:
+            pass
+        return False
     return True
 
 
