@@ -61,7 +61,7 @@ def smooth_flow(B, H, W, device, gen):
 class HotPath:
     """Synthetic inputs + modules of one rank."""
 
-    def __init__(self, B, device, seed, modules=None):
+    def __init__(self, B, device, seed, modules=None, vgg_grad=True):
         gen = torch.Generator(device=device).manual_seed(seed)
         self.B, self.device = B, device
         self.attn, self.inputs, self.vgg = [], [], []
@@ -75,7 +75,7 @@ class HotPath:
             self.inputs.append((src, tgt, flow))
         self.upstream = None
         for (name, C, H, W) in VGG:
-            feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
+            feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_(vgg_grad)
             self.vgg.append(feat)
 
     def params(self):
@@ -301,6 +301,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vgg-grad", action="store_true",
+                    help="treat the VGG features fed to Resample2d as constants (what the reference's training step "
+                         "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave the FC-layer GEMMs to hipBLASLt's default heuristics (no TunableOp)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -321,7 +324,7 @@ def main():
     # happens inside the priming step below (a few seconds per new shape), never in the timed region.
     gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
         os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop.csv"))
-    hp = HotPath(args.batch, device, seed=100 + rank)
+    hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad)
     resample = gfla.Resample2d(4, 1, 2)
 
     def barrier():
@@ -360,7 +363,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
                                "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. FC convs, "
-                               "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)",
+                               "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)"
+                               + ("" if not args.no_vgg_grad else " with constant VGG features (no d/d input1)"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world,
                    "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape, tuned in the priming step)"
