@@ -400,12 +400,18 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
 template <typename T, int K>
 __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ glogits, int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles) {
+    T *__restrict__ glogits, int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles,
+    int total) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   A *planes = reinterpret_cast<A *>(gfla_smem);
-  int bid = blockIdx.x;
+  // The pixel tiles of one (sample, super-group) stage the SAME planes.  Workgroups are dealt round-robin to
+  // the 8 XCDs, so give every XCD a contiguous run of the (b, sg, tile) index space: the tiles that share
+  // planes then share one L2 instead of fetching them from HBM once per XCD.
+  const int per_xcd = (total + kNumXCD - 1) / kNumXCD;
+  int bid = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+  if (bid >= total) return;
   const int tile = bid % ntiles;
   bid /= ntiles;
   const int sg = bid % nsuper;
@@ -610,8 +616,10 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
       const int64_t blocks = B * nsuper * ntiles;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       const unsigned lds = (unsigned)(G * Hs * Ws * sizeof(A));
-      GFLA_K_SWITCH(k, agg_ga_lds_kernel<T, K><<<dim3((unsigned)blocks), dim3(threads), lds, stream>>>(
-                           src, flow, gout, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, (int)G, (int)nsuper, (int)CS, (int)ntiles));
+      const int64_t padded = ceil_div(blocks, kNumXCD) * kNumXCD;  // the XCD remap needs a multiple of 8
+      GFLA_K_SWITCH(k, agg_ga_lds_kernel<T, K><<<dim3((unsigned)padded), dim3(threads), lds, stream>>>(
+                           src, flow, gout, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, (int)G, (int)nsuper, (int)CS, (int)ntiles,
+                           (int)blocks));
       st = launch_status();
       if (st == GFLA_OK && sm) {
         const int64_t n = B * H * W;
