@@ -323,7 +323,7 @@ def main():
     # FC layers = library GEMMs; let torch pick the fastest rocBLAS/hipBLASLt solution per shape.  The tuning
     # happens inside the priming step below (a few seconds per new shape), never in the timed region.
     gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
-        os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop.csv"))
+        os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop_rank%d.csv" % rank))
     hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad)
     resample = gfla.Resample2d(4, 1, 2)
 
@@ -367,7 +367,8 @@ def main():
                                + ("" if not args.no_vgg_grad else " with constant VGG features (no d/d input1)"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world,
-                   "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape, tuned in the priming step)"
+                   "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape; shipped results for the FC "
+                               "shapes, anything else tuned in the priming step)"
                                if gemm_tuning else "hipBLASLt default heuristics"},
         "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],

@@ -13,10 +13,16 @@ import os
 import torch
 
 
-def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tune=True):
-    """Turn TunableOp on for this process.  filename: results cache (read if present, written at exit; torch
-    appends the device ordinal).  tune=False only replays a cache.  Returns False when torch has no
-    TunableOp (nothing changes then)."""
+SHIPPED_RESULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950_fc_gemms.csv")
+
+
+def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tune=True, seed=SHIPPED_RESULTS):
+    """Turn TunableOp on for this process.  filename: results cache (read if present, written at exit).
+    seed: a results file copied to `filename` when that does not exist yet -- by default the solutions tuned
+    on MI355X for the FC GEMMs of the PoseGenerator shapes (tuned/tunableop_gfx950_fc_gemms.csv); torch ignores
+    it, and tunes from scratch, when its validator lines (torch / ROCm / hipBLASLt / rocBLAS versions, GPU
+    architecture) do not match the running stack.  tune=False only replays a cache.  Returns False when
+    torch has no TunableOp (nothing changes then)."""
     tunable = getattr(torch.cuda, "tunable", None)
     if tunable is None or not torch.cuda.is_available():
         return False
@@ -27,6 +33,9 @@ def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tu
         tunable.set_max_tuning_iterations(int(max_iterations))
         if filename:
             os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+            if seed and os.path.exists(seed) and not os.path.exists(filename):
+                import shutil
+                shutil.copyfile(seed, filename)
             tunable.set_filename(filename)
     except Exception as e:  # an optional speed-up must never take the caller down
         import warnings
