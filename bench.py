@@ -322,6 +322,8 @@ def main():
 
     # FC layers = library GEMMs; let torch pick the fastest rocBLAS/hipBLASLt solution per shape.  The tuning
     # happens inside the priming step below (a few seconds per new shape), never in the timed region.
+    if not args.no_gemm_tuning:  # same idea for MIOpen: recorded find results / kernel parameters for the FC convs
+        gfla.seed_conv_db(os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_miopen_db_rank%d" % rank))
     gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
         os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop_rank%d.csv" % rank))
     hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad)
@@ -368,7 +370,8 @@ def main():
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world,
                    "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape; shipped results for the FC "
-                               "shapes, anything else tuned in the priming step)"
+                               "shapes, anything else tuned in the priming step); MIOpen user db seeded with the recorded "
+                               "find results for the FC convolutions"
                                if gemm_tuning else "hipBLASLt default heuristics"},
         "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],

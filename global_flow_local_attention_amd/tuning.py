@@ -48,6 +48,34 @@ def enable_gemm_tuning(filename=None, max_duration_ms=200, max_iterations=20, tu
     return True
 
 
+SHIPPED_MIOPEN_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "miopen")
+
+
+def seed_conv_db(directory, seed=SHIPPED_MIOPEN_DB):
+    """Point MIOpen's user databases (find results + tuned kernel parameters) at `directory`, pre-filled
+    with the entries recorded on MI355X for the target-half convolutions of the PoseGenerator shapes
+    (tuned/miopen/*.ufdb.txt, *.udb.txt).  MIOpen times each candidate once when torch asks it to `find` an
+    algorithm and does not always settle on the same implicit-GEMM configuration (the L2 backward-data
+    convolution came out at 658, 674, 689, 739 and 767 us in five runs); with the database present it reuses
+    the recorded choice and skips the search.  The file names carry the GPU and the MIOpen version, so a
+    different stack simply ignores them.  Must be called before the first convolution of the process; does
+    nothing when the user already set MIOPEN_USER_DB_PATH.  Returns the directory in use."""
+    if os.environ.get("MIOPEN_USER_DB_PATH"):
+        return os.environ["MIOPEN_USER_DB_PATH"]
+    try:
+        os.makedirs(directory, exist_ok=True)
+        if seed and os.path.isdir(seed):
+            import shutil
+            for name in os.listdir(seed):
+                dst = os.path.join(directory, name)
+                if not os.path.exists(dst):
+                    shutil.copyfile(os.path.join(seed, name), dst)
+        os.environ["MIOPEN_USER_DB_PATH"] = directory
+        return directory
+    except OSError:
+        return None
+
+
 def gemm_tuning_results():
     tunable = getattr(torch.cuda, "tunable", None)
     return list(tunable.get_results()) if tunable is not None and tunable.is_enabled() else []
