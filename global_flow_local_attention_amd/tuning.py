@@ -77,5 +77,11 @@ def seed_conv_db(directory, seed=SHIPPED_MIOPEN_DB):
 
 
 def gemm_tuning_results():
+    """The (operator, shape, chosen solution, time) rows TunableOp holds in this process; [] when it is off."""
     tunable = getattr(torch.cuda, "tunable", None)
-    return list(tunable.get_results()) if tunable is not None and tunable.is_enabled() else []
+    if tunable is None or not torch.cuda.is_available():
+        return []
+    try:
+        return list(tunable.get_results()) if tunable.is_enabled() else []
+    except Exception:
+        return []
