@@ -42,6 +42,14 @@ _SINGLE = {
     "gfla_replicate_pad_bwd_f64": [_ptr] * 2 + [_i64] * 3 + [_int] * 4 + [_ptr],
     "gfla_correctness_map_fwd_f32": [_ptr] * 5 + [_i64] * 3 + [ctypes.c_double] * 2 + [_ptr],
     "gfla_correctness_map_bwd_f32": [_ptr] * 9 + [_i64] * 3 + [ctypes.c_double] * 2 + [_ptr],
+    "gfla_fc_supported": [_i64] * 3 + [_int, _int],
+    "gfla_fc_workspace_bytes": [_i64] * 4 + [_int] * 3,
+    "gfla_fc_forward_f32": [_ptr] * 9 + [_i64] * 4 + [_int, ctypes.c_double, _int, _ptr],
+    "gfla_fc_backward_f32": [_ptr] * 12 + [_i64] * 4 + [_int, ctypes.c_double, _int, _ptr],
+    "gfla_fc_geometry": [_i64, _i64, _int, _int, _ptr],
+    "gfla_fc_conv_fwd_f32": [_ptr, _ptr, _int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
+    "gfla_fc_conv_bwd_f32": [_ptr, _int, _ptr, _ptr, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
+    "gfla_fc_tr_probe": [_ptr, _int, _ptr, _ptr, _ptr],
 }
 _FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
                   "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}

@@ -1,0 +1,309 @@
+// C ABI of the MFMA path of ExtractorAttn's fully_connect_layer (fc_gemm.hip, fc_sample.hip): one call per
+// direction, all kernels enqueued on the caller's stream, scratch memory supplied by the caller.
+//
+// Reference: model/networks/base_function.py:799-807 -- logits = Conv2d(128,k*k,1)(nonlinearity(
+// Conv2d(2C,128,k,stride k)(cat(BlockExtractor(target, 0), BlockExtractor(source, flow))))).
+#include "fc_gemm.h"
+
+namespace gfla {
+
+static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// amax slots (uint32 each): max |x| of the tensors that get split into f16 terms
+enum { kAmaxSrc = 0, kAmaxTgt = 1, kAmaxW = 2, kAmaxZs = 3, kAmaxZt = 4, kAmaxSlots = 8 };
+
+struct FcLayout {
+  FcHalf hs, ht;
+  int nch_c, cpad, nt_d, KK, dw1_tiles;
+  // forward workspace, kept for backward
+  int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, fwd_total;
+  // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, bwd_total;
+};
+
+static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode) {
+  FcLayout L;
+  L.hs = fc_half(H, W, k, true);
+  L.ht = fc_half(H, W, k, false);
+  L.nch_c = (int)ceil_div(C, kFcChunk);
+  L.cpad = L.nch_c * kFcChunk;
+  L.nt_d = (int)ceil_div(C, kFcTN);
+  L.KK = k * k;
+  const int nch_h = kFcHidden / kFcChunk;
+  int64_t o = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t at = o;
+    o += align256(bytes);
+    return at;
+  };
+  L.amax = take(kAmaxSlots * 4);
+  L.xs = take(fc_packed_bytes(B, L.nch_c, L.hs.Sx, mode));
+  L.xt = take(fc_packed_bytes(B, L.nch_c, L.ht.Sx, mode));
+  L.gs = take(B * L.hs.Mg * kFcHidden * 4);
+  L.hid = take(B * (int64_t)H * W * kFcHidden * 4);
+  L.wd_t = take(fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  L.wd_s = take(fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  L.gt = take(B * L.ht.Mg * kFcHidden * 4);
+  L.wf_t = take(fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.wf_s = take(fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.fwd_total = o;
+
+  o = 0;
+  L.dzs = take(B * L.hs.Sz * kFcHidden * 4);
+  L.dzt = take(B * L.ht.Sz * kFcHidden * 4);
+  L.dw_s = take((int64_t)L.KK * L.cpad * kFcHidden * 4);
+  L.dw_t = take((int64_t)L.KK * L.cpad * kFcHidden * 4);
+  L.zero_bytes = o;
+  L.zs_pk = take(mode ? fc_packed_bytes(B, nch_h, L.hs.Sz, mode) : 0);
+  L.zt_pk = take(mode ? fc_packed_bytes(B, nch_h, L.ht.Sz, mode) : 0);
+  L.dxs = take(B * L.hs.Mdg * (int64_t)C * 4);
+  L.dxt = take(B * L.ht.Mdg * (int64_t)C * 4);
+  const int64_t tiles = ceil_div((int64_t)H * W, 64);
+  L.b0p = take(B * tiles * kFcHidden * 4);
+  // d W1: enough workgroups to fill the chip, few enough rows to reduce
+  int t = 1;
+  while (B * t < 2 * kNumCU && t * 128 < H * W) t *= 2;
+  L.dw1_tiles = t;
+  L.dw1p = take(B * t * (32 * kFcHidden + 32) * 4);
+  L.red = take((32 * kFcHidden + 32 + kFcHidden) * 4);
+  L.bwd_total = o;
+  return L;
+}
+
+static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mode) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
+  if (!fc_mode_ok(mode) || (k != 3 && k != 5)) return GFLA_ERR_UNSUPPORTED;
+  if (B > 65535 || C > 4096 || H > 2048 || W > 2048) return GFLA_ERR_UNSUPPORTED;
+  // the input tile of the convolution (128 outputs + the tap halo) has to fit the LDS of a CU
+  const int wp = (int)W + 2 * (k - 1);
+  const int tmh = kFcTM + (k - 1) * (wp + 1);
+  const int ns = fc_nsplit(mode), pitch = mode ? 48 : 80;
+  if ((int64_t)(ns * tmh + 2 * ns * kFcTN) * pitch > 150 * 1024) return GFLA_ERR_UNSUPPORTED;
+  if ((int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
+  return GFLA_OK;
+}
+
+#define GFLA_TRY(expr)           \
+  do {                           \
+    const int rc_ = (expr);      \
+    if (rc_ != GFLA_OK) return rc_; \
+  } while (0)
+
+static int fc_forward(const float *source, const float *target, const float *flow, const float *w0, const float *b0,
+                      const float *w1, const float *b1, void *ws_, float *logits, int64_t B, int C, int H, int W,
+                      int k, float slope, int mode, hipStream_t stream) {
+  if (!source || !target || !flow || !w0 || !w1 || !ws_ || !logits) return GFLA_ERR_NULL_POINTER;
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  if (B == 0) return GFLA_OK;
+  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  unsigned char *ws = static_cast<unsigned char *>(ws_);
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  const uint32_t *a_src = mode ? amax + kAmaxSrc : nullptr, *a_tgt = mode ? amax + kAmaxTgt : nullptr;
+  const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
+  if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (mode) {
+    GFLA_TRY(fc_maxabs(source, B * (int64_t)C * H * W, amax + kAmaxSrc, stream));
+    GFLA_TRY(fc_maxabs(target, B * (int64_t)C * H * W, amax + kAmaxTgt, stream));
+    GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
+  }
+  GFLA_TRY(fc_pack_act(source, a_src, ws + L.xs, B, C, H, W, L.hs, mode, stream));
+  GFLA_TRY(fc_pack_act(target, a_tgt, ws + L.xt, B, C, H, W, L.ht, mode, stream));
+  GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
+  float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
+  const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
+  const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
+  const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
+  GFLA_TRY(fc_conv(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.M,
+                   L.hs.Wp, k, mode, a_src, a_w, stream));
+  GFLA_TRY(fc_conv(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.M,
+                   L.ht.Wp, k, mode, a_tgt, a_w, stream));
+  return fc_sample_tail_fwd(gs, gt, flow, b0, w1, b1, reinterpret_cast<float *>(ws + L.hid), logits, B, H, W, k,
+                            L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wp, L.ht.Wp, slope, stream);
+}
+
+// data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
+// Z-layout gradient map
+static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
+                            float *g_x, bool want_w, int64_t B, int C, int H, int W, int k, int mode,
+                            hipStream_t stream) {
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  const int nch_h = kFcHidden / kFcChunk;
+  float *dz = reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt));
+  unsigned char *zpk = sc + (source ? L.zs_pk : L.zt_pk);
+  uint32_t *a_z = mode ? amax + (source ? kAmaxZs : kAmaxZt) : nullptr;
+  const uint32_t *a_x = mode ? amax + (source ? kAmaxSrc : kAmaxTgt) : nullptr;
+  (void)a_x;
+  const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
+  PackedDesc Z;
+  if (mode) {
+    GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z, stream));
+    GFLA_TRY(fc_pack_z(dz, a_z, zpk, B, g.Sz, kFcHidden, mode, stream));
+    Z = fc_desc_packed(zpk, B, nch_h, g.Sz, mode);
+  } else {
+    Z = fc_desc_nhwc(dz, g.Sz, kFcHidden);
+  }
+  if (g_x) {
+    float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
+    const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
+    GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
+                     k, mode, a_z, a_w, stream));
+    GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, 0, stream));
+  }
+  if (want_w) {
+    const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
+    GFLA_TRY(fc_wgrad(X, Z, g.lead, reinterpret_cast<float *>(sc + (source ? L.dw_s : L.dw_t)), L.cpad, B, g.M, g.Wp,
+                      k, mode, stream));
+  }
+  return GFLA_OK;
+}
+
+static int fc_backward(void *ws_, const float *flow, const float *w1, const float *g_logits, void *scratch_,
+                       float *g_source, float *g_target, float *g_flow, float *g_w0, float *g_b0, float *g_w1,
+                       float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode,
+                       hipStream_t stream) {
+  if (!ws_ || !flow || !w1 || !g_logits || !scratch_) return GFLA_ERR_NULL_POINTER;
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  if (B == 0) return GFLA_OK;
+  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  const float *gs = reinterpret_cast<const float *>(ws + L.gs);
+  const float *hid = reinterpret_cast<const float *>(ws + L.hid);
+  const bool need_s = g_source || g_w0, need_t = g_target || g_w0;
+  float *dzs = need_s ? reinterpret_cast<float *>(sc + L.dzs) : nullptr;
+  float *dzt = need_t ? reinterpret_cast<float *>(sc + L.dzt) : nullptr;
+  float *b0p = g_b0 ? reinterpret_cast<float *>(sc + L.b0p) : nullptr;
+  const int64_t tiles = ceil_div((int64_t)H * W, 64);
+  GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
+                              L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
+                              stream));
+  float *red = reinterpret_cast<float *>(sc + L.red);
+  if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, stream));
+  if (g_w1 || g_b1) {
+    float *part = reinterpret_cast<float *>(sc + L.dw1p);
+    GFLA_TRY(fc_dw1(hid, g_logits, part, B, H * W, L.KK, L.dw1_tiles, slope, stream));
+    GFLA_TRY(fc_reduce_rows(part, red, B * L.dw1_tiles, 32 * kFcHidden + 32, 1.f, stream));
+    if (g_w1 && hipMemcpyAsync(g_w1, red, (size_t)L.KK * kFcHidden * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return GFLA_ERR_LAUNCH;
+    if (g_b1 && hipMemcpyAsync(g_b1, red + 32 * kFcHidden, (size_t)L.KK * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return GFLA_ERR_LAUNCH;
+  }
+  if (need_s) GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0 != nullptr, B, C, H, W, k, mode, stream));
+  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0 != nullptr, B, C, H, W, k, mode, stream));
+  if (g_w0) {
+    const uint32_t *a = mode ? amax : nullptr;
+    GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
+                             a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,
+                             a ? a + kAmaxZs : nullptr, g_w0, C, L.cpad, k, stream));
+  }
+  return GFLA_OK;
+}
+
+}  // namespace gfla
+
+extern "C" {
+using namespace gfla;
+
+int gfla_fc_supported(int64_t C, int64_t H, int64_t W, int kernel_size, int mode) {
+  return fc_args_ok(1, C, H, W, kernel_size, mode) == GFLA_OK ? 1 : 0;
+}
+
+int64_t gfla_fc_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, int mode, int which) {
+  if (fc_args_ok(B, C, H, W, kernel_size, mode) != GFLA_OK) return -1;
+  const FcLayout L = fc_layout(B, (int)C, (int)H, (int)W, kernel_size, mode);
+  return which == 0 ? L.fwd_total : L.bwd_total;
+}
+
+int gfla_fc_forward_f32(const float *source, const float *target, const float *flow, const float *w0,
+                        const float *b0, const float *w1, const float *b1, void *workspace, float *logits, int64_t B,
+                        int64_t C, int64_t H, int64_t W, int kernel_size, double slope, int mode,
+                        gfla_stream_t stream) {
+  return fc_forward(source, target, flow, w0, b0, w1, b1, workspace, logits, B, (int)C, (int)H, (int)W, kernel_size,
+                    (float)slope, mode, static_cast<hipStream_t>(stream));
+}
+
+int gfla_fc_backward_f32(void *workspace, const float *flow, const float *w1, const float *grad_logits,
+                         void *scratch, float *grad_source, float *grad_target, float *grad_flow, float *grad_w0,
+                         float *grad_b0, float *grad_w1, float *grad_b1, int64_t B, int64_t C, int64_t H, int64_t W,
+                         int kernel_size, double slope, int mode, gfla_stream_t stream) {
+  return fc_backward(workspace, flow, w1, grad_logits, scratch, grad_source, grad_target, grad_flow, grad_w0, grad_b0,
+                     grad_w1, grad_b1, B, (int)C, (int)H, (int)W, kernel_size, (float)slope, mode,
+                     static_cast<hipStream_t>(stream));
+}
+
+/* ---- pieces of the above, exposed for the parity tests ---- */
+
+/* out[0..11] = Hp, Wp, Ho, Wo, pad_t, pad_l, M, Md, lead, Sx, Sz, Mg;  out[12] = Mdg */
+int gfla_fc_geometry(int64_t H, int64_t W, int kernel_size, int is_source, int64_t *out) {
+  if (!out) return GFLA_ERR_NULL_POINTER;
+  if (H <= 0 || W <= 0 || kernel_size < 1) return GFLA_ERR_BAD_SHAPE;
+  const FcHalf g = fc_half((int)H, (int)W, kernel_size, is_source != 0);
+  const int64_t v[13] = {g.Hp, g.Wp, g.Ho, g.Wo, g.pad_t, g.pad_l, g.M, g.Md, g.lead, g.Sx, g.Sz, g.Mg, g.Mdg};
+  for (int i = 0; i < 13; ++i) out[i] = v[i];
+  return GFLA_OK;
+}
+
+/* convolved map of one half: out (B, Mg, 128) f32, row m = yo*Wp + xo (gfla_fc_geometry) */
+int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *workspace, float *out, int64_t B,
+                         int64_t C_, int64_t H_, int64_t W_, int kernel_size, int mode, gfla_stream_t stream_) {
+  if (!x || !w0 || !workspace || !out) return GFLA_ERR_NULL_POINTER;
+  const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  if (B == 0) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  const FcHalf &g = is_source ? L.hs : L.ht;
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  uint32_t *a_x = mode ? amax + (is_source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;
+  if (mode) {
+    GFLA_TRY(fc_maxabs(x, B * (int64_t)C * H * W, a_x, stream));
+    GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, a_w, stream));
+  }
+  unsigned char *xp = ws + (is_source ? L.xs : L.xt);
+  GFLA_TRY(fc_pack_act(x, a_x, xp, B, C, H, W, g, mode, stream));
+  GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
+  const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
+  const PackedDesc X = fc_desc_packed(xp, B, L.nch_c, g.Sx, mode);
+  return fc_conv(X, ws + (is_source ? L.wf_s : L.wf_t), wsplit_f, out, g.Mg * kFcHidden, kFcHidden, kFcHidden, B,
+                 L.nch_c, g.M, g.Wp, k, mode, a_x, a_w, stream);
+}
+
+/* gradients of one half from its Z-layout gradient map z (B, Sz, 128) f32 (zero outside the data, see
+ * gfla_fc_geometry): grad_x (B,C,H,W), grad_w0 (128, 2C, k, k) with the other half zero.  `workspace` must hold the
+ * result of gfla_fc_conv_fwd_f32 for the same x / w0 / half. */
+int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *scratch, float *grad_x, float *grad_w0,
+                         int64_t B, int64_t C_, int64_t H_, int64_t W_, int kernel_size, int mode,
+                         gfla_stream_t stream_) {
+  if (!z || !workspace || !scratch) return GFLA_ERR_NULL_POINTER;
+  const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  if (B == 0) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  const FcHalf &g = is_source ? L.hs : L.ht;
+  unsigned char *ws = static_cast<unsigned char *>(workspace), *sc = static_cast<unsigned char *>(scratch);
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (hipMemcpyAsync(sc + (is_source ? L.dzs : L.dzt), z, (size_t)(B * g.Sz * kFcHidden * 4), hipMemcpyDeviceToDevice,
+                     stream) != hipSuccess)
+    return GFLA_ERR_LAUNCH;
+  GFLA_TRY(fc_half_backward(L, g, is_source != 0, ws, sc, grad_x, grad_w0 != nullptr, B, C, H, W, k, mode, stream));
+  if (grad_w0) {
+    const uint32_t *a = mode ? amax : nullptr;
+    GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
+                             a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,
+                             a ? a + kAmaxZs : nullptr, grad_w0, C, L.cpad, k, stream));
+  }
+  return GFLA_OK;
+}
+
+int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out, gfla_stream_t stream) {
+  if (!image || !offsets || !out) return GFLA_ERR_NULL_POINTER;
+  return fc_tr_probe(image, n_halves, offsets, out, static_cast<hipStream_t>(stream));
+}
+}

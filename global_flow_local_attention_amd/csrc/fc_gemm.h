@@ -1,0 +1,148 @@
+// Shared declarations of the MFMA kernels behind ExtractorAttn's first FC layer (fc_gemm.hip, fc_sample.hip,
+// fc_block.hip).  See fc_gemm.hip for the formulation.
+#pragma once
+
+#include "gfla_common.h"
+
+namespace gfla {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kFcChunk = 16;   // channels per K chunk (one 16-channel record per pixel)
+constexpr int kFcTM = 128;     // output pixels per workgroup of the convolution kernel
+constexpr int kFcTN = 128;     // output channels per workgroup
+constexpr int kFcHidden = 128; // hidden_nc of ExtractorAttn (base_function.py:794)
+
+// Arithmetic of the contraction ("mode").  All three accumulate in f32 inside the MFMA.
+//   0: v_mfma_f32_32x32x2_f32 on f32 operands -- a k-ordered fmaf chain, bit-for-bit f32 (157 TF/s peak).
+//   3: operands split into THREE f16 terms (x*s = x1 + x2 + x3 exactly, s a power of two chosen from the
+//      tensor's max |x| so that nothing under/overflows), 6 cross products on v_mfma_f32_32x32x16_f16:
+//      every product term above 2^-32 of the product is kept (an f32 multiply rounds at 2^-24), so the
+//      result is f32-grade or better at 2.67x the f32 MFMA rate.
+//   2: two f16 terms, 3 cross products: per-product error 2^-21 -- far below the f32 accumulation
+//      error of a K = 2304..3200 dot product -- at 5.3x the f32 MFMA rate.
+template <int MODE>
+struct Fc;
+template <>
+struct Fc<0> {
+  static constexpr int NS = 1, ESZ = 4, REC = 64, PIECES = 4, PITCH = 80, KB = 2;
+};
+template <>
+struct Fc<2> {
+  static constexpr int NS = 2, ESZ = 2, REC = 32, PIECES = 2, PITCH = 48, KB = 1;
+};
+template <>
+struct Fc<3> {
+  static constexpr int NS = 3, ESZ = 2, REC = 32, PIECES = 2, PITCH = 48, KB = 1;
+};
+
+inline int fc_nsplit(int mode) { return mode == 0 ? 1 : mode; }
+inline int fc_esz(int mode) { return mode == 0 ? 4 : 2; }
+inline bool fc_mode_ok(int mode) { return mode == 0 || mode == 2 || mode == 3; }
+
+// An activation operand: 16-channel records, pixel-linear inside a sample (row pitch = the padded width, so a
+// k x k tap is a constant pixel offset), chunk-major.  Strides in bytes.
+struct PackedDesc {
+  const unsigned char *base;
+  int64_t split_stride;  // between the f16 terms (mode 2/3)
+  int64_t batch_stride;  // between samples
+  int64_t chunk_stride;  // between 16-channel chunks of one sample
+  int pix_stride;        // between consecutive pixels of one chunk
+};
+
+// scale = 2^(14 - e) for a tensor whose max |x| has binary exponent e: scaled values stay below 2^15 (f16 max
+// 65504) and the smallest f16 subnormal is 2^-39 of the largest element.  amax_bits = float bits of max |x|.
+__host__ __device__ __forceinline__ int fc_scale_exp(uint32_t amax_bits) {
+  const int eb = (int)((amax_bits >> 23) & 0xffu);
+  if (eb == 0 || eb == 255) return 127;  // all-zero (or non-finite) tensor: scale 1
+  int se = 268 - eb;
+  return se < 2 ? 2 : (se > 252 ? 252 : se);
+}
+__device__ __forceinline__ float fc_scale(const uint32_t *amax) {
+  return amax ? __uint_as_float((uint32_t)fc_scale_exp(*amax) << 23) : 1.f;
+}
+__device__ __forceinline__ float fc_inv_scale(const uint32_t *amax) {
+  return amax ? __uint_as_float((uint32_t)(254 - fc_scale_exp(*amax)) << 23) : 1.f;
+}
+
+// ---- geometry of one half (source or target) of the layer, shared by host code ------------------
+struct FcHalf {
+  int Hp, Wp;      // replicate-padded input (Wp = the row pitch of every linearised buffer of this half)
+  int Ho, Wo;      // convolution output domain
+  int pad_t, pad_l, pad_b, pad_r;
+  int M;           // Ho * Wp outputs per sample (columns >= Wo of a row are don't-care)
+  int Md;          // Hp * Wp = outputs per sample of the data-gradient convolution
+  int lead;        // (k-1)*(Wp+1): zero pixels ahead of the gradient map ("Z layout")
+  int64_t Sx;      // pixels per sample of the packed input (with read slack)
+  int64_t Sz;      // pixels per sample of the Z-layout gradient map
+  int64_t Mg;      // rows per sample of the f32 convolution output (tile multiple)
+  int64_t Mdg;     // rows per sample of the f32 data-gradient output
+};
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+inline FcHalf fc_half(int H, int W, int k, bool source) {
+  FcHalf g;
+  const int lo = k / 2, hi = k - 1 - lo;
+  if (source) {  // sampled at p + flow: the convolved map is needed on [-hi, H-1+lo] x [-hi, W-1+lo]
+    g.pad_t = g.pad_l = g.pad_b = g.pad_r = k - 1;
+  } else {       // zero flow: plain replicate-padded unfold
+    g.pad_t = g.pad_l = lo;
+    g.pad_b = g.pad_r = hi;
+  }
+  g.Hp = H + g.pad_t + g.pad_b;
+  g.Wp = W + g.pad_l + g.pad_r;
+  g.Ho = g.Hp - k + 1;
+  g.Wo = g.Wp - k + 1;
+  g.M = g.Ho * g.Wp;
+  g.Md = g.Hp * g.Wp;
+  g.lead = (k - 1) * (g.Wp + 1);
+  g.Mg = round_up(g.M, kFcTM);
+  g.Mdg = round_up(g.Md, kFcTM);
+  g.Sx = round_up(g.Mg + 64 + g.lead + 16, 16);
+  const int64_t need_w = g.lead + round_up(g.M, 64) + 64;  // weight-gradient kernel: K range in 64-pixel steps
+  const int64_t need_d = g.Mdg + g.lead;                   // data-gradient convolution reads Z[m + tap]
+  g.Sz = round_up((need_w > need_d ? need_w : need_d) + 16, 16);
+  return g;
+}
+
+// kernels / launchers defined in fc_gemm.hip
+int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream);
+int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
+                int mode, hipStream_t stream);
+int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
+              hipStream_t stream);
+int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
+                    int k, int mode, hipStream_t stream);
+int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
+            int n_valid, int64_t B, int nch, int M, int Wp, int k, int mode, const uint32_t *amax_x,
+            const uint32_t *amax_w, hipStream_t stream);
+int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dwacc, int cpad, int64_t B, int Mk,
+             int Wp, int k, int mode, hipStream_t stream);
+int fc_unpack_wgrad(const float *dw_t, const float *dw_s, const uint32_t *amax_xt, const uint32_t *amax_xs,
+                    const uint32_t *amax_zt, const uint32_t *amax_zs, float *grad_w0, int C, int cpad, int k,
+                    hipStream_t stream);
+PackedDesc fc_desc_packed(const void *base, int64_t B, int nch, int64_t S, int mode);
+PackedDesc fc_desc_nhwc(const float *base, int64_t S, int Cz);
+int64_t fc_packed_bytes(int64_t B, int nch, int64_t S, int mode);
+int64_t fc_wpack_bytes(int ntiles, int nch, int k, int mode);
+int fc_tr_probe(const short *image, int n_halves, const int *offsets, short *out, hipStream_t stream);
+
+// fc_sample.hip
+int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,
+                       const float *b1, float *hid, float *logits, int64_t B, int H, int W, int k, int64_t gs_bs,
+                       int64_t gt_bs, int wps, int wpt, float slope, hipStream_t stream);
+int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
+                       float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
+                       int64_t gs_bs, int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
+                       float slope, hipStream_t stream);
+int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, int HW, int KK, int tiles_per_sample,
+           float slope, hipStream_t stream);
+int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
+            int accumulate, hipStream_t stream);
+int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, hipStream_t stream);
+
+}  // namespace gfla

@@ -1,0 +1,745 @@
+// MFMA kernels for the first FC layer of ExtractorAttn, gfx950.
+//
+// Reference (model/networks/base_function.py:799-807):
+//   fully_connect_layer[0] = Conv2d(2C, 128, k, stride k) applied to cat(block_target, block_source), where
+//   block_source = BlockExtractor(source, flow), block_target = BlockExtractor(target, 0): 2*C*k*k inputs per
+//   output position, 147 + 27 GFLOP per forward at the PoseGenerator shapes -- the one real contraction on the
+//   hot path.  The reference materialises both (B,C,kH,kW) block tensors and runs a strided convolution.
+//
+// Here no block tensor (and no k^2-times-larger GEMM operand) exists in either direction:
+//   * all k*k taps of one position share ONE fractional offset, and integer shifts commute with a convolution, so
+//       FC0_source(p) = bilinear_sample( conv_kxk(replicate_extend(source, k-1), W[:, C:]), p + flow(p) )
+//     exactly, border rule (clamped index, unclamped weight; block_extractor_kernel.cu:69-76) included;
+//     FC0_target(p) = conv_kxk(replicate_pad(target), W[:, :C])(p).  Both halves are PLAIN stride-1 convolutions of
+//     small maps; the flow enters only through a 4-tap sampling of a 128-channel map (fc_sample.hip).
+//   * backward: the hidden gradient is scattered (4 taps) into the convolved map's gradient, then the data
+//     gradient is the transposed convolution (the same kernel with flipped weights) and the weight gradient a
+//     pixel-reduction GEMM.
+//
+// The convolutions are implicit GEMMs on the matrix cores:
+//   * operands are "linearised": a map is stored pixel-linear with its padded width as row pitch, 16-channel
+//     records per pixel, so tap (i,j) is the constant pixel offset i*Wp + j and an input tile is ONE contiguous
+//     range (outputs in the k-1 wrap-around columns of a row are computed and ignored: 8 % of the work);
+//   * gradient maps use the same pitch with the k-1 trailing columns of each row zero ("Z layout") and
+//     (k-1)*(Wp+1) leading zeros: the wrap-around of a tap then lands on zeros, so the transposed convolution
+//     needs no border logic at all;
+//   * a workgroup (4 waves) owns 128 output pixels x 128 output channels: the input tile (+ tap halo) of a
+//     16-channel chunk is staged once and reused by all k*k taps, the 128x16 weight tile of a tap is streamed
+//     through a double buffer; a wave accumulates 64x64 outputs in 4 MFMA 32x32 tiles;
+//   * the weight gradient reduces over pixels, which are the STRIDED dimension of the pixel-major records:
+//     ds_read_b64_tr_b16 (transposing LDS read) delivers 4 consecutive pixels of one channel per lane.
+// Arithmetic modes (fc_gemm.h): exact f32 MFMA, or f16-split operands with f32 accumulation.
+#include "fc_gemm.h"
+
+namespace gfla {
+
+// ------------------------------------------------------------------------------------------ helpers
+template <int NS>
+__device__ __forceinline__ void split_f16(float v, _Float16 (&o)[NS]) {
+  o[0] = (_Float16)v;
+  if constexpr (NS >= 2) {
+    const float r = v - (float)o[0];
+    o[1] = (_Float16)r;
+    if constexpr (NS >= 3) o[2] = (_Float16)(r - (float)o[1]);
+  }
+}
+
+// 8 consecutive channels -> one 16-byte piece per f16 term (or two pieces of f32), scaled by s
+template <int MODE>
+__device__ __forceinline__ void store_pieces(const float (&v)[8], float s, unsigned char *dst, int64_t split_stride) {
+  using F = Fc<MODE>;
+  if constexpr (MODE == 0) {
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    d[0] = make_float4(v[0], v[1], v[2], v[3]);
+    d[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    f16x8 out[F::NS];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 parts[F::NS];
+      split_f16<F::NS>(v[e] * s, parts);
+#pragma unroll
+      for (int sp = 0; sp < F::NS; ++sp) out[sp][e] = parts[sp];
+    }
+#pragma unroll
+    for (int sp = 0; sp < F::NS; ++sp) *reinterpret_cast<f16x8 *>(dst + sp * split_stride) = out[sp];
+  }
+}
+
+PackedDesc fc_desc_packed(const void *base, int64_t B, int nch, int64_t S, int mode) {
+  PackedDesc d;
+  d.base = static_cast<const unsigned char *>(base);
+  d.pix_stride = kFcChunk * fc_esz(mode);
+  d.chunk_stride = S * d.pix_stride;
+  d.batch_stride = (int64_t)nch * d.chunk_stride;
+  d.split_stride = B * d.batch_stride;
+  return d;
+}
+PackedDesc fc_desc_nhwc(const float *base, int64_t S, int Cz) {  // f32 (B, S, Cz): mode 0 reads it in place
+  PackedDesc d;
+  d.base = reinterpret_cast<const unsigned char *>(base);
+  d.pix_stride = Cz * 4;
+  d.chunk_stride = kFcChunk * 4;
+  d.batch_stride = S * (int64_t)Cz * 4;
+  d.split_stride = 0;
+  return d;
+}
+int64_t fc_packed_bytes(int64_t B, int nch, int64_t S, int mode) {
+  return (int64_t)fc_nsplit(mode) * B * nch * S * kFcChunk * fc_esz(mode);
+}
+int64_t fc_wpack_bytes(int ntiles, int nch, int k, int mode) {
+  return (int64_t)fc_nsplit(mode) * ntiles * nch * k * k * kFcTN * kFcChunk * fc_esz(mode);
+}
+
+// ------------------------------------------------------------------------------------------ max |x|
+__global__ __launch_bounds__(256) void fc_maxabs_kernel(const float *__restrict__ x, int64_t n, uint32_t *slot) {
+  uint32_t m = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+    m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot, m);
+}
+
+int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream) {
+  if (n <= 0) return GFLA_OK;
+  int64_t blocks = ceil_div(n, 256 * 16);
+  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  fc_maxabs_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(x, n, slot);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------ pack: NCHW f32 -> records
+// out[term][b][chunk][m = yp*Wp + xp][16] = src[b][16*chunk + ch][clamp(yp - pad_t)][clamp(xp - pad_l)] * scale for
+// m < Hp*Wp, zero for the read slack behind it (m < S) and for channels >= C (C not a multiple of 16).
+// A thread produces one 8-channel piece: its 8 reads are coalesced along x across the lanes, the stores contiguous.
+template <int MODE>
+__global__ __launch_bounds__(256) void fc_pack_act_kernel(const float *__restrict__ src,
+                                                         const uint32_t *__restrict__ amax,
+                                                         unsigned char *__restrict__ out, int C, int H, int W, int Hp,
+                                                         int Wp, int pad_t, int pad_l, int64_t S, int nch,
+                                                         int64_t split_stride) {
+  using F = Fc<MODE>;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (m, half)
+  const int64_t m = idx >> 1;
+  const int half = (int)(idx & 1);
+  if (m >= S) return;
+  const int cc = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (m < (int64_t)Hp * Wp) {
+    const int yp = (int)(m / Wp), xp = (int)(m - (int64_t)yp * Wp);
+    const int y = clampi(yp - pad_t, 0, H - 1), x = clampi(xp - pad_l, 0, W - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cc * kFcChunk + half * 8 + e;
+      if (c < C) v[e] = src[((b * C + c) * H + y) * (int64_t)W + x];
+    }
+  }
+  const float s = MODE == 0 ? 1.f : fc_scale(amax);
+  unsigned char *dst = out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
+  store_pieces<MODE>(v, s, dst, split_stride);
+}
+
+int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
+                int mode, hipStream_t stream) {
+  const int nch = (int)ceil_div(C, kFcChunk);
+  if (nch > 65535 || B > 65535) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)ceil_div(2 * g.Sx, 256), (unsigned)nch, (unsigned)B);
+  const PackedDesc d = fc_desc_packed(out, B, nch, g.Sx, mode);
+  unsigned char *o = static_cast<unsigned char *>(out);
+#define GFLA_LAUNCH(M_)                                                                                             \
+  fc_pack_act_kernel<M_><<<grid, 256, 0, stream>>>(src, amax, o, C, H, W, g.Hp, g.Wp, g.pad_t, g.pad_l, g.Sx, nch, \
+                                                   d.split_stride)
+  if (mode == 0) GFLA_LAUNCH(0);
+  else if (mode == 2) GFLA_LAUNCH(2);
+  else GFLA_LAUNCH(3);
+#undef GFLA_LAUNCH
+  return launch_status();
+}
+
+// ------------------------------------------------------------- pack: f32 (B, S, Cz) pixel-major -> f16 records
+// (mode 2/3 only; mode 0 reads the f32 map in place).  A thread owns one pixel and walks its chunks: the reads of
+// a wave hit every 64-byte line of the map exactly once (through L2), the stores are contiguous per chunk.
+template <int MODE>
+__global__ __launch_bounds__(256) void fc_pack_z_kernel(const float *__restrict__ z, const uint32_t *__restrict__ amax,
+                                                       unsigned char *__restrict__ out, int64_t S, int Cz,
+                                                       int64_t split_stride) {
+  using F = Fc<MODE>;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= S) return;
+  const int64_t b = blockIdx.y;
+  const int nch = Cz / kFcChunk;
+  const float s = fc_scale(amax);
+  const float4 *zp = reinterpret_cast<const float4 *>(z + (b * S + m) * Cz);
+  for (int cc = 0; cc < nch; ++cc) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4 a = zp[cc * 4 + half * 2], c = zp[cc * 4 + half * 2 + 1];
+      const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      unsigned char *dst = out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
+      store_pieces<MODE>(v, s, dst, split_stride);
+    }
+  }
+}
+
+int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
+              hipStream_t stream) {
+  if (mode == 0) return GFLA_OK;
+  const dim3 grid((unsigned)ceil_div(S, 256), (unsigned)B);
+  const PackedDesc d = fc_desc_packed(out, B, Cz / kFcChunk, S, mode);
+  unsigned char *o = static_cast<unsigned char *>(out);
+  if (mode == 2)
+    fc_pack_z_kernel<2><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
+  else
+    fc_pack_z_kernel<3><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------ pack: weights
+// conv0.weight (128, 2C, k, k), channel order (target, source) (base_function.py:805: cat((block_target, block_source))).
+// Forward tiles   wf[term][0][chunk][tap][n = 0..127][16 c]      = W[n][off + 16*chunk + c][i][j]
+// data-grad tiles wd[term][ntile][chunk][tap'][c_out = 0..127][16 n] = W[16*chunk + n][off + 128*ntile + c_out][k-1-i'][k-1-j']
+// (the transposed convolution as a convolution with flipped taps and swapped channel roles).
+template <int MODE>
+__global__ __launch_bounds__(256) void fc_pack_w_kernel(const float *__restrict__ w0, const uint32_t *__restrict__ amax,
+                                                       unsigned char *__restrict__ dst, int C, int c_off, int k,
+                                                       int dgrad, int nch, int64_t total_pieces,
+                                                       int64_t split_stride) {
+  using F = Fc<MODE>;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (ntile, chunk, tap, row, half)
+  if (idx >= total_pieces) return;
+  const int half = (int)(idx & 1);
+  const int row = (int)((idx >> 1) & 127);
+  int64_t rest = idx >> 8;
+  const int KK = k * k;
+  const int tap = (int)(rest % KK);
+  rest /= KK;
+  const int cc = (int)(rest % nch);
+  const int ntile = (int)(rest / nch);
+  const int i = tap / k, j = tap - i * k;
+  const float s = MODE == 0 ? 1.f : fc_scale(amax);
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kc = cc * kFcChunk + half * 8 + e;
+    float val = 0.f;
+    if (!dgrad) {
+      const int n = ntile * kFcTN + row;
+      if (n < kFcHidden && kc < C) val = w0[(((int64_t)n * 2 * C + c_off + kc) * k + i) * k + j];
+    } else {
+      const int co = ntile * kFcTN + row;
+      if (co < C && kc < kFcHidden) val = w0[(((int64_t)kc * 2 * C + c_off + co) * k + (k - 1 - i)) * k + (k - 1 - j)];
+    }
+    v[e] = val;
+  }
+  store_pieces<MODE>(v, s, dst + (idx >> 1) * (int64_t)F::REC + half * 8 * F::ESZ, split_stride);
+}
+
+int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
+                    int k, int mode, hipStream_t stream) {
+  const int nch_c = (int)ceil_div(C, kFcChunk), nch_h = kFcHidden / kFcChunk, nt_d = (int)ceil_div(C, kFcTN);
+  struct Job {
+    void *dst;
+    int c_off, dgrad, ntiles, nch;
+  } jobs[4] = {{wf_t, 0, 0, 1, nch_c}, {wf_s, C, 0, 1, nch_c}, {wd_t, 0, 1, nt_d, nch_h}, {wd_s, C, 1, nt_d, nch_h}};
+  for (const Job &jb : jobs) {
+    if (!jb.dst) continue;
+    const int64_t pieces = (int64_t)jb.ntiles * jb.nch * k * k * kFcTN * 2;
+    const int64_t split_stride = pieces / 2 * kFcChunk * fc_esz(mode);
+    const dim3 grid((unsigned)ceil_div(pieces, 256));
+    unsigned char *d = static_cast<unsigned char *>(jb.dst);
+    if (mode == 0)
+      fc_pack_w_kernel<0><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
+    else if (mode == 2)
+      fc_pack_w_kernel<2><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
+    else
+      fc_pack_w_kernel<3><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
+  }
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ MFMA fragments
+// One fragment = the K-slice of a 32-row operand block a lane feeds to the matrix core:
+//   mode 0: 4 consecutive channels (one 16-byte LDS slot); lanes 0-31 take slot 2*kb, lanes 32-63 slot 2*kb+1, and
+//           the four v_mfma_f32_32x32x2_f32 of a fragment pair element e of both halves (a permutation of the 8
+//           channels of the K block, the same for A and B);
+//   mode 2/3: 8 consecutive channels of each f16 term: lanes 0-31 channels 0-7, lanes 32-63 channels 8-15 -- the
+//           A/B layout of v_mfma_f32_32x32x16_f16.
+template <int MODE>
+struct Frag;
+template <>
+struct Frag<0> {
+  float4 v;
+};
+template <>
+struct Frag<2> {
+  f16x8 s[2];
+};
+template <>
+struct Frag<3> {
+  f16x8 s[3];
+};
+
+template <int MODE>
+__device__ __forceinline__ Frag<MODE> load_frag(const unsigned char *rec, int plane_stride, int kb, int kh) {
+  Frag<MODE> f;
+  if constexpr (MODE == 0) {
+    f.v = *reinterpret_cast<const float4 *>(rec + (2 * kb + kh) * 16);
+  } else {
+#pragma unroll
+    for (int sp = 0; sp < Fc<MODE>::NS; ++sp)
+      f.s[sp] = *reinterpret_cast<const f16x8 *>(rec + sp * plane_stride + kh * 16);
+  }
+  return f;
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x16 mma(const Frag<MODE> &a, const Frag<MODE> &b, f32x16 acc) {
+  if constexpr (MODE == 0) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.x, b.v.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.y, b.v.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.z, b.v.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.w, b.v.w, acc, 0, 0, 0);
+  } else if constexpr (MODE == 2) {  // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[2], b.s[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[0], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------- convolution as an implicit GEMM
+// out[b][m][n] = inv_scale * sum_{chunk, tap=(i,j), c} X[b][chunk][m + i*Wp + j][c] * Wk[ntile][chunk][tap][n][c]
+// grid (ceil(M / 128), B, ntiles); 256 threads = 4 waves as 2 (pixels) x 2 (channels), 64 x 64 outputs each.
+template <int MODE, int KS>
+__global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const unsigned char *__restrict__ Wk,
+                                                        int64_t w_split_stride, float *__restrict__ out,
+                                                        int64_t out_bs, int ldo, int n_valid, int M, int Wp, int nch,
+                                                        int tmh, const uint32_t *__restrict__ amax_x,
+                                                        const uint32_t *__restrict__ amax_w) {
+  using F = Fc<MODE>;
+  constexpr int KK = KS * KS;
+  constexpr int NBUF = MODE == 3 ? 1 : 2;  // three f16 terms: one weight buffer, so two workgroups fit a CU
+  constexpr int PITCH = F::PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  unsigned char *xs = gfla_smem;                                   // [NS][tmh][PITCH]
+  unsigned char *ws = gfla_smem + (size_t)F::NS * tmh * PITCH;     // [NBUF][NS][128][PITCH]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.x * kFcTM;
+  const int64_t b = blockIdx.y;
+  const int ntile = blockIdx.z;
+  const int64_t x_ss = X.split_stride, x_cs = X.chunk_stride;
+  const int x_ps = X.pix_stride;
+  const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)m0 * x_ps;
+  constexpr int64_t kWTile = (int64_t)kFcTN * F::REC;  // bytes of one (chunk, tap) weight tile of one term
+  const unsigned char *wg = Wk + (int64_t)ntile * nch * KK * kWTile;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  // weight tile staging: every thread moves WPT 16-byte pieces global -> registers -> LDS
+  constexpr int WPIECES = F::NS * kFcTN * F::PIECES;
+  constexpr int WPT = WPIECES / 256;
+  static_assert(WPT == 2 || WPT == 3, "weight tile pieces per thread");
+  int w_src[WPT], w_dst[WPT];  // per-thread byte offsets inside a tile (global) / a buffer (LDS)
+#pragma unroll
+  for (int q = 0; q < WPT; ++q) {
+    const int idx = t + 256 * q;
+    const int sp = idx / (kFcTN * F::PIECES), rem = idx % (kFcTN * F::PIECES);
+    w_src[q] = rem * 16;
+    w_dst[q] = (sp * kFcTN + rem / F::PIECES) * PITCH + (rem % F::PIECES) * 16;
+    (void)sp;
+  }
+  const int w_sp0 = t / (kFcTN * F::PIECES), w_sp1 = (t + 256) / (kFcTN * F::PIECES),
+            w_sp2 = (t + 512) / (kFcTN * F::PIECES);
+  uint4 wr0, wr1, wr2 = make_uint4(0, 0, 0, 0);
+#define GFLA_W_FETCH(cc_, tap_)                                                                       \
+  {                                                                                                   \
+    const unsigned char *src_ = wg + ((int64_t)(cc_) * KK + (tap_)) * kWTile;                           \
+    wr0 = *reinterpret_cast<const uint4 *>(src_ + w_sp0 * w_split_stride + w_src[0]);                   \
+    wr1 = *reinterpret_cast<const uint4 *>(src_ + w_sp1 * w_split_stride + w_src[1]);                   \
+    if constexpr (WPT == 3) wr2 = *reinterpret_cast<const uint4 *>(src_ + w_sp2 * w_split_stride + w_src[2]); \
+  }
+#define GFLA_W_STORE(buf_)                                                                            \
+  {                                                                                                   \
+    unsigned char *dst_ = ws + (size_t)(buf_) * F::NS * kFcTN * PITCH;                                 \
+    *reinterpret_cast<uint4 *>(dst_ + w_dst[0]) = wr0;                                                 \
+    *reinterpret_cast<uint4 *>(dst_ + w_dst[1]) = wr1;                                                 \
+    if constexpr (WPT == 3) *reinterpret_cast<uint4 *>(dst_ + w_dst[2]) = wr2;                         \
+  }
+  const int per = tmh * F::PIECES;  // pieces of one term of the input tile
+  const int x_total = per * F::NS;
+  const unsigned char *xa0 = xs + (size_t)(wm * 64 + l31) * PITCH;
+  const unsigned char *wb0 = ws + (size_t)(wn * 64 + l31) * PITCH;
+  const int xplane = tmh * PITCH, wplane = kFcTN * PITCH;
+
+  for (int cc = 0; cc < nch; ++cc) {
+    __syncthreads();  // every wave is done with the previous chunk's tiles
+    {  // input tile of this chunk: x_total 16-byte pieces, 4 loads in flight per thread
+      const unsigned char *src = xg + (int64_t)cc * x_cs;
+      for (int base = t; base < x_total; base += 256 * 4) {
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+#define GFLA_X_SP(idx_) (((idx_) >= per) + ((idx_) >= 2 * per))
+#define GFLA_X_REM(idx_) ((idx_)-GFLA_X_SP(idx_) * per)
+#define GFLA_X_SRC(idx_) \
+  (src + GFLA_X_SP(idx_) * x_ss + (int64_t)(GFLA_X_REM(idx_) / F::PIECES) * x_ps + (GFLA_X_REM(idx_) % F::PIECES) * 16)
+#define GFLA_X_DST(idx_) \
+  (xs + ((size_t)GFLA_X_SP(idx_) * tmh + GFLA_X_REM(idx_) / F::PIECES) * PITCH + (GFLA_X_REM(idx_) % F::PIECES) * 16)
+        if (base < x_total) v0 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base));
+        if (base + 256 < x_total) v1 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 256));
+        if (base + 512 < x_total) v2 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 512));
+        if (base + 768 < x_total) v3 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 768));
+        if (base < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base)) = v0;
+        if (base + 256 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 256)) = v1;
+        if (base + 512 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 512)) = v2;
+        if (base + 768 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 768)) = v3;
+#undef GFLA_X_SRC
+#undef GFLA_X_DST
+#undef GFLA_X_SP
+#undef GFLA_X_REM
+      }
+    }
+    GFLA_W_FETCH(cc, 0);
+    GFLA_W_STORE(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < KK; ++tap) {
+      const int buf = NBUF == 2 ? (tap & 1) : 0;
+      if (tap + 1 < KK) GFLA_W_FETCH(cc, tap + 1);
+      const int i = tap / KS, j = tap - i * KS;
+      const unsigned char *xa = xa0 + (size_t)(i * Wp + j) * PITCH;
+      const unsigned char *wb = wb0 + (size_t)buf * F::NS * wplane;
+#pragma unroll
+      for (int kb = 0; kb < F::KB; ++kb) {
+        Frag<MODE> fa[2], fb[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) fa[mb] = load_frag<MODE>(xa + mb * 32 * PITCH, xplane, kb, kh);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) fb[nb] = load_frag<MODE>(wb + nb * 32 * PITCH, wplane, kb, kh);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mma<MODE>(fa[mb], fb[nb], acc[mb][nb]);
+      }
+      if (NBUF == 1) __syncthreads();  // everyone has read the single weight buffer
+      if (tap + 1 < KK) GFLA_W_STORE(NBUF == 2 ? (buf ^ 1) : 0);
+      __syncthreads();
+    }
+  }
+#undef GFLA_W_FETCH
+#undef GFLA_W_STORE
+
+  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const float inv = MODE == 0 ? 1.f : fc_inv_scale(amax_x) * fc_inv_scale(amax_w);
+  float *ob = out + b * out_bs;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int col = ntile * kFcTN + wn * 64 + nb * 32 + l31;
+      if (col >= n_valid) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < M) ob[(int64_t)m * ldo + col] = acc[mb][nb][r] * inv;
+      }
+    }
+}
+
+template <int MODE, int KS>
+static void launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,
+                        int ldo, int n_valid, int64_t B, int nch, int M, int Wp, const uint32_t *amax_x,
+                        const uint32_t *amax_w, hipStream_t stream) {
+  using F = Fc<MODE>;
+  const int tmh = kFcTM + (KS - 1) * (Wp + 1);
+  const int nbuf = MODE == 3 ? 1 : 2;
+  const unsigned lds = (unsigned)((F::NS * tmh + nbuf * F::NS * kFcTN) * F::PITCH);
+  const dim3 grid((unsigned)ceil_div(M, kFcTM), (unsigned)B, (unsigned)ceil_div(n_valid, kFcTN));
+  auto kern = fc_conv_kernel<MODE, KS>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs, ldo,
+                                   n_valid, M, Wp, nch, tmh, amax_x, amax_w);
+}
+
+int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
+            int n_valid, int64_t B, int nch, int M, int Wp, int k, int mode, const uint32_t *amax_x,
+            const uint32_t *amax_w, hipStream_t stream) {
+  if (!fc_mode_ok(mode) || (k != 3 && k != 5)) return GFLA_ERR_UNSUPPORTED;
+  const int tmh = kFcTM + (k - 1) * (Wp + 1);
+  if ((int64_t)(fc_nsplit(mode) * tmh + 2 * fc_nsplit(mode) * kFcTN) * 80 > 150 * 1024) return GFLA_ERR_UNSUPPORTED;
+  if (B > 65535 || B <= 0 || M <= 0) return B == 0 ? GFLA_OK : GFLA_ERR_UNSUPPORTED;
+#define GFLA_CONV(M_, K_)                                                                                      \
+  launch_conv<M_, K_>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wp, amax_x, amax_w, stream)
+  if (k == 3) {
+    if (mode == 0) GFLA_CONV(0, 3);
+    else if (mode == 2) GFLA_CONV(2, 3);
+    else GFLA_CONV(3, 3);
+  } else {
+    if (mode == 0) GFLA_CONV(0, 5);
+    else if (mode == 2) GFLA_CONV(2, 5);
+    else GFLA_CONV(3, 5);
+  }
+#undef GFLA_CONV
+  return launch_status();
+}
+
+// -------------------------------------------------------------------------------- weight gradient
+// dwacc[tap][16*chunk + c][n] += sum_{b, m} X[b][chunk][m + i*Wp + j][c] * Y[b][n/16][lead + m][n%16]
+// (scaled by both operands' scales; fc_unpack_wgrad undoes that).  The reduction runs over pixels, the strided
+// dimension of both operands, so fragments come from transposing LDS reads (mode 2/3) or plain 4-byte reads
+// (mode 0).  A workgroup owns one 16-channel chunk of X, a group of 2*NB taps and a range of samples; the MFMA rows
+// are (tap parity, channel), the columns the 128 hidden channels (wave w: columns 32w..32w+31), so results leave
+// as 128-byte coalesced atomics.
+template <int MODE>
+struct WgTile {
+  static constexpr int KC = MODE == 2 ? 64 : 32;      // pixels per staged K step
+  static constexpr int PX = MODE == 0 ? 64 : 32;      // LDS pitch of an X pixel record
+  static constexpr int PY = MODE == 0 ? 512 : 320;    // LDS pitch of a Y pixel (128 channels; 256 B + 64: tr-read banks)
+};
+
+// Two ds_read_b64_tr_b16: within each group of 16 lanes the hardware reads 8 bytes (4 halves) at every lane's own
+// address and hands lane i, element j the element (i & 3) read by lane 4*j + (i >> 2) of its group -- a 4 x 16 block
+// of halves (row = 4 consecutive supplier lanes, here one pixel) delivered column-wise: lane i gets channel i of 4
+// consecutive pixels.  GFLA_TR_EMULATE builds the same thing from plain reads + shuffles (debug A/B).
+__device__ __forceinline__ s16x4 tr_read4(const unsigned char *p) {
+#ifdef GFLA_TR_EMULATE
+  const s16x4 mine = *reinterpret_cast<const s16x4 *>(p);
+  const int lane = threadIdx.x & 63, i = lane & 15, gbase = lane & 48;
+  s16x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int src = gbase + 4 * j + (i >> 2);
+    const int e0 = __shfl((int)mine[0], src), e1 = __shfl((int)mine[1], src);
+    const int e2 = __shfl((int)mine[2], src), e3 = __shfl((int)mine[3], src);
+    const int sel = i & 3;
+    out[j] = (short)(sel == 0 ? e0 : sel == 1 ? e1 : sel == 2 ? e2 : e3);
+  }
+  return out;
+#else
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+#endif
+}
+__device__ __forceinline__ f16x8 tr_read8(const unsigned char *p, int second) {
+  const s16x4 lo = tr_read4(p), hi = tr_read4(p + second);
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// debug/test entry: raw semantics of the transposing read on an arbitrary LDS image and per-lane byte offsets
+__global__ void fc_tr_probe_kernel(const short *__restrict__ image, int n_halves, const int *__restrict__ offsets,
+                                   short *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  short *img = reinterpret_cast<short *>(gfla_smem);
+  for (int i = threadIdx.x; i < n_halves; i += 64) img[i] = image[i];
+  __syncthreads();
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(gfla_smem + offsets[threadIdx.x]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+int fc_tr_probe(const short *image, int n_halves, const int *offsets, short *out, hipStream_t stream) {
+  if (n_halves <= 0 || n_halves > 16384) return GFLA_ERR_BAD_SHAPE;
+  fc_tr_probe_kernel<<<1, 64, n_halves * 2, stream>>>(image, n_halves, offsets, out);
+  return launch_status();
+}
+
+template <int MODE, int KS, int NB>
+__global__ __launch_bounds__(256, 2) void fc_wgrad_kernel(PackedDesc X, PackedDesc Y, int64_t y_lead,
+                                                         float *__restrict__ dwacc, int cpad, int Mk, int Wp,
+                                                         int spw, int B) {
+  using F = Fc<MODE>;
+  using T = WgTile<MODE>;
+  constexpr int KK = KS * KS, KC = T::KC, PX = T::PX, PY = T::PY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  const int xh = KC + (KS - 1) * (Wp + 1);               // X pixels per K step (tile + tap halo)
+  unsigned char *xs = gfla_smem;                         // [NS][xh][PX]
+  unsigned char *ys = gfla_smem + (size_t)F::NS * xh * PX;  // [NS][KC][PY]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cc = blockIdx.x, tg = blockIdx.z;
+  const int b_begin = blockIdx.y * spw, b_end = min(B, b_begin + spw);
+  const int kh = lane >> 5;
+
+  // per-lane LDS offsets of the fragments
+  int xa_off, yb_off, cb;
+  if constexpr (MODE == 0) {
+    cb = (lane >> 4) & 1;                           // MFMA row = (tap parity, channel)
+    xa_off = kh * PX + (lane & 15) * 4;
+    yb_off = kh * PY + (wave * 32 + (lane & 31)) * 4;
+  } else {
+    const int i = lane & 15;
+    cb = (lane >> 4) & 1;
+    xa_off = ((i >> 2) + 8 * kh) * PX + (i & 3) * 8;
+    yb_off = ((i >> 2) + 8 * kh) * PY + (wave * 32 + cb * 16 + (i & 3) * 4) * 2;
+  }
+  int xsh[NB];  // tap shift of this lane's MFMA rows, per row block
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int tap = tg * 2 * NB + 2 * nb + cb;
+    const int i = tap / KS, j = tap - i * KS;
+    xsh[nb] = tap < KK ? (i * Wp + j) * PX : 0;
+  }
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const int xper = xh * F::PIECES;                 // pieces of one term of the X tile
+  constexpr int yper = KC * (kFcHidden / kFcChunk) * F::PIECES;  // pieces of one term of the Y tile
+  for (int b = b_begin; b < b_end; ++b) {
+    const unsigned char *xg = X.base + (int64_t)b * X.batch_stride + (int64_t)cc * X.chunk_stride;
+    const unsigned char *yg = Y.base + (int64_t)b * Y.batch_stride + y_lead * Y.pix_stride;
+    const int64_t x_ss = X.split_stride, y_ss = Y.split_stride, y_cs = Y.chunk_stride;
+    const int x_ps = X.pix_stride, y_ps = Y.pix_stride;
+    for (int mc = 0; mc < Mk; mc += KC) {
+      __syncthreads();
+      for (int idx = t; idx < xper * F::NS; idx += 256) {
+        const int sp = (idx >= xper) + (idx >= 2 * xper);
+        const int rem = idx - sp * xper;
+        const int r = rem / F::PIECES, piece = rem % F::PIECES;
+        *reinterpret_cast<uint4 *>(xs + ((size_t)sp * xh + r) * PX + piece * 16) = *reinterpret_cast<const uint4 *>(
+            xg + sp * x_ss + (int64_t)(mc + r) * x_ps + piece * 16);
+      }
+      for (int idx = t; idx < yper * F::NS; idx += 256) {
+        const int sp = idx / yper, rem = idx % yper;
+        const int piece = rem % F::PIECES, cn = (rem / F::PIECES) % (kFcHidden / kFcChunk);
+        const int r = rem / (F::PIECES * (kFcHidden / kFcChunk));
+        *reinterpret_cast<uint4 *>(ys + ((size_t)sp * KC + r) * PY + cn * F::REC + piece * 16) =
+            *reinterpret_cast<const uint4 *>(yg + sp * y_ss + (int64_t)cn * y_cs + (int64_t)(mc + r) * y_ps + piece * 16);
+      }
+      __syncthreads();
+      if constexpr (MODE == 0) {
+#pragma unroll 4
+        for (int s = 0; s < KC / 2; ++s) {
+          const float bv = *reinterpret_cast<const float *>(ys + yb_off + 2 * s * PY);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float av = *reinterpret_cast<const float *>(xs + xa_off + xsh[nb] + 2 * s * PX);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int ks = 0; ks < KC / 16; ++ks) {
+          Frag<MODE> fb;
+#pragma unroll
+          for (int sp = 0; sp < F::NS; ++sp)
+            fb.s[sp] = tr_read8(ys + (size_t)sp * KC * PY + yb_off + ks * 16 * PY, 4 * PY);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            Frag<MODE> fa;
+#pragma unroll
+            for (int sp = 0; sp < F::NS; ++sp)
+              fa.s[sp] = tr_read8(xs + (size_t)sp * xh * PX + xa_off + xsh[nb] + ks * 16 * PX, 4 * PX);
+            acc[nb] = mma<MODE>(fa, fb, acc[nb]);
+          }
+        }
+      }
+    }
+  }
+  // rows = (tap parity, channel), columns = hidden channel 32*wave + (lane & 31)
+  const int n = wave * 32 + (lane & 31);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int tap = tg * 2 * NB + 2 * nb + (row >> 4);
+      if (tap < KK)
+        atomic_add(dwacc + ((int64_t)tap * cpad + cc * kFcChunk + (row & 15)) * kFcHidden + n, acc[nb][r]);
+    }
+}
+
+template <int MODE, int KS, int NB>
+static void launch_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dwacc, int cpad, int64_t B,
+                         int Mk, int Wp, hipStream_t stream) {
+  using F = Fc<MODE>;
+  using T = WgTile<MODE>;
+  constexpr int KK = KS * KS;
+  const int xh = T::KC + (KS - 1) * (Wp + 1);
+  const unsigned lds = (unsigned)(F::NS * (xh * T::PX + T::KC * T::PY));
+  const int ngroups = (int)ceil_div(ceil_div(KK, 2), NB);
+  const int nch = cpad / kFcChunk;
+  // samples per workgroup: keep >= 2 workgroups per CU when the batch allows, fewer atomics otherwise
+  int spw = 1;
+  while ((int64_t)nch * ngroups * ceil_div(B, spw * 2) >= 2 * kNumCU && spw < 8) spw *= 2;
+  const dim3 grid((unsigned)nch, (unsigned)ceil_div(B, spw), (unsigned)ngroups);
+  auto kern = fc_wgrad_kernel<MODE, KS, NB>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, 256, lds, stream>>>(X, Y, y_lead, dwacc, cpad, Mk, Wp, spw, (int)B);
+}
+
+int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dwacc, int cpad, int64_t B, int Mk,
+             int Wp, int k, int mode, hipStream_t stream) {
+  if (!fc_mode_ok(mode) || (k != 3 && k != 5)) return GFLA_ERR_UNSUPPORTED;
+#define GFLA_WG(M_, K_, NB_) launch_wgrad<M_, K_, NB_>(X, Y, y_lead, dwacc, cpad, B, Mk, Wp, stream)
+  if (k == 3) {
+    if (mode == 0) GFLA_WG(0, 3, 5);
+    else if (mode == 2) GFLA_WG(2, 3, 5);
+    else GFLA_WG(3, 3, 5);
+  } else {
+    if (mode == 0) GFLA_WG(0, 5, 7);
+    else if (mode == 2) GFLA_WG(2, 5, 7);
+    else GFLA_WG(3, 5, 7);
+  }
+#undef GFLA_WG
+  return launch_status();
+}
+
+// conv0.weight.grad (128, 2C, k, k) from the two accumulators [tap][cpad][128], undoing the operand scales
+__global__ __launch_bounds__(256) void fc_unpack_wgrad_kernel(const float *__restrict__ dw_t,
+                                                             const float *__restrict__ dw_s,
+                                                             const uint32_t *amax_xt, const uint32_t *amax_xs,
+                                                             const uint32_t *amax_zt, const uint32_t *amax_zs,
+                                                             float *__restrict__ gw, int C, int cpad, int k) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int KK = k * k;
+  const int64_t total = (int64_t)kFcHidden * 2 * C * KK;
+  if (idx >= total) return;
+  const int tap = (int)(idx % KK);
+  const int c2 = (int)((idx / KK) % (2 * C));
+  const int n = (int)(idx / ((int64_t)KK * 2 * C));
+  const bool src = c2 >= C;
+  const int c = src ? c2 - C : c2;
+  const float *acc = src ? dw_s : dw_t;
+  const float inv = src ? fc_inv_scale(amax_xs) * fc_inv_scale(amax_zs) : fc_inv_scale(amax_xt) * fc_inv_scale(amax_zt);
+  gw[idx] = acc[((int64_t)tap * cpad + c) * kFcHidden + n] * inv;
+}
+
+int fc_unpack_wgrad(const float *dw_t, const float *dw_s, const uint32_t *amax_xt, const uint32_t *amax_xs,
+                    const uint32_t *amax_zt, const uint32_t *amax_zs, float *grad_w0, int C, int cpad, int k,
+                    hipStream_t stream) {
+  const int64_t total = (int64_t)kFcHidden * 2 * C * k * k;
+  fc_unpack_wgrad_kernel<<<dim3((unsigned)ceil_div(total, 256)), 256, 0, stream>>>(dw_t, dw_s, amax_xt, amax_xs,
+                                                                                   amax_zt, amax_zs, grad_w0, C, cpad, k);
+  return launch_status();
+}
+
+}  // namespace gfla

@@ -1,0 +1,391 @@
+// The non-GEMM part of ExtractorAttn's fully_connect_layer in the "sample the convolved map" formulation
+// (fc_gemm.hip), gfx950.
+//
+// Reference (base_function.py:799-807): hidden = Conv2d(2C,128,k,stride k)(cat(block_target, block_source)),
+// logits = Conv2d(128, k*k, 1)(nonlinearity(hidden)).  With Gs = conv_kxk(extended source, W[:, C:]) and
+// Gt = conv_kxk(padded target, W[:, :C]) (both (pixel, 128) f32 maps out of fc_conv):
+//   forward : hidden[p, n] = b0[n] + Gt[p, n] + sum_{4 corners} w_corner(p) * Gs[q(p) + corner, n]
+//             with q = floor(p + flow(p)), the reference's corner weights / clamped indices
+//             (block_extractor_kernel.cu:66-76, applied to the convolved map instead of to every tap), then
+//             LeakyReLU and the 1x1 convolution -> logits (B, k*k, H, W).
+//   backward: d hidden = (W1^T d logits) * lrelu'(hidden); it IS the gradient of Gt (written into the zero-bordered
+//             "Z layout" the transposed convolution wants), is scattered with the 4 corner weights into the gradient
+//             of Gs (coalesced 128-channel atomics), and d flow = sum_n d hidden[n] * d/d(x,y) of the bilinear mix.
+// Work decomposition: a workgroup = 64 positions of one sample.  Sampling / scattering phases put the 128 hidden
+// channels on the lanes (a tap is 512 contiguous bytes), the 1x1 convolution puts the positions on the lanes and
+// deals the channels to the 4 waves (as fc_tail.hip); a (64 x 128) tile in LDS turns one into the other.
+#include "fc_gemm.h"
+
+namespace gfla {
+
+constexpr int kSmpPix = 64;
+constexpr int kSmpPitch = kFcHidden + 1;  // floats; odd pitch: column reads (lanes = positions) are conflict-free
+
+struct Corner {
+  int i00, i01, i10, i11;   // indices into the convolved map (row pitch wps)
+  float xl, xr, yt, yb;     // the reference's xL_P, xR_P, yT_P, yB_P
+};
+
+// block_extractor_kernel.cu:58-70 for the centre tap; the convolved map lives on [-hi, H-1+lo] x [-hi, W-1+lo]
+template <int KS>
+__device__ __forceinline__ Corner corners(float fx, float fy, int x, int y, int H, int W, int wps) {
+  constexpr int LO = KS / 2, HI = KS - 1 - LO;
+  const float dx = fx + (float)x, dy = fy + (float)y;
+  const float fdx = floorf(dx), fdy = floorf(dy);
+  Corner c;
+  c.xr = dx - fdx;
+  c.xl = 1.f - c.xr;
+  c.yb = dy - fdy;
+  c.yt = 1.f - c.yb;
+  // float clamp first: keeps the int conversion defined for huge / non-finite flows
+  const float cx = fminf(fmaxf(fdx, -(float)(HI + 1)), (float)(W + LO));
+  const float cy = fminf(fmaxf(fdy, -(float)(HI + 1)), (float)(H + LO));
+  const int qx = (int)cx, qy = (int)cy;
+  const int gx0 = clampi(qx, -HI, W - 1 + LO) + HI, gx1 = clampi(qx + 1, -HI, W - 1 + LO) + HI;
+  const int gy0 = clampi(qy, -HI, H - 1 + LO) + HI, gy1 = clampi(qy + 1, -HI, H - 1 + LO) + HI;
+  c.i00 = gy0 * wps + gx0;
+  c.i01 = gy0 * wps + gx1;
+  c.i10 = gy1 * wps + gx0;
+  c.i11 = gy1 * wps + gx1;
+  return c;
+}
+
+__device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void fc_tail_fwd_kernel(const float *__restrict__ gs, const float *__restrict__ gt,
+                                                         const float *__restrict__ flow, const float *__restrict__ b0,
+                                                         const float *__restrict__ w1, const float *__restrict__ b1,
+                                                         float *__restrict__ hid, float *__restrict__ logits, int H,
+                                                         int W, int64_t gs_bs, int64_t gt_bs, int wps, int wpt,
+                                                         float slope) {
+  constexpr int KK = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][129] hidden pre-activations
+  float *w_s = tile + kSmpPix * kSmpPitch;             // [128][KK]
+  float *red = tile;                                   // [4][KK][64] partial logits, once the tile is dead
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int HW = H * W;
+  const int64_t b = blockIdx.y;
+  const int p0 = blockIdx.x * kSmpPix;
+  for (int i = t; i < kFcHidden * KK; i += 256) {
+    const int o = i / KK, q = i - o * KK;
+    w_s[i] = w1[q * kFcHidden + o];
+  }
+  // phase A: lanes = hidden channels (lane, lane + 64); a wave walks 16 positions
+  const float *gsb = gs + b * gs_bs, *gtb = gt + b * gt_bs;
+  const float bias0 = b0 ? b0[lane] : 0.f, bias1 = b0 ? b0[lane + 64] : 0.f;
+#pragma unroll 4
+  for (int it = 0; it < kSmpPix / 4; ++it) {
+    const int pp = wave + 4 * it, p = p0 + pp;
+    float h0 = 0.f, h1 = 0.f;
+    if (p < HW) {
+      const int y = p / W, x = p - y * W;
+      const float fx = flow[(b * 2 + 0) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
+      const Corner c = corners<KS>(fx, fy, x, y, H, W, wps);
+      const float *g00 = gsb + (int64_t)c.i00 * kFcHidden + lane, *g01 = gsb + (int64_t)c.i01 * kFcHidden + lane;
+      const float *g10 = gsb + (int64_t)c.i10 * kFcHidden + lane, *g11 = gsb + (int64_t)c.i11 * kFcHidden + lane;
+      const float *tp = gtb + (int64_t)(y * wpt + x) * kFcHidden + lane;
+      const float wa = c.xl * c.yt, wb = c.xr * c.yt, wc = c.xl * c.yb, wd = c.xr * c.yb;
+      h0 = bias0 + tp[0] + (wa * g00[0] + wb * g01[0] + wc * g10[0] + wd * g11[0]);
+      h1 = bias1 + tp[64] + (wa * g00[64] + wb * g01[64] + wc * g10[64] + wd * g11[64]);
+      float *hp = hid + (b * HW + p) * kFcHidden + lane;
+      hp[0] = h0;
+      hp[64] = h1;
+    }
+    tile[pp * kSmpPitch + lane] = h0;
+    tile[pp * kSmpPitch + lane + 64] = h1;
+  }
+  __syncthreads();
+  // phase B: lanes = positions, wave s takes hidden channels s, s+4, ...
+  float acc[KK];
+#pragma unroll
+  for (int q = 0; q < KK; ++q) acc[q] = 0.f;
+#pragma unroll 4
+  for (int o = wave; o < kFcHidden; o += 4) {
+    const float a = lrelu_f(tile[lane * kSmpPitch + o], slope);
+    const float *w = w_s + o * KK;
+#pragma unroll
+    for (int q = 0; q < KK; ++q) acc[q] = fmaf(w[q], a, acc[q]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KK; ++q) red[(wave * KK + q) * kSmpPix + lane] = acc[q];
+  __syncthreads();
+  float *lg = logits + b * (int64_t)KK * HW;
+  for (int i = t; i < KK * kSmpPix; i += 256) {
+    const int q = i / kSmpPix, l = i - q * kSmpPix;
+    const int pq = p0 + l;
+    if (pq >= HW) continue;
+    float v = b1 ? b1[q] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v += red[(s * KK + q) * kSmpPix + l];
+    lg[(int64_t)q * HW + pq] = v;
+  }
+}
+
+// b0_partials: one row of 128 per workgroup (sum of d hidden over its positions); the caller adds the rows up.
+template <int KS>
+__global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
+    const float *__restrict__ gs, const float *__restrict__ flow, const float *__restrict__ hid,
+    const float *__restrict__ w1, const float *__restrict__ g_logits, float *__restrict__ dzs,
+    float *__restrict__ dzt, float *__restrict__ gflow, float *__restrict__ b0_partials, int H, int W, int64_t gs_bs,
+    int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope) {
+  constexpr int KK = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][129]: hidden pre-activations, then their gradient
+  float *w_s = tile + kSmpPix * kSmpPitch;             // [128][KK]
+  float *bsum = w_s + kFcHidden * KK;                  // [4][128]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int HW = H * W;
+  const int64_t b = blockIdx.y;
+  const int p0 = blockIdx.x * kSmpPix;
+  for (int i = t; i < kFcHidden * KK; i += 256) {
+    const int o = i / KK, q = i - o * KK;
+    w_s[i] = w1[q * kFcHidden + o];
+  }
+  for (int i = t; i < kSmpPix * kFcHidden; i += 256) {
+    const int pp = i >> 7, n = i & 127;
+    tile[pp * kSmpPitch + n] = p0 + pp < HW ? hid[(b * HW + p0 + pp) * kFcHidden + n] : 0.f;
+  }
+  __syncthreads();
+  {  // phase 1: lanes = positions: d hidden = (W1^T d logits) * lrelu'(hidden)
+    const int p = p0 + lane;
+    const bool live = p < HW;
+    float gl[KK];
+    const float *glp = g_logits + b * (int64_t)KK * HW + (live ? p : 0);
+#pragma unroll
+    for (int q = 0; q < KK; ++q) gl[q] = live ? glp[(int64_t)q * HW] : 0.f;
+#pragma unroll 4
+    for (int o = wave; o < kFcHidden; o += 4) {
+      const float pre = tile[lane * kSmpPitch + o];
+      const float *w = w_s + o * KK;
+      float ga = 0.f;
+#pragma unroll
+      for (int q = 0; q < KK; ++q) ga = fmaf(w[q], gl[q], ga);
+      tile[lane * kSmpPitch + o] = pre > 0.f ? ga : ga * slope;
+    }
+  }
+  __syncthreads();
+  // phase 2: lanes = hidden channels (lane, lane + 64); a wave walks 16 positions
+  const float *gsb = gs + b * gs_bs;
+  float *zsb = dzs ? dzs + b * zs_bs : nullptr;
+  float *ztb = dzt ? dzt + b * zt_bs : nullptr;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 2
+  for (int it = 0; it < kSmpPix / 4; ++it) {
+    const int pp = wave + 4 * it, p = p0 + pp;
+    if (p >= HW) continue;
+    const float d0 = tile[pp * kSmpPitch + lane], d1 = tile[pp * kSmpPitch + lane + 64];
+    s0 += d0;
+    s1 += d1;
+    const int y = p / W, x = p - y * W;
+    if (ztb) {
+      float *zp = ztb + (int64_t)(lead_t + y * wpt + x) * kFcHidden + lane;
+      zp[0] = d0;
+      zp[64] = d1;
+    }
+    const float fx = flow[(b * 2 + 0) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
+    const Corner c = corners<KS>(fx, fy, x, y, H, W, wps);
+    if (zsb) {
+      const float wa = c.xl * c.yt, wb = c.xr * c.yt, wc = c.xl * c.yb, wd = c.xr * c.yb;
+      float *z00 = zsb + (int64_t)(lead_s + c.i00) * kFcHidden + lane, *z01 = zsb + (int64_t)(lead_s + c.i01) * kFcHidden + lane;
+      float *z10 = zsb + (int64_t)(lead_s + c.i10) * kFcHidden + lane, *z11 = zsb + (int64_t)(lead_s + c.i11) * kFcHidden + lane;
+      atomic_add(z00, wa * d0); atomic_add(z00 + 64, wa * d1);
+      atomic_add(z01, wb * d0); atomic_add(z01 + 64, wb * d1);
+      atomic_add(z10, wc * d0); atomic_add(z10 + 64, wc * d1);
+      atomic_add(z11, wd * d0); atomic_add(z11 + 64, wd * d1);
+    }
+    if (gflow) {
+      const float *g00 = gsb + (int64_t)c.i00 * kFcHidden + lane, *g01 = gsb + (int64_t)c.i01 * kFcHidden + lane;
+      const float *g10 = gsb + (int64_t)c.i10 * kFcHidden + lane, *g11 = gsb + (int64_t)c.i11 * kFcHidden + lane;
+      const float a00 = g00[0], a01 = g01[0], a10 = g10[0], a11 = g11[0];
+      const float e00 = g00[64], e01 = g01[64], e10 = g10[64], e11 = g11[64];
+      // block_extractor_kernel.cu:160-161 with the convolved map in place of the source plane
+      float gx = d0 * (c.yt * (a01 - a00) + c.yb * (a11 - a10)) + d1 * (c.yt * (e01 - e00) + c.yb * (e11 - e10));
+      float gy = d0 * (c.xl * (a10 - a00) + c.xr * (a11 - a01)) + d1 * (c.xl * (e10 - e00) + c.xr * (e11 - e01));
+      gx = wave_sum_f(gx);
+      gy = wave_sum_f(gy);
+      if (lane == 0) {
+        gflow[(b * 2 + 0) * HW + p] = gx;
+        gflow[(b * 2 + 1) * HW + p] = gy;
+      }
+    }
+  }
+  if (b0_partials) {
+    bsum[wave * kFcHidden + lane] = s0;
+    bsum[wave * kFcHidden + lane + 64] = s1;
+    __syncthreads();
+    if (t < kFcHidden)
+      b0_partials[(b * gridDim.x + blockIdx.x) * kFcHidden + t] =
+          (bsum[t] + bsum[kFcHidden + t]) + (bsum[2 * kFcHidden + t] + bsum[3 * kFcHidden + t]);
+  }
+}
+
+static int smp_check(int64_t B, int H, int W, int k) {
+  if (B < 0 || H <= 0 || W <= 0) return GFLA_ERR_BAD_SHAPE;
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  if (B > 65535 || (int64_t)H * W > 0x3fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  return GFLA_OK;
+}
+
+int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,
+                       const float *b1, float *hid, float *logits, int64_t B, int H, int W, int k, int64_t gs_bs,
+                       int64_t gt_bs, int wps, int wpt, float slope, hipStream_t stream) {
+  if (!gs || !gt || !flow || !w1 || !hid || !logits) return GFLA_ERR_NULL_POINTER;
+  if (int rc = smp_check(B, H, W, k)) return rc;
+  if (B == 0) return GFLA_OK;
+  const dim3 grid((unsigned)ceil_div((int64_t)H * W, kSmpPix), (unsigned)B);
+  const unsigned lds = (unsigned)((kSmpPix * kSmpPitch + kFcHidden * k * k) * sizeof(float));
+  if (k == 3)
+    fc_tail_fwd_kernel<3><<<grid, 256, lds, stream>>>(gs, gt, flow, b0, w1, b1, hid, logits, H, W, gs_bs, gt_bs, wps, wpt, slope);
+  else
+    fc_tail_fwd_kernel<5><<<grid, 256, lds, stream>>>(gs, gt, flow, b0, w1, b1, hid, logits, H, W, gs_bs, gt_bs, wps, wpt, slope);
+  return launch_status();
+}
+
+int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
+                       float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
+                       int64_t gs_bs, int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
+                       float slope, hipStream_t stream) {
+  if (!gs || !flow || !hid || !w1 || !g_logits) return GFLA_ERR_NULL_POINTER;
+  if (int rc = smp_check(B, H, W, k)) return rc;
+  if (B == 0) return GFLA_OK;
+  const dim3 grid((unsigned)ceil_div((int64_t)H * W, kSmpPix), (unsigned)B);
+  const unsigned lds = (unsigned)((kSmpPix * kSmpPitch + kFcHidden * k * k + 4 * kFcHidden) * sizeof(float));
+  if (k == 3)
+    fc_tail_bwd_kernel<3><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
+                                                       gs_bs, wps, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+  else
+    fc_tail_bwd_kernel<5><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
+                                                       gs_bs, wps, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ d W1 (k*k, 128) and d b1 (k*k)
+// dW1[q][n] = sum_{b,p} g_logits[b,q,p] * lrelu(hidden[b,p,n]): a (32 x 128 x pixels) product on the f32 matrix
+// cores (rows q >= k*k are zero).  A workgroup reduces a range of positions of one sample and writes one partial
+// row of 32*128 + 32 floats (the last 32: sum_p g_logits[q]); fc_reduce_rows adds the rows.
+constexpr int kDw1Row = 32 * kFcHidden + 32;
+
+__global__ __launch_bounds__(256) void fc_dw1_kernel(const float *__restrict__ hid, const float *__restrict__ g_logits,
+                                                    float *__restrict__ partials, int HW, int KK, int per, float slope) {
+  __shared__ float gls[32][65];
+  __shared__ float hs[64][kFcHidden];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int64_t b = blockIdx.y;
+  const int p_begin = blockIdx.x * per, p_end = min(HW, p_begin + per);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int pc = p_begin; pc < p_end; pc += 64) {
+    __syncthreads();
+    for (int i = t; i < 32 * 64; i += 256) {
+      const int q = i >> 6, pp = i & 63;
+      gls[q][pp] = (q < KK && pc + pp < p_end) ? g_logits[(b * KK + q) * (int64_t)HW + pc + pp] : 0.f;
+    }
+    for (int i = t; i < 64 * kFcHidden; i += 256) {
+      const int pp = i >> 7, n = i & 127;
+      hs[pp][n] = pc + pp < p_end ? lrelu_f(hid[(b * HW + pc + pp) * (int64_t)kFcHidden + n], slope) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gls[l31][2 * s + kk], hs[2 * s + kk][wave * 32 + l31], acc, 0, 0, 0);
+    if (t < 32) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int pp = 0; pp < 64; ++pp) v += gls[t][pp];
+      bsum += v;
+    }
+  }
+  float *row = partials + (b * gridDim.x + blockIdx.x) * (int64_t)kDw1Row;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    row[q * kFcHidden + wave * 32 + l31] = acc[r];
+  }
+  if (t < 32) row[32 * kFcHidden + t] = bsum;
+}
+
+int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, int HW, int KK, int tiles_per_sample,
+           float slope, hipStream_t stream) {
+  if (!hid || !g_logits || !partials) return GFLA_ERR_NULL_POINTER;
+  if (KK > 32 || KK <= 0 || tiles_per_sample <= 0) return GFLA_ERR_UNSUPPORTED;
+  if (B <= 0) return GFLA_OK;
+  const int per = (int)round_up(ceil_div(HW, tiles_per_sample), 64);
+  fc_dw1_kernel<<<dim3((unsigned)tiles_per_sample, (unsigned)B), 256, 0, stream>>>(hid, g_logits, partials, HW, KK, per,
+                                                                                   slope);
+  return launch_status();
+}
+
+// out[c] = scale * sum_r partials[r][c]
+__global__ __launch_bounds__(256) void fc_reduce_rows_kernel(const float *__restrict__ partials, float *__restrict__ out,
+                                                            int64_t rows, int cols, float scale) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = slice; r < rows; r += 4) s += partials[r * cols + c];
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && c < cols) out[c] = scale * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, hipStream_t stream) {
+  if (cols <= 0) return GFLA_OK;
+  fc_reduce_rows_kernel<<<dim3((unsigned)ceil_div(cols, 64)), 256, 0, stream>>>(partials, out, rows, cols, scale);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ replicate-pad gradient + (pixel, C) -> NCHW
+// grad[b,c,y,x] (+)= sum of dxpad[b, (yy, xx), c] over the padded positions that clamp onto (y, x).
+__global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ dxpad, float *__restrict__ grad, int C,
+                                                     int H, int W, int Hp, int Wp, int pad_t, int pad_l,
+                                                     int64_t dx_bs, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][W + 1]
+  const int y = blockIdx.x, c0 = blockIdx.y * 64;
+  const int64_t b = blockIdx.z;
+  const int c = threadIdx.x & 63, xq = threadIdx.x >> 6;
+  const int y0 = y == 0 ? 0 : y + pad_t, y1 = y == H - 1 ? Hp - 1 : y + pad_t;
+  const float *src = dxpad + b * dx_bs + c0 + c;
+  if (c0 + c < C) {
+    for (int x = xq; x < W; x += 4) {
+      const int x0 = x == 0 ? 0 : x + pad_l, x1 = x == W - 1 ? Wp - 1 : x + pad_l;
+      float acc = 0.f;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) acc += src[(int64_t)(yy * Wp + xx) * C];
+      tile[c * (W + 1) + x] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * W; i += 256) {
+    const int cl = i / W, x = i - cl * W;
+    if (c0 + cl >= C) break;
+    float *g = grad + ((b * C + c0 + cl) * H + y) * (int64_t)W + x;
+    const float v = tile[cl * (W + 1) + x];
+    *g = accumulate ? *g + v : v;
+  }
+}
+
+int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
+            int accumulate, hipStream_t stream) {
+  if (!dxpad || !grad) return GFLA_ERR_NULL_POINTER;
+  if (B <= 0) return GFLA_OK;
+  if (B > 65535 || ceil_div(C, 64) > 65535 || (int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)H, (unsigned)ceil_div(C, 64), (unsigned)B);
+  fc_fold_kernel<<<grid, 256, (unsigned)(64 * (W + 1) * sizeof(float)), stream>>>(dxpad, grad, C, H, W, g.Hp, g.Wp, g.pad_t,
+                                                                                g.pad_l, dx_bs, accumulate);
+  return launch_status();
+}
+
+}  // namespace gfla

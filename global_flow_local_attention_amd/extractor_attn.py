@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, fc_mfma
 from .block_extractor import BlockExtractor
 from .local_attn_reshape import LocalAttnReshape
 
@@ -194,6 +194,11 @@ class FcTailFunction(Function):
     def forward(ctx, hs, ht, b0, w1, b1, slope):
         _lib.require_gpu(hs, ht, w1)
         B, Hc, H, W = hs.shape
+        if tuple(ht.shape) != (B, Hc, H, W):
+            raise ValueError("fc_tail: the two halves differ in shape: %s vs %s" % (tuple(hs.shape), tuple(ht.shape)))
+        if w1.dim() != 2 or w1.size(1) != Hc or (b0 is not None and b0.numel() != Hc) \
+                or (b1 is not None and b1.numel() != w1.size(0)):
+            raise ValueError("fc_tail: w1 %s / biases do not match %d hidden channels" % (tuple(w1.shape), Hc))
         if hs.stride(3) != 1 or hs.stride(2) != W:
             hs = hs.contiguous()
         ht = ht.contiguous()
@@ -250,14 +255,43 @@ def _tail_fusable(self, conv0, act, conv1, dtype, k):
     return conv1.in_channels == hc and max(hc * kk + hc, 4 * kk * 64) * esz <= 64 * 1024
 
 
+def _mfma_mode(self, source, target, flow_field, conv0, act, conv1, k):
+    """Arithmetic mode of the MFMA path for the FC layers (fc_mfma.py), or None to use the library path."""
+    if getattr(self, "fc_impl", "mfma") != "mfma" or _tail_slope(act) is None:
+        return None
+    mode = getattr(self, "fc_mode", None)
+    mode = fc_mfma.DEFAULT_MODE if mode is None else int(mode)
+    ok = (source.dtype == torch.float32 and target.dtype == torch.float32 and flow_field.dtype == torch.float32
+          and source.shape == target.shape and source.shape[2:] == flow_field.shape[2:]
+          and isinstance(conv0, nn.Conv2d) and isinstance(conv1, nn.Conv2d)
+          and conv0.out_channels == 128 and conv0.in_channels == 2 * source.size(1)
+          and conv0.kernel_size == (k, k) and conv0.stride == (k, k) and conv0.padding == (0, 0)
+          and conv0.dilation == (1, 1) and conv0.groups == 1
+          and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.padding == (0, 0)
+          and conv1.groups == 1 and conv1.in_channels == 128 and conv1.out_channels == k * k)
+    if not ok or mode not in fc_mfma.MODES:
+        return None
+    return mode if fc_mfma.supported(source.size(1), source.size(2), source.size(3), k, mode) else None
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
     fc = self.fully_connect_layer
     conv0, act, conv1, last = fc[0], fc[1], fc[2], fc[3]
     c = source.size(1)
+    if target.shape[2:] != flow_field.shape[2:] or target.size(1) != c:
+        # the fused forms convolve the padded target at its own resolution; the reference samples it at the
+        # flow's (base_function.py:805-807) -- only the op-by-op composition covers that
+        return _unfused_attention(self, source, target, flow_field)
     source_c = source.contiguous()
     flow_c = flow_field.contiguous()
+    mode = _mfma_mode(self, source_c, target, flow_c, conv0, act, conv1, k)
+    if mode is not None:
+        # both FC layers on the matrix cores: no block tensor, no library GEMM / convolution (fc_mfma.py)
+        logits = fc_mfma.FcMfmaFunction.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
+                                              conv1.bias, k, _tail_slope(act), mode)
+        return _aggregate(source_c, flow_c, logits, last, k, None)
     # base_function.py:805-807: conv0(cat(block_target, block_source)).  block_target is the
     # zero-flow (replicate-padded) unfold of target, so its half of the convolution equals a
     # stride-1 convolution of the padded target and block_target is never built; block_source's half
@@ -277,6 +311,11 @@ def _fused_attention(self, source, target, flow_field):
         hidden = F.conv2d(target_p, conv0.weight[:, :c], conv0.bias, stride=1)
         hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
         logits = conv1(act(hidden))
+    return _aggregate(source_c, flow_c, logits, last, k, link)
+
+
+def _aggregate(source_c, flow_c, logits, last, k, link):
+    """Softmax -> LocalAttnReshape -> multiply -> avg_pool2d (base_function.py:803,808-809) as one kernel."""
     if isinstance(last, nn.Softmax) and last.dim == 1:
         result, attn = LocalAttnAggregateFunction.apply(source_c, flow_c, logits.contiguous(), k, True, link)
     else:  # softmax=None builds the block with the plain nonlinearity instead (:794)

@@ -244,6 +244,52 @@ GFLA_DECL_FC_TAIL(f32, float)
 GFLA_DECL_FC_TAIL(f64, double)
 #undef GFLA_DECL_FC_TAIL
 
+/* ---- first FC layer of ExtractorAttn on the matrix cores (csrc/fc_gemm.hip, fc_sample.hip, fc_block.hip) -----
+ * Replaces, in ExtractorAttn.forward (model/networks/base_function.py:799-807),
+ *   block_source = extractor(source, flow); block_target = extractor(target, 0)
+ *   logits = Conv2d(128, k*k, 1)(nonlinearity(Conv2d(2C, 128, k, stride k)(cat(block_target, block_source))))
+ * i.e. the two BlockExtractor launches, the cat and both convolutions of fully_connect_layer (its softmax stays
+ * with gfla_local_attn_aggregate_*).  Neither block tensor is built:  FC0(source half) = bilinear sample, at
+ * p + flow(p), of conv_kxk(replicate-extended source, W[:, C:]) -- exact, because all k*k taps of a position share
+ * one fractional offset -- and FC0(target half) = conv_kxk(replicate-padded target, W[:, :C]); the convolutions
+ * are implicit GEMMs on MFMA, hand-written for gfx950.
+ *   source, target (B,C,H,W)  flow (B,2,H,W)  w0 = conv0.weight (128, 2C, k, k)  b0 (128) or NULL
+ *   w1 = conv1.weight (k*k, 128)  b1 (k*k) or NULL  logits (B,k*k,H,W), overwritten.  fp32; k in {3, 5}.
+ *   slope: LeakyReLU negative slope (0 = ReLU).
+ *   mode: arithmetic of the contraction -- 0: v_mfma_f32_32x32x2_f32 (exact f32 fma chain); 3: operands as three
+ *   f16 terms, six cross products, f32 accumulate (every product term above 2^-32 kept: f32-grade); 2: two f16
+ *   terms, three products (2^-21 per product).
+ *   workspace: gfla_fc_workspace_bytes(..., which = 0) bytes, 256-byte aligned; forward fills it and backward
+ *   reads it (packed inputs, convolved source map, hidden activations).  scratch: (..., which = 1) bytes.
+ * backward: given grad_logits, overwrites whichever of grad_source, grad_target (B,C,H,W), grad_flow (B,2,H,W),
+ *   grad_w0, grad_b0, grad_w1, grad_b1 is not NULL (no buffer needs zeroing).
+ * gfla_fc_supported(C, H, W, k, mode): 1 if the shape is handled (the convolution's input tile must fit LDS).  */
+int gfla_fc_supported(int64_t C, int64_t H, int64_t W, int kernel_size, int mode);
+int64_t gfla_fc_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, int mode,
+                                int which);
+int gfla_fc_forward_f32(const float *source, const float *target, const float *flow, const float *w0,
+                        const float *b0, const float *w1, const float *b1, void *workspace, float *logits,
+                        int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, double slope, int mode,
+                        gfla_stream_t stream);
+int gfla_fc_backward_f32(void *workspace, const float *flow, const float *w1, const float *grad_logits,
+                         void *scratch, float *grad_source, float *grad_target, float *grad_flow, float *grad_w0,
+                         float *grad_b0, float *grad_w1, float *grad_b1, int64_t B, int64_t C, int64_t H,
+                         int64_t W, int kernel_size, double slope, int mode, gfla_stream_t stream);
+/* Pieces of the above for the parity tests.  gfla_fc_geometry: out[0..12] = Hp, Wp, Ho, Wo, pad_top, pad_left, M,
+ * Md, lead, Sx, Sz, Mg, Mdg of one half (is_source: the source half is extended by k-1, the target half padded by
+ * k/2).  gfla_fc_conv_fwd: out (B, Mg, 128) = the convolved map of one half, row yo*Wp + xo.  gfla_fc_conv_bwd:
+ * from z (B, Sz, 128), the gradient of that map in "Z layout" (row lead + yo*Wp + xo, zero elsewhere), grad_x
+ * (B,C,H,W) and grad_w0 (128,2C,k,k; the other half zero); needs the workspace of gfla_fc_conv_fwd.
+ * gfla_fc_tr_probe: raw result of ds_read_b64_tr_b16 for an LDS image and 64 per-lane byte offsets.            */
+int gfla_fc_geometry(int64_t H, int64_t W, int kernel_size, int is_source, int64_t *out);
+int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *workspace, float *out, int64_t B,
+                         int64_t C, int64_t H, int64_t W, int kernel_size, int mode, gfla_stream_t stream);
+int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *scratch, float *grad_x,
+                         float *grad_w0, int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, int mode,
+                         gfla_stream_t stream);
+int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out,
+                     gfla_stream_t stream);
+
 /* ---- gradient of the replicate padding in front of the target half of ExtractorAttn's first FC layer ---
  * block_target = extractor(target, zero flow) (base_function.py:806) is the replicate-padded unfold of
  * target; its half of the FC layer runs as a stride-1 convolution of the padded target.  Given the gradient
