@@ -61,13 +61,15 @@ def smooth_flow(B, H, W, device, gen):
 class HotPath:
     """Synthetic inputs + modules of one rank."""
 
-    def __init__(self, B, device, seed, modules=None, vgg_grad=True):
+    def __init__(self, B, device, seed, modules=None, vgg_grad=True, fc_impl=None, fc_mode=None):
         gen = torch.Generator(device=device).manual_seed(seed)
         self.B, self.device = B, device
         self.attn, self.inputs, self.vgg = [], [], []
         torch.manual_seed(1234)  # identical FC parameters on every rank
         for i, (name, C, H, W, k) in enumerate(LAYERS):
             mod = modules[i] if modules else gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+            if fc_impl is not None:
+                mod.fc_impl, mod.fc_mode = fc_impl, fc_mode
             self.attn.append(mod.to(device))
             src = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
             tgt = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_()
@@ -306,6 +308,11 @@ def main():
                          "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave the FC-layer GEMMs to hipBLASLt's default heuristics (no TunableOp)")
+    ap.add_argument("--fc-impl", choices=("mfma", "library"), default="mfma",
+                    help="FC layers of ExtractorAttn: this library's MFMA kernels (default) or round 1's vendor GEMM/conv path")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
+                    help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
+                         "f16 terms per operand with f32 accumulation (labelled experiments)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -326,7 +333,8 @@ def main():
         gfla.seed_conv_db(os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_miopen_db_rank%d" % rank))
     gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
         os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop_rank%d.csv" % rank))
-    hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad)
+    hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
+                 fc_mode=args.fc_mode)
     resample = gfla.Resample2d(4, 1, 2)
 
     def barrier():
