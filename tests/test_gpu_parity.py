@@ -585,6 +585,28 @@ def test_golden_vectors(gfla):
     assert_close(out.cpu(), torch.from_numpy(z["rs_out"]), 4e-6, "golden resample2d")
 
 
+def test_golden_vectors_backward(gfla):
+    """The HIP backward kernels against the gradients the REAL reference kernels produced for the golden inputs
+    (be_gsrc / be_gflow, lar_gin, rs_gin1 / rs_gin2 in tests/golden/ref_golden.npz)."""
+    path = os.path.join(GOLDEN, "ref_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ref_golden.npz not generated yet")
+    z = np.load(path)
+    t = lambda name: torch.from_numpy(z[name]).to(DEV)
+    for k in (3, 5):
+        s, f = t("be_source").requires_grad_(), t("be_flow").requires_grad_()
+        gfla.BlockExtractorFunction.apply(s, f, k).backward(t("be_gout_k%d" % k))
+        assert_close(s.grad.cpu(), torch.from_numpy(z["be_gsrc_k%d" % k]), F32_GRAD, "golden grad_source k=%d" % k)
+        assert_close(f.grad.cpu(), torch.from_numpy(z["be_gflow_k%d" % k]), F32_GRAD, "golden grad_flow k=%d" % k)
+    x = t("lar_in").requires_grad_()
+    gfla.LocalAttnReshapeFunction.apply(x, 3).backward(t("lar_gout"))
+    assert torch.equal(x.grad.cpu(), torch.from_numpy(z["lar_gin"]))
+    i1, i2 = t("rs_in1").requires_grad_(), t("rs_in2").requires_grad_()
+    gfla.Resample2dFunction.apply(i1, i2, 4, 1).backward(t("rs_gout"))
+    assert_close(i1.grad.cpu(), torch.from_numpy(z["rs_gin1"]), F32_GRAD, "golden resample2d grad input1 (int() quirk)")
+    assert_close(i2.grad.cpu(), torch.from_numpy(z["rs_gin2"]), 1e-4, "golden resample2d grad input2")
+
+
 # ------------------------------------------------------------------------- replicate-pad gradient
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("shape,pad", [((2, 3, 7, 5), (2, 2, 2, 2)), ((1, 4, 6, 9), (1, 2, 1, 2)),
