@@ -2,7 +2,8 @@
 #include "gfla_common.h"
 
 namespace gfla {
-static int g_tuning[16] = {0};
+// per thread: a host thread that drives its own device (DataParallel-style workers, tests) tunes only its own launches
+static thread_local int g_tuning[16] = {0};
 int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
 }  // namespace gfla
 

@@ -18,7 +18,7 @@ struct FcLayout {
   // forward workspace, kept for backward
   int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
-  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, bwd_total;
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, bwd_total;
 };
 
 static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode) {
@@ -66,6 +66,10 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode) {
   L.dw1_tiles = t;
   L.dw1p = take(B * t * (32 * kFcHidden + 32) * 4);
   L.red = take((32 * kFcHidden + 32 + kFcHidden) * 4);
+  L.red_tmp = take((int64_t)kFcRedTmpFloats * 4);
+  // exact-f32 weight gradient: per-split partial sums (the two halves run one after the other and share it)
+  const int64_t sp_s = fc_wgrad_splits(B, L.hs.M, L.cpad), sp_t = fc_wgrad_splits(B, L.ht.M, L.cpad);
+  L.dwp = take(mode == 0 ? (sp_s > sp_t ? sp_s : sp_t) * L.KK * L.cpad * kFcHidden * 4 : 0);
   L.bwd_total = o;
   return L;
 }
@@ -74,11 +78,11 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
   if (B < 0 || C <= 0 || H <= 0 || W <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
   if (!fc_mode_ok(mode) || (k != 3 && k != 5)) return GFLA_ERR_UNSUPPORTED;
   if (B > 65535 || C > 4096 || H > 2048 || W > 2048) return GFLA_ERR_UNSUPPORTED;
-  // the input tile of the convolution (128 outputs + the tap halo) has to fit the LDS of a CU
-  const int wp = (int)W + 2 * (k - 1);
-  const int tmh = kFcTM + (k - 1) * (wp + 1);
-  const int ns = fc_nsplit(mode), pitch = mode ? 48 : 80;
-  if ((int64_t)(ns * tmh + 2 * ns * kFcTN) * pitch > 150 * 1024) return GFLA_ERR_UNSUPPORTED;
+  // the smallest input tile of each convolution (64 outputs + the tap halo) has to fit the LDS of a CU
+  const FcHalf hs = fc_half((int)H, (int)W, k, true), ht = fc_half((int)H, (int)W, k, false);
+  if (!fc_conv_fits(hs.Wo, hs.Wp, k, mode) || !fc_conv_fits(hs.Wp, hs.Wp, k, mode) ||
+      !fc_conv_fits(ht.Wo, ht.Wp, k, mode) || !fc_conv_fits(ht.Wp, ht.Wp, k, mode))
+    return GFLA_ERR_UNSUPPORTED;
   if ((int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
   return GFLA_OK;
 }
@@ -113,19 +117,20 @@ static int fc_forward(const float *source, const float *target, const float *flo
   const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
-  GFLA_TRY(fc_conv(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.M,
-                   L.hs.Wp, k, mode, a_src, a_w, stream));
-  GFLA_TRY(fc_conv(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.M,
-                   L.ht.Wp, k, mode, a_tgt, a_w, stream));
+  GFLA_TRY(fc_conv(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.Mv,
+                   L.hs.Wo, L.hs.Wp, k, mode, a_src, a_w, stream));
+  GFLA_TRY(fc_conv(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.Mv,
+                   L.ht.Wo, L.ht.Wp, k, mode, a_tgt, a_w, stream));
   return fc_sample_tail_fwd(gs, gt, flow, b0, w1, b1, reinterpret_cast<float *>(ws + L.hid), logits, B, H, W, k,
-                            L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wp, L.ht.Wp, slope, stream);
+                            L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wo, L.ht.Wo, slope, stream);
 }
 
 // data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
 // Z-layout gradient map
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
-                            float *g_x, bool want_w, int64_t B, int C, int H, int W, int k, int mode,
+                            float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode,
                             hipStream_t stream) {
+  const bool want_w = g_w0 != nullptr;
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const int nch_h = kFcHidden / kFcChunk;
   float *dz = reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt));
@@ -146,13 +151,19 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
     float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
     const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
     GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
-                     k, mode, a_z, a_w, stream));
+                     g.Wp, k, mode, a_z, a_w, stream));
     GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, 0, stream));
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
-    GFLA_TRY(fc_wgrad(X, Z, g.lead, reinterpret_cast<float *>(sc + (source ? L.dw_s : L.dw_t)), L.cpad, B, g.M, g.Wp,
-                      k, mode, stream));
+    if (mode == 0) {
+      float *part = reinterpret_cast<float *>(sc + L.dwp);
+      GFLA_TRY(fc_wgrad_f32(X, Z, g.lead, part, L.cpad, B, g.M, g.Wp, k, stream));
+      GFLA_TRY(fc_wgrad_reduce(part, fc_wgrad_splits(B, g.M, L.cpad), g_w0, C, source ? C : 0, L.cpad, k, stream));
+    } else {
+      GFLA_TRY(fc_wgrad(X, Z, g.lead, reinterpret_cast<float *>(sc + (source ? L.dw_s : L.dw_t)), L.cpad, B, g.M, g.Wp,
+                        k, mode, stream));
+    }
   }
   return GFLA_OK;
 }
@@ -177,22 +188,23 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   float *b0p = g_b0 ? reinterpret_cast<float *>(sc + L.b0p) : nullptr;
   const int64_t tiles = ceil_div((int64_t)H * W, 64);
   GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
-                              L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
+                              L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
                               stream));
   float *red = reinterpret_cast<float *>(sc + L.red);
-  if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, stream));
+  float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
+  if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, red_tmp, stream));
   if (g_w1 || g_b1) {
     float *part = reinterpret_cast<float *>(sc + L.dw1p);
     GFLA_TRY(fc_dw1(hid, g_logits, part, B, H * W, L.KK, L.dw1_tiles, slope, stream));
-    GFLA_TRY(fc_reduce_rows(part, red, B * L.dw1_tiles, 32 * kFcHidden + 32, 1.f, stream));
+    GFLA_TRY(fc_reduce_rows(part, red, B * L.dw1_tiles, 32 * kFcHidden + 32, 1.f, red_tmp, stream));
     if (g_w1 && hipMemcpyAsync(g_w1, red, (size_t)L.KK * kFcHidden * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return GFLA_ERR_LAUNCH;
     if (g_b1 && hipMemcpyAsync(g_b1, red + 32 * kFcHidden, (size_t)L.KK * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return GFLA_ERR_LAUNCH;
   }
-  if (need_s) GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0 != nullptr, B, C, H, W, k, mode, stream));
-  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0 != nullptr, B, C, H, W, k, mode, stream));
-  if (g_w0) {
+  if (need_s) GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode, stream));
+  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode, stream));
+  if (g_w0 && mode != 0) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
                              a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,
@@ -245,7 +257,7 @@ int gfla_fc_geometry(int64_t H, int64_t W, int kernel_size, int is_source, int64
   return GFLA_OK;
 }
 
-/* convolved map of one half: out (B, Mg, 128) f32, row m = yo*Wp + xo (gfla_fc_geometry) */
+/* convolved map of one half: out (B, Mg, 128) f32, row m = yo*Wo + xo (gfla_fc_geometry) */
 int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *workspace, float *out, int64_t B,
                          int64_t C_, int64_t H_, int64_t W_, int kernel_size, int mode, gfla_stream_t stream_) {
   if (!x || !w0 || !workspace || !out) return GFLA_ERR_NULL_POINTER;
@@ -269,7 +281,7 @@ int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *w
   const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
   const PackedDesc X = fc_desc_packed(xp, B, L.nch_c, g.Sx, mode);
   return fc_conv(X, ws + (is_source ? L.wf_s : L.wf_t), wsplit_f, out, g.Mg * kFcHidden, kFcHidden, kFcHidden, B,
-                 L.nch_c, g.M, g.Wp, k, mode, a_x, a_w, stream);
+                 L.nch_c, g.Mv, g.Wo, g.Wp, k, mode, a_x, a_w, stream);
 }
 
 /* gradients of one half from its Z-layout gradient map z (B, Sz, 128) f32 (zero outside the data, see
@@ -292,8 +304,11 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
   if (hipMemcpyAsync(sc + (is_source ? L.dzs : L.dzt), z, (size_t)(B * g.Sz * kFcHidden * 4), hipMemcpyDeviceToDevice,
                      stream) != hipSuccess)
     return GFLA_ERR_LAUNCH;
-  GFLA_TRY(fc_half_backward(L, g, is_source != 0, ws, sc, grad_x, grad_w0 != nullptr, B, C, H, W, k, mode, stream));
-  if (grad_w0) {
+  if (grad_w0 && mode == 0 &&  // the other half of conv0.weight.grad is zero by contract
+      hipMemsetAsync(grad_w0, 0, (size_t)kFcHidden * 2 * C * k * k * 4, stream) != hipSuccess)
+    return GFLA_ERR_LAUNCH;
+  GFLA_TRY(fc_half_backward(L, g, is_source != 0, ws, sc, grad_x, grad_w0, B, C, H, W, k, mode, stream));
+  if (grad_w0 && mode != 0) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
                              a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,

@@ -1,0 +1,233 @@
+// The stride-1 k x k convolutions of the FC layer as implicit GEMMs on the matrix cores, gfx950 (see fc_gemm.hip for
+// the formulation).  Included by fc_conv_m{0,2,3}.hip, one translation unit per arithmetic mode.
+//
+// out[b][r][n] = inv_scale * sum_{chunk, tap=(i,j), c} X[b][chunk][pix(r) + i*Wp + j][c] * Wk[ntile][chunk][tap][n][c]
+// with pix(r) = (r / Wv) * Wp + r % Wv: the output rows are the VALID positions only (Wv = valid width of a row of
+// the linearised map); Wv = Wp makes pix the identity -- the data-gradient convolution, where every position of the
+// padded domain is an output.  A lane owns one row of each 32-row MFMA block, so the row -> pixel map is one
+// per-lane LDS offset per block: the k-1 wrap-around columns of the linearised map cost no MFMA work.
+//
+// grid (row tiles, B, channel tiles); 256 threads = 4 waves.  Wave w owns output channels 32w..32w+31 of the
+// 128-channel tile and ALL 32*NMB rows of the row tile (NMB = 2..8 row blocks, a template parameter chosen per launch
+// so that the last round of workgroups is full, see pick_row_blocks):
+//   * A operand: the input pixels of the row tile (+ tap halo) of one 16-channel chunk, staged once per chunk in LDS
+//     and reused by all k*k taps and all four waves; fragments are read one row block ahead of the MFMAs that use
+//     them (an f32 MFMA occupies the pipe for 64 cycles, the LDS answers in about as many);
+//   * B operand: the wave's 32 x 16 slice of the (chunk, tap) weight tile goes global -> registers directly in MFMA
+//     fragment layout (a wave reads 1-2 KB contiguous), prefetched one tap ahead: no LDS, no barrier per tap.
+#pragma once
+
+#include "fc_mma.h"
+
+namespace gfla {
+
+template <int MODE>
+__device__ __forceinline__ void load_b_frags(Frag<MODE> (&fb)[Fc<MODE>::KB], const unsigned char *p, int64_t split_stride) {
+  if constexpr (MODE == 0) {
+    fb[0].v = *reinterpret_cast<const float4 *>(p);
+    fb[1].v = *reinterpret_cast<const float4 *>(p + 32);
+  } else {
+#pragma unroll
+    for (int sp = 0; sp < Fc<MODE>::NS; ++sp) fb[0].s[sp] = *reinterpret_cast<const f16x8 *>(p + sp * split_stride);
+  }
+}
+
+template <int MODE, int KS, int NMB>
+__global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const unsigned char *__restrict__ Wk,
+                                                        int64_t w_split_stride, float *__restrict__ out,
+                                                        int64_t out_bs, int ldo, int n_valid, int M, int Wv, int Wp,
+                                                        int nch, int tmh, const uint32_t *__restrict__ amax_x,
+                                                        const uint32_t *__restrict__ amax_w) {
+  using F = Fc<MODE>;
+  constexpr int KK = KS * KS, PITCH = F::PITCH, STEPS = F::KB * NMB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  unsigned char *xs = gfla_smem;  // [NS][tmh][PITCH]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.x * 32 * NMB;
+  const int64_t b = blockIdx.y;
+  const int ntile = blockIdx.z;
+  const int y0 = m0 / Wv, p0 = y0 * Wp + (m0 - y0 * Wv);  // first input pixel of the row tile
+  const int64_t x_ss = X.split_stride, x_cs = X.chunk_stride;
+  const int x_ps = X.pix_stride;
+  const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)p0 * x_ps;
+  constexpr int64_t kWTile = (int64_t)kFcTN * F::REC;  // bytes of one (chunk, tap) weight tile of one term
+  // this lane's slice of a weight tile: row n = 32*wave + l31, K half kh
+  const unsigned char *wg = Wk + (int64_t)ntile * nch * KK * kWTile + (wave * 32 + l31) * F::REC + kh * 16;
+
+  int a_off[NMB];  // LDS byte offset of this lane's row in each 32-row block
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) {
+    const int r = min(m0 + mb * 32 + l31, M - 1);
+    const int y = r / Wv;
+    a_off[mb] = (y * Wp + (r - y * Wv) - p0) * PITCH;
+  }
+
+  f32x16 acc[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  const int per = tmh * F::PIECES;  // 16-byte pieces of one term of the input tile
+  const int x_total = per * F::NS;
+  const int xplane = tmh * PITCH;
+
+  Frag<MODE> cur[F::KB], nxt[F::KB];
+  load_b_frags<MODE>(cur, wg, w_split_stride);
+  for (int cc = 0; cc < nch; ++cc) {
+    __syncthreads();  // every wave is done with the previous chunk's tile
+    {  // input tile of this chunk: x_total 16-byte pieces, 4 loads in flight per thread
+      const unsigned char *src = xg + (int64_t)cc * x_cs;
+      for (int base = t; base < x_total; base += 256 * 4) {
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+#define GFLA_X_SP(idx_) (((idx_) >= per) + ((idx_) >= 2 * per))
+#define GFLA_X_REM(idx_) ((idx_)-GFLA_X_SP(idx_) * per)
+#define GFLA_X_SRC(idx_) \
+  (src + GFLA_X_SP(idx_) * x_ss + (int64_t)(GFLA_X_REM(idx_) / F::PIECES) * x_ps + (GFLA_X_REM(idx_) % F::PIECES) * 16)
+#define GFLA_X_DST(idx_) \
+  (xs + ((size_t)GFLA_X_SP(idx_) * tmh + GFLA_X_REM(idx_) / F::PIECES) * PITCH + (GFLA_X_REM(idx_) % F::PIECES) * 16)
+        if (base < x_total) v0 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base));
+        if (base + 256 < x_total) v1 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 256));
+        if (base + 512 < x_total) v2 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 512));
+        if (base + 768 < x_total) v3 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 768));
+        if (base < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base)) = v0;
+        if (base + 256 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 256)) = v1;
+        if (base + 512 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 512)) = v2;
+        if (base + 768 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 768)) = v3;
+#undef GFLA_X_SRC
+#undef GFLA_X_DST
+#undef GFLA_X_SP
+#undef GFLA_X_REM
+      }
+    }
+    __syncthreads();
+    Frag<MODE> fa = load_frag<MODE>(xs + a_off[0], xplane, 0, kh);  // first fragment of tap 0
+#pragma unroll 1
+    for (int tap = 0; tap < KK; ++tap) {
+      {  // next (chunk, tap) weight slice: in flight during this tap's MFMAs
+        const int lin = cc * KK + tap + 1;
+#pragma unroll
+        for (int q = 0; q < F::KB; ++q) nxt[q] = cur[q];
+        if (lin < nch * KK) load_b_frags<MODE>(nxt, wg + (int64_t)lin * kWTile, w_split_stride);
+      }
+      const int i = tap / KS, j = tap - i * KS;
+      const unsigned char *xa = xs + (size_t)(i * Wp + j) * PITCH;
+      const int tn = tap + 1 < KK ? tap + 1 : 0;  // after the last tap: a harmless re-read, the next chunk starts over
+      const int in = tn / KS, jn = tn - in * KS;
+      const unsigned char *xa_next = xs + (size_t)(in * Wp + jn) * PITCH;
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int kb = st / NMB, mb = st % NMB;
+        const Frag<MODE> fc = fa;
+        if (st + 1 < STEPS)
+          fa = load_frag<MODE>(xa + a_off[(st + 1) % NMB], xplane, (st + 1) / NMB, kh);
+        else
+          fa = load_frag<MODE>(xa_next + a_off[0], xplane, 0, kh);
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS read ahead of the MFMAs it overlaps with
+        acc[mb] = mma<MODE>(fc, cur[kb], acc[mb]);
+      }
+#pragma unroll
+      for (int q = 0; q < F::KB; ++q) cur[q] = nxt[q];
+    }
+  }
+
+  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const float inv = MODE == 0 ? 1.f : fc_inv_scale(amax_x) * fc_inv_scale(amax_w);
+  float *ob = out + b * out_bs;
+  const int col = ntile * kFcTN + wave * 32 + l31;
+  if (col < n_valid) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < M) ob[(int64_t)m * ldo + col] = acc[mb][r] * inv;
+      }
+    }
+  }
+}
+
+constexpr int kFcMinRowBlocks = 2, kFcMaxRowBlocks = 8;
+
+// pixels of the LDS input tile for 32*mb output rows: the rows' own span + the tap halo
+inline int fc_conv_tile_pixels(int mb, int Wv, int Wp, int k) {
+  const int tm = 32 * mb;
+  return tm + ((tm - 1) / Wv + 1) * (Wp - Wv) + (k - 1) * (Wp + 1);
+}
+
+// Row blocks per workgroup: all row tiles cost the same, so the launch takes ceil(tiles / slots) rounds of
+// (mb + staging) block-times; take the mb that minimises that (ties: the larger tile re-reads the weights less).
+inline int pick_row_blocks(int M, int64_t B, int ntiles_n, int Wv, int Wp, int k, int mode) {
+  const int ns = fc_nsplit(mode), pitch = mode ? 48 : 80;
+  int best = 0;
+  double best_cost = 1e300;
+  const int forced = tuning(11);
+  for (int mb = kFcMinRowBlocks; mb <= kFcMaxRowBlocks; ++mb) {
+    if (forced >= kFcMinRowBlocks && forced <= kFcMaxRowBlocks && mb != forced) continue;
+    const int64_t lds = (int64_t)ns * fc_conv_tile_pixels(mb, Wv, Wp, k) * pitch;
+    if (lds > 156 * 1024) continue;
+    const int w = lds * 2 <= 160 * 1024 ? 2 : 1;
+    const int64_t tiles = ceil_div(M, 32 * mb) * B * ntiles_n;
+    const int64_t rounds = ceil_div(tiles, (int64_t)kNumCU * w);
+    const double cost = (double)rounds * (mb + 0.35) * (w == 1 ? 1.12 : 1.0);
+    if (cost <= best_cost) best_cost = cost, best = mb;
+  }
+  return best;
+}
+
+template <int MODE, int KS, int NMB>
+static int launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,
+                       int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const uint32_t *amax_x,
+                       const uint32_t *amax_w, hipStream_t stream) {
+  using F = Fc<MODE>;
+  const int tmh = fc_conv_tile_pixels(NMB, Wv, Wp, KS);
+  const unsigned lds = (unsigned)(F::NS * tmh * F::PITCH);
+  const dim3 grid((unsigned)ceil_div(M, 32 * NMB), (unsigned)B, (unsigned)ceil_div(n_valid, kFcTN));
+  auto kern = fc_conv_kernel<MODE, KS, NMB>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs, ldo,
+                                   n_valid, M, Wv, Wp, nch, tmh, amax_x, amax_w);
+  return launch_status();
+}
+
+template <int MODE, int KS>
+static int dispatch_conv(int nmb, const PackedDesc &X, const void *wk, int64_t wss, float *out, int64_t out_bs, int ldo,
+                         int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const uint32_t *ax, const uint32_t *aw,
+                         hipStream_t s) {
+  switch (nmb) {
+#define GFLA_CASE(N_) \
+  case N_: return launch_conv<MODE, KS, N_>(X, wk, wss, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, ax, aw, s)
+    GFLA_CASE(2);
+    GFLA_CASE(3);
+    GFLA_CASE(4);
+    GFLA_CASE(5);
+    GFLA_CASE(6);
+    GFLA_CASE(7);
+    GFLA_CASE(8);
+#undef GFLA_CASE
+  }
+  return GFLA_ERR_UNSUPPORTED;
+}
+
+// one arithmetic mode, both kernel sizes (defined in fc_conv_m<MODE>.hip)
+template <int MODE>
+int fc_conv_mode(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
+                 int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k, const uint32_t *amax_x,
+                 const uint32_t *amax_w, hipStream_t stream);
+
+#define GFLA_DEFINE_FC_CONV_MODE(MODE_)                                                                               \
+  template <>                                                                                                         \
+  int fc_conv_mode<MODE_>(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,    \
+                          int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k,                     \
+                          const uint32_t *amax_x, const uint32_t *amax_w, hipStream_t stream) {                       \
+    const int nmb = pick_row_blocks(M, B, (int)ceil_div(n_valid, kFcTN), Wv, Wp, k, MODE_);                            \
+    if (nmb == 0) return GFLA_ERR_UNSUPPORTED;                                                                        \
+    if (k == 3)                                                                                                       \
+      return dispatch_conv<MODE_, 3>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, amax_x, \
+                                     amax_w, stream);                                                                 \
+    return dispatch_conv<MODE_, 5>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, amax_x,   \
+                                   amax_w, stream);                                                                   \
+  }
+
+}  // namespace gfla

@@ -1,0 +1,6 @@
+// fc_conv_kernel<0, *, *>: the FC-layer convolutions in arithmetic mode 0 (fc_gemm.h), see fc_conv_impl.h.
+#include "fc_conv_impl.h"
+
+namespace gfla {
+GFLA_DEFINE_FC_CONV_MODE(0)
+}  // namespace gfla

@@ -12,7 +12,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kFcChunk = 16;   // channels per K chunk (one 16-channel record per pixel)
-constexpr int kFcTM = 128;     // output pixels per workgroup of the convolution kernel
 constexpr int kFcTN = 128;     // output channels per workgroup
 constexpr int kFcHidden = 128; // hidden_nc of ExtractorAttn (base_function.py:794)
 
@@ -70,16 +69,17 @@ __device__ __forceinline__ float fc_inv_scale(const uint32_t *amax) {
 
 // ---- geometry of one half (source or target) of the layer, shared by host code ------------------
 struct FcHalf {
-  int Hp, Wp;      // replicate-padded input (Wp = the row pitch of every linearised buffer of this half)
-  int Ho, Wo;      // convolution output domain
+  int Hp, Wp;      // replicate-padded input (Wp = the row pitch of the linearised input and gradient maps of this half)
+  int Ho, Wo;      // convolution output domain; the convolved map is stored compactly, row pitch Wo
   int pad_t, pad_l, pad_b, pad_r;
-  int M;           // Ho * Wp outputs per sample (columns >= Wo of a row are don't-care)
+  int M;           // Ho * Wp: the output positions in the input's linearisation (weight-gradient reduction range)
+  int Mv;          // Ho * Wo valid outputs per sample = rows of the convolved map
   int Md;          // Hp * Wp = outputs per sample of the data-gradient convolution
   int lead;        // (k-1)*(Wp+1): zero pixels ahead of the gradient map ("Z layout")
   int64_t Sx;      // pixels per sample of the packed input (with read slack)
   int64_t Sz;      // pixels per sample of the Z-layout gradient map
-  int64_t Mg;      // rows per sample of the f32 convolution output (tile multiple)
-  int64_t Mdg;     // rows per sample of the f32 data-gradient output
+  int64_t Mg;      // rows per sample allocated for the f32 convolved map
+  int64_t Mdg;     // rows per sample allocated for the f32 data-gradient output
 };
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -98,13 +98,16 @@ inline FcHalf fc_half(int H, int W, int k, bool source) {
   g.Ho = g.Hp - k + 1;
   g.Wo = g.Wp - k + 1;
   g.M = g.Ho * g.Wp;
+  g.Mv = g.Ho * g.Wo;
   g.Md = g.Hp * g.Wp;
   g.lead = (k - 1) * (g.Wp + 1);
-  g.Mg = round_up(g.M, kFcTM);
-  g.Mdg = round_up(g.Md, kFcTM);
-  g.Sx = round_up(g.Mg + 64 + g.lead + 16, 16);
+  g.Mg = round_up(g.Mv, 16);
+  g.Mdg = round_up(g.Md, 16);
+  // a row tile of the convolution reads [pix(m0), pix(m0) + span + halo) with pix(Mv-1) + halo + 1 = Hp*Wp and
+  // span <= 256 + (255 / Wo + 1) * (k-1) for the largest tile (fc_gemm.hip: fc_conv_tile_pixels)
+  g.Sx = round_up((int64_t)g.Md + 256 + (255 / g.Wo + 1) * (k - 1) + 16, 16);
   const int64_t need_w = g.lead + round_up(g.M, 64) + 64;  // weight-gradient kernel: K range in 64-pixel steps
-  const int64_t need_d = g.Mdg + g.lead;                   // data-gradient convolution reads Z[m + tap]
+  const int64_t need_d = (int64_t)g.Md + 256 + g.lead;     // data-gradient convolution reads Z[m + tap], 256-row tiles
   g.Sz = round_up((need_w > need_d ? need_w : need_d) + 16, 16);
   return g;
 }
@@ -118,10 +121,16 @@ int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_
 int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
                     int k, int mode, hipStream_t stream);
 int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
-            int n_valid, int64_t B, int nch, int M, int Wp, int k, int mode, const uint32_t *amax_x,
+            int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k, int mode, const uint32_t *amax_x,
             const uint32_t *amax_w, hipStream_t stream);
+bool fc_conv_fits(int Wv, int Wp, int k, int mode);
 int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dwacc, int cpad, int64_t B, int Mk,
              int Wp, int k, int mode, hipStream_t stream);
+int fc_wgrad_splits(int64_t B, int Mk, int cpad);
+int fc_wgrad_f32(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *part, int cpad, int64_t B, int Mk,
+                 int Wp, int k, hipStream_t stream);
+int fc_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
+                    hipStream_t stream);
 int fc_unpack_wgrad(const float *dw_t, const float *dw_s, const uint32_t *amax_xt, const uint32_t *amax_xs,
                     const uint32_t *amax_zt, const uint32_t *amax_zs, float *grad_w0, int C, int cpad, int k,
                     hipStream_t stream);
@@ -137,12 +146,14 @@ int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, cons
                        int64_t gt_bs, int wps, int wpt, float slope, hipStream_t stream);
 int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
                        float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
-                       int64_t gs_bs, int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
+                       int64_t gs_bs, int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
                        float slope, hipStream_t stream);
 int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, int HW, int KK, int tiles_per_sample,
            float slope, hipStream_t stream);
 int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
             int accumulate, hipStream_t stream);
-int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, hipStream_t stream);
+constexpr int kFcRedTmpFloats = 32 * (32 * kFcHidden + 32);  // scratch of fc_reduce_rows' first pass (32 splits x widest row)
+int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, float *tmp,
+                   hipStream_t stream);
 
 }  // namespace gfla

@@ -29,7 +29,7 @@
 //   * the weight gradient reduces over pixels, which are the STRIDED dimension of the pixel-major records:
 //     ds_read_b64_tr_b16 (transposing LDS read) delivers 4 consecutive pixels of one channel per lane.
 // Arithmetic modes (fc_gemm.h): exact f32 MFMA, or f16-split operands with f32 accumulation.
-#include "fc_gemm.h"
+#include "fc_mma.h"
 
 namespace gfla {
 
@@ -269,245 +269,6 @@ int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_
   return launch_status();
 }
 
-// ------------------------------------------------------------------------------------------ MFMA fragments
-// One fragment = the K-slice of a 32-row operand block a lane feeds to the matrix core:
-//   mode 0: 4 consecutive channels (one 16-byte LDS slot); lanes 0-31 take slot 2*kb, lanes 32-63 slot 2*kb+1, and
-//           the four v_mfma_f32_32x32x2_f32 of a fragment pair element e of both halves (a permutation of the 8
-//           channels of the K block, the same for A and B);
-//   mode 2/3: 8 consecutive channels of each f16 term: lanes 0-31 channels 0-7, lanes 32-63 channels 8-15 -- the
-//           A/B layout of v_mfma_f32_32x32x16_f16.
-template <int MODE>
-struct Frag;
-template <>
-struct Frag<0> {
-  float4 v;
-};
-template <>
-struct Frag<2> {
-  f16x8 s[2];
-};
-template <>
-struct Frag<3> {
-  f16x8 s[3];
-};
-
-template <int MODE>
-__device__ __forceinline__ Frag<MODE> load_frag(const unsigned char *rec, int plane_stride, int kb, int kh) {
-  Frag<MODE> f;
-  if constexpr (MODE == 0) {
-    f.v = *reinterpret_cast<const float4 *>(rec + (2 * kb + kh) * 16);
-  } else {
-#pragma unroll
-    for (int sp = 0; sp < Fc<MODE>::NS; ++sp)
-      f.s[sp] = *reinterpret_cast<const f16x8 *>(rec + sp * plane_stride + kh * 16);
-  }
-  return f;
-}
-
-template <int MODE>
-__device__ __forceinline__ f32x16 mma(const Frag<MODE> &a, const Frag<MODE> &b, f32x16 acc) {
-  if constexpr (MODE == 0) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.x, b.v.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.y, b.v.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.z, b.v.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.w, b.v.w, acc, 0, 0, 0);
-  } else if constexpr (MODE == 2) {  // small terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[0], acc, 0, 0, 0);
-  } else {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[2], b.s[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[0], acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-// ---------------------------------------------------------------------- convolution as an implicit GEMM
-// out[b][m][n] = inv_scale * sum_{chunk, tap=(i,j), c} X[b][chunk][m + i*Wp + j][c] * Wk[ntile][chunk][tap][n][c]
-// grid (ceil(M / 128), B, ntiles); 256 threads = 4 waves as 2 (pixels) x 2 (channels), 64 x 64 outputs each.
-template <int MODE, int KS>
-__global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const unsigned char *__restrict__ Wk,
-                                                        int64_t w_split_stride, float *__restrict__ out,
-                                                        int64_t out_bs, int ldo, int n_valid, int M, int Wp, int nch,
-                                                        int tmh, const uint32_t *__restrict__ amax_x,
-                                                        const uint32_t *__restrict__ amax_w) {
-  using F = Fc<MODE>;
-  constexpr int KK = KS * KS;
-  constexpr int NBUF = MODE == 3 ? 1 : 2;  // three f16 terms: one weight buffer, so two workgroups fit a CU
-  constexpr int PITCH = F::PITCH;
-  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  unsigned char *xs = gfla_smem;                                   // [NS][tmh][PITCH]
-  unsigned char *ws = gfla_smem + (size_t)F::NS * tmh * PITCH;     // [NBUF][NS][128][PITCH]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * kFcTM;
-  const int64_t b = blockIdx.y;
-  const int ntile = blockIdx.z;
-  const int64_t x_ss = X.split_stride, x_cs = X.chunk_stride;
-  const int x_ps = X.pix_stride;
-  const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)m0 * x_ps;
-  constexpr int64_t kWTile = (int64_t)kFcTN * F::REC;  // bytes of one (chunk, tap) weight tile of one term
-  const unsigned char *wg = Wk + (int64_t)ntile * nch * KK * kWTile;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-  // weight tile staging: every thread moves WPT 16-byte pieces global -> registers -> LDS
-  constexpr int WPIECES = F::NS * kFcTN * F::PIECES;
-  constexpr int WPT = WPIECES / 256;
-  static_assert(WPT == 2 || WPT == 3, "weight tile pieces per thread");
-  int w_src[WPT], w_dst[WPT];  // per-thread byte offsets inside a tile (global) / a buffer (LDS)
-#pragma unroll
-  for (int q = 0; q < WPT; ++q) {
-    const int idx = t + 256 * q;
-    const int sp = idx / (kFcTN * F::PIECES), rem = idx % (kFcTN * F::PIECES);
-    w_src[q] = rem * 16;
-    w_dst[q] = (sp * kFcTN + rem / F::PIECES) * PITCH + (rem % F::PIECES) * 16;
-    (void)sp;
-  }
-  const int w_sp0 = t / (kFcTN * F::PIECES), w_sp1 = (t + 256) / (kFcTN * F::PIECES),
-            w_sp2 = (t + 512) / (kFcTN * F::PIECES);
-  uint4 wr0, wr1, wr2 = make_uint4(0, 0, 0, 0);
-#define GFLA_W_FETCH(cc_, tap_)                                                                       \
-  {                                                                                                   \
-    const unsigned char *src_ = wg + ((int64_t)(cc_) * KK + (tap_)) * kWTile;                           \
-    wr0 = *reinterpret_cast<const uint4 *>(src_ + w_sp0 * w_split_stride + w_src[0]);                   \
-    wr1 = *reinterpret_cast<const uint4 *>(src_ + w_sp1 * w_split_stride + w_src[1]);                   \
-    if constexpr (WPT == 3) wr2 = *reinterpret_cast<const uint4 *>(src_ + w_sp2 * w_split_stride + w_src[2]); \
-  }
-#define GFLA_W_STORE(buf_)                                                                            \
-  {                                                                                                   \
-    unsigned char *dst_ = ws + (size_t)(buf_) * F::NS * kFcTN * PITCH;                                 \
-    *reinterpret_cast<uint4 *>(dst_ + w_dst[0]) = wr0;                                                 \
-    *reinterpret_cast<uint4 *>(dst_ + w_dst[1]) = wr1;                                                 \
-    if constexpr (WPT == 3) *reinterpret_cast<uint4 *>(dst_ + w_dst[2]) = wr2;                         \
-  }
-  const int per = tmh * F::PIECES;  // pieces of one term of the input tile
-  const int x_total = per * F::NS;
-  const unsigned char *xa0 = xs + (size_t)(wm * 64 + l31) * PITCH;
-  const unsigned char *wb0 = ws + (size_t)(wn * 64 + l31) * PITCH;
-  const int xplane = tmh * PITCH, wplane = kFcTN * PITCH;
-
-  for (int cc = 0; cc < nch; ++cc) {
-    __syncthreads();  // every wave is done with the previous chunk's tiles
-    {  // input tile of this chunk: x_total 16-byte pieces, 4 loads in flight per thread
-      const unsigned char *src = xg + (int64_t)cc * x_cs;
-      for (int base = t; base < x_total; base += 256 * 4) {
-        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-#define GFLA_X_SP(idx_) (((idx_) >= per) + ((idx_) >= 2 * per))
-#define GFLA_X_REM(idx_) ((idx_)-GFLA_X_SP(idx_) * per)
-#define GFLA_X_SRC(idx_) \
-  (src + GFLA_X_SP(idx_) * x_ss + (int64_t)(GFLA_X_REM(idx_) / F::PIECES) * x_ps + (GFLA_X_REM(idx_) % F::PIECES) * 16)
-#define GFLA_X_DST(idx_) \
-  (xs + ((size_t)GFLA_X_SP(idx_) * tmh + GFLA_X_REM(idx_) / F::PIECES) * PITCH + (GFLA_X_REM(idx_) % F::PIECES) * 16)
-        if (base < x_total) v0 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base));
-        if (base + 256 < x_total) v1 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 256));
-        if (base + 512 < x_total) v2 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 512));
-        if (base + 768 < x_total) v3 = *reinterpret_cast<const uint4 *>(GFLA_X_SRC(base + 768));
-        if (base < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base)) = v0;
-        if (base + 256 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 256)) = v1;
-        if (base + 512 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 512)) = v2;
-        if (base + 768 < x_total) *reinterpret_cast<uint4 *>(GFLA_X_DST(base + 768)) = v3;
-#undef GFLA_X_SRC
-#undef GFLA_X_DST
-#undef GFLA_X_SP
-#undef GFLA_X_REM
-      }
-    }
-    GFLA_W_FETCH(cc, 0);
-    GFLA_W_STORE(0);
-    __syncthreads();
-#pragma unroll 1
-    for (int tap = 0; tap < KK; ++tap) {
-      const int buf = NBUF == 2 ? (tap & 1) : 0;
-      if (tap + 1 < KK) GFLA_W_FETCH(cc, tap + 1);
-      const int i = tap / KS, j = tap - i * KS;
-      const unsigned char *xa = xa0 + (size_t)(i * Wp + j) * PITCH;
-      const unsigned char *wb = wb0 + (size_t)buf * F::NS * wplane;
-#pragma unroll
-      for (int kb = 0; kb < F::KB; ++kb) {
-        Frag<MODE> fa[2], fb[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) fa[mb] = load_frag<MODE>(xa + mb * 32 * PITCH, xplane, kb, kh);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) fb[nb] = load_frag<MODE>(wb + nb * 32 * PITCH, wplane, kb, kh);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mma<MODE>(fa[mb], fb[nb], acc[mb][nb]);
-      }
-      if (NBUF == 1) __syncthreads();  // everyone has read the single weight buffer
-      if (tap + 1 < KK) GFLA_W_STORE(NBUF == 2 ? (buf ^ 1) : 0);
-      __syncthreads();
-    }
-  }
-#undef GFLA_W_FETCH
-#undef GFLA_W_STORE
-
-  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const float inv = MODE == 0 ? 1.f : fc_inv_scale(amax_x) * fc_inv_scale(amax_w);
-  float *ob = out + b * out_bs;
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int col = ntile * kFcTN + wn * 64 + nb * 32 + l31;
-      if (col >= n_valid) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m < M) ob[(int64_t)m * ldo + col] = acc[mb][nb][r] * inv;
-      }
-    }
-}
-
-template <int MODE, int KS>
-static void launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,
-                        int ldo, int n_valid, int64_t B, int nch, int M, int Wp, const uint32_t *amax_x,
-                        const uint32_t *amax_w, hipStream_t stream) {
-  using F = Fc<MODE>;
-  const int tmh = kFcTM + (KS - 1) * (Wp + 1);
-  const int nbuf = MODE == 3 ? 1 : 2;
-  const unsigned lds = (unsigned)((F::NS * tmh + nbuf * F::NS * kFcTN) * F::PITCH);
-  const dim3 grid((unsigned)ceil_div(M, kFcTM), (unsigned)B, (unsigned)ceil_div(n_valid, kFcTN));
-  auto kern = fc_conv_kernel<MODE, KS>;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<grid, 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs, ldo,
-                                   n_valid, M, Wp, nch, tmh, amax_x, amax_w);
-}
-
-int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
-            int n_valid, int64_t B, int nch, int M, int Wp, int k, int mode, const uint32_t *amax_x,
-            const uint32_t *amax_w, hipStream_t stream) {
-  if (!fc_mode_ok(mode) || (k != 3 && k != 5)) return GFLA_ERR_UNSUPPORTED;
-  const int tmh = kFcTM + (k - 1) * (Wp + 1);
-  if ((int64_t)(fc_nsplit(mode) * tmh + 2 * fc_nsplit(mode) * kFcTN) * 80 > 150 * 1024) return GFLA_ERR_UNSUPPORTED;
-  if (B > 65535 || B <= 0 || M <= 0) return B == 0 ? GFLA_OK : GFLA_ERR_UNSUPPORTED;
-#define GFLA_CONV(M_, K_)                                                                                      \
-  launch_conv<M_, K_>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wp, amax_x, amax_w, stream)
-  if (k == 3) {
-    if (mode == 0) GFLA_CONV(0, 3);
-    else if (mode == 2) GFLA_CONV(2, 3);
-    else GFLA_CONV(3, 3);
-  } else {
-    if (mode == 0) GFLA_CONV(0, 5);
-    else if (mode == 2) GFLA_CONV(2, 5);
-    else GFLA_CONV(3, 5);
-  }
-#undef GFLA_CONV
-  return launch_status();
-}
-
 // -------------------------------------------------------------------------------- weight gradient
 // dwacc[tap][16*chunk + c][n] += sum_{b, m} X[b][chunk][m + i*Wp + j][c] * Y[b][n/16][lead + m][n%16]
 // (scaled by both operands' scales; fc_unpack_wgrad undoes that).  The reduction runs over pixels, the strided
@@ -710,6 +471,170 @@ int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dw
     else GFLA_WG(3, 5, 7);
   }
 #undef GFLA_WG
+  return launch_status();
+}
+
+// ------------------------------------------------------------------- weight gradient, exact f32 (mode 0)
+// part[s][tap][16*chunk + c][n] = sum over the (sample, pixel block)s of split s of X[b][chunk][m + i*Wp + j][c] *
+// Z[b][lead + m][n] on v_mfma_f32_16x16x4_f32 (same FLOP rate as the 32x32x2 form, but 16-row blocks: one 16-channel
+// chunk per block, so ALL k*k taps fit one wave's accumulators and no MFMA row is padding).
+// A workgroup (8 waves) = one chunk x all taps x the 128 hidden channels (wave w: columns 16w..16w+15) x a contiguous
+// range of 32-pixel blocks of the flattened (sample, pixel) space -- the ranges are equal, so one round of workgroups
+// is full whatever the batch.  Per 4-pixel K step a wave issues k*k MFMAs against k*k + 1 four-byte LDS reads, the
+// reads of a tap row running one row ahead of its MFMAs.  Blocks are double-buffered in LDS and arrive by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, the next block lands while this one is multiplied; both the
+// 16-channel X records and the 128-channel Z pixels are contiguous in memory, so the LDS image is linear).  Partial
+// sums leave as plain coalesced stores, fc_wgrad_reduce adds the splits and writes conv0.weight.grad's layout.
+constexpr int kWgKC = 32;  // pixels per staged block
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_dma16(const unsigned char *gsrc, unsigned char *lds_wave_base) {
+  // 64 lanes x 16 bytes: lane l's 16 bytes land at lds_wave_base + 16*l (the LDS address is wave-uniform + lane*16)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void fc_wgrad_f32_kernel(PackedDesc X, PackedDesc Y, int64_t y_lead,
+                                                             float *__restrict__ part, int cpad, int Wp, int nblk,
+                                                             int64_t total_blocks, int nsplit) {
+  constexpr int KK = KS * KS, KC = kWgKC, YB = KC * kFcHidden * 4;  // bytes of one Z block
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  const int xh = KC + (KS - 1) * (Wp + 1);
+  const int nx = (xh * 4 + 63) >> 6;      // wave-instructions (64 x 16 B) of one X block, rounded up (the input has slack)
+  constexpr int ny = YB >> 10;
+  const int xbytes = nx << 10;
+  unsigned char *xs = gfla_smem;                // [2][xbytes]: pixel records of 64 B
+  unsigned char *ys = gfla_smem + 2 * xbytes;   // [2][KC][512 B]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cc = blockIdx.x, sp = blockIdx.y;
+  const int64_t blk0 = total_blocks * sp / nsplit, blk1 = total_blocks * (sp + 1) / nsplit;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int xa = kq * 64 + l15 * 4;
+  const int yb = kq * 512 + (wave * 16 + l15) * 4;
+  const int row_pitch = Wp * 64;
+
+  f32x4 acc[KK];
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[tap][r] = 0.f;
+
+  auto issue = [&](int64_t blk, int buf) {
+    const int64_t b = blk / nblk;
+    const int m = (int)(blk - b * nblk) * KC;
+    const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)cc * X.chunk_stride + (int64_t)m * 64 + lane * 16;
+    const unsigned char *yg = Y.base + b * Y.batch_stride + (y_lead + m) * 512 + lane * 16;
+    for (int w = wave; w < nx + ny; w += 8) {
+      if (w < nx)
+        lds_dma16(xg + ((int64_t)w << 10), xs + buf * xbytes + (w << 10));
+      else
+        lds_dma16(yg + ((int64_t)(w - nx) << 10), ys + buf * YB + ((w - nx) << 10));
+    }
+  };
+
+  if (blk0 < blk1) issue(blk0, 0);
+  int buf = 0;
+  for (int64_t blk = blk0; blk < blk1; ++blk, buf ^= 1) {
+    // the compiler drains this wave's DMA (vmcnt 0) ahead of the barrier: past it the block has landed for every
+    // wave, and every wave is done with the other buffer
+    __syncthreads();
+    if (blk + 1 < blk1) issue(blk + 1, buf ^ 1);
+    const unsigned char *xb = xs + buf * xbytes + xa;
+    const unsigned char *ybp = ys + buf * YB + yb;
+    float an[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const float *>(xb + j * 64);
+    float bn = *reinterpret_cast<const float *>(ybp);
+#pragma unroll 2
+    for (int s4 = 0; s4 < KC / 4; ++s4) {
+      const float bc = bn;
+      bn = *reinterpret_cast<const float *>(ybp + (s4 + 1 < KC / 4 ? s4 + 1 : s4) * 2048);
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        float ac[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) ac[j] = an[j];
+        // next tap row (of this K step, or the first row of the next one; past the last step: a harmless in-bounds read)
+        const unsigned char *nx_row = i + 1 < KS ? xb + s4 * 256 + (i + 1) * row_pitch : xb + (s4 + 1) * 256;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const float *>(nx_row + j * 64);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs they overlap with
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+          acc[i * KS + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j], bc, acc[i * KS + j], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + r
+  float *o = part + (((int64_t)sp * KK) * cpad + cc * kFcChunk) * kFcHidden + wave * 16 + l15;
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[((int64_t)tap * cpad + 4 * kq + r) * kFcHidden] = acc[tap][r];
+}
+
+int fc_wgrad_splits(int64_t B, int Mk, int cpad) {
+  const int nch = cpad / kFcChunk;
+  const int64_t total = B * ceil_div(Mk, kWgKC);
+  int64_t s = tuning(12) > 0 ? tuning(12) : (2 * kNumCU) / nch;
+  if (s < 1) s = 1;
+  return (int)(s > total ? total : s);
+}
+
+// part: fc_wgrad_splits(...) * k*k * cpad * 128 floats.  X: packed f32 records (mode 0), Y: the f32 (B, Sz, 128) map
+int fc_wgrad_f32(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *part, int cpad, int64_t B, int Mk,
+                 int Wp, int k, hipStream_t stream) {
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  if (X.pix_stride != 64 || Y.pix_stride != kFcHidden * 4 || Y.chunk_stride != 64) return GFLA_ERR_UNSUPPORTED;
+  if (B <= 0) return GFLA_OK;
+  const int nblk = (int)ceil_div(Mk, kWgKC);
+  const int nsplit = fc_wgrad_splits(B, Mk, cpad);
+  const int xh = kWgKC + (k - 1) * (Wp + 1);
+  const unsigned lds = (unsigned)(2 * ((((xh * 4 + 63) >> 6) << 10) + kWgKC * kFcHidden * 4));
+  if (lds > 156 * 1024) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)nsplit);
+#define GFLA_WGF(K_)                                                                                                 \
+  {                                                                                                                  \
+    auto kern = fc_wgrad_f32_kernel<K_>;                                                                             \
+    if (lds > 64 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    kern<<<grid, 512, lds, stream>>>(X, Y, y_lead, part, cpad, Wp, nblk, B * nblk, nsplit);                           \
+  }
+  if (k == 3) GFLA_WGF(3) else GFLA_WGF(5)
+#undef GFLA_WGF
+  return launch_status();
+}
+
+// conv0.weight.grad[n][c_off + c][i][j] = sum_s part[s][tap][c][n]  (one half of the 2C input channels)
+__global__ __launch_bounds__(256) void fc_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit,
+                                                             float *__restrict__ gw, int C, int c_off, int cpad,
+                                                             int KK) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (tap, c, n), n fastest: coalesced reads
+  const int64_t per = (int64_t)KK * cpad * kFcHidden;
+  if (idx >= per) return;
+  const int n = (int)(idx & (kFcHidden - 1));
+  const int c = (int)((idx >> 7) % cpad);
+  const int tap = (int)(idx / ((int64_t)cpad * kFcHidden));
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sp = 0;
+  for (; sp + 4 <= nsplit; sp += 4) {
+    s0 += part[(sp + 0) * per + idx];
+    s1 += part[(sp + 1) * per + idx];
+    s2 += part[(sp + 2) * per + idx];
+    s3 += part[(sp + 3) * per + idx];
+  }
+  for (; sp < nsplit; ++sp) s0 += part[sp * per + idx];
+  gw[((int64_t)n * 2 * C + c_off + c) * KK + tap] = (s0 + s1) + (s2 + s3);
+}
+
+int fc_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
+                    hipStream_t stream) {
+  const int64_t per = (int64_t)k * k * cpad * kFcHidden;
+  fc_wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per, 256)), 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad,
+                                                                               k * k);
   return launch_status();
 }
 

@@ -23,12 +23,13 @@ constexpr int kSmpPitch = kFcHidden + 1;  // floats; odd pitch: column reads (la
 
 struct Corner {
   int i00, i01, i10, i11;   // indices into the convolved map (row pitch wps)
+  int z00, z01, z10, z11;   // the same four positions in the Z-layout gradient map (row pitch wpz)
   float xl, xr, yt, yb;     // the reference's xL_P, xR_P, yT_P, yB_P
 };
 
 // block_extractor_kernel.cu:58-70 for the centre tap; the convolved map lives on [-hi, H-1+lo] x [-hi, W-1+lo]
 template <int KS>
-__device__ __forceinline__ Corner corners(float fx, float fy, int x, int y, int H, int W, int wps) {
+__device__ __forceinline__ Corner corners(float fx, float fy, int x, int y, int H, int W, int wps, int wpz = 0) {
   constexpr int LO = KS / 2, HI = KS - 1 - LO;
   const float dx = fx + (float)x, dy = fy + (float)y;
   const float fdx = floorf(dx), fdy = floorf(dy);
@@ -47,6 +48,10 @@ __device__ __forceinline__ Corner corners(float fx, float fy, int x, int y, int 
   c.i01 = gy0 * wps + gx1;
   c.i10 = gy1 * wps + gx0;
   c.i11 = gy1 * wps + gx1;
+  c.z00 = gy0 * wpz + gx0;
+  c.z01 = gy0 * wpz + gx1;
+  c.z10 = gy1 * wpz + gx0;
+  c.z11 = gy1 * wpz + gx1;
   return c;
 }
 
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     const float *__restrict__ gs, const float *__restrict__ flow, const float *__restrict__ hid,
     const float *__restrict__ w1, const float *__restrict__ g_logits, float *__restrict__ dzs,
     float *__restrict__ dzt, float *__restrict__ gflow, float *__restrict__ b0_partials, int H, int W, int64_t gs_bs,
-    int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope) {
+    int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope) {
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][129]: hidden pre-activations, then their gradient
@@ -192,11 +197,11 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       zp[64] = d1;
     }
     const float fx = flow[(b * 2 + 0) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
-    const Corner c = corners<KS>(fx, fy, x, y, H, W, wps);
+    const Corner c = corners<KS>(fx, fy, x, y, H, W, wps, wpz);
     if (zsb) {
       const float wa = c.xl * c.yt, wb = c.xr * c.yt, wc = c.xl * c.yb, wd = c.xr * c.yb;
-      float *z00 = zsb + (int64_t)(lead_s + c.i00) * kFcHidden + lane, *z01 = zsb + (int64_t)(lead_s + c.i01) * kFcHidden + lane;
-      float *z10 = zsb + (int64_t)(lead_s + c.i10) * kFcHidden + lane, *z11 = zsb + (int64_t)(lead_s + c.i11) * kFcHidden + lane;
+      float *z00 = zsb + (int64_t)(lead_s + c.z00) * kFcHidden + lane, *z01 = zsb + (int64_t)(lead_s + c.z01) * kFcHidden + lane;
+      float *z10 = zsb + (int64_t)(lead_s + c.z10) * kFcHidden + lane, *z11 = zsb + (int64_t)(lead_s + c.z11) * kFcHidden + lane;
       atomic_add(z00, wa * d0); atomic_add(z00 + 64, wa * d1);
       atomic_add(z01, wb * d0); atomic_add(z01 + 64, wb * d1);
       atomic_add(z10, wc * d0); atomic_add(z10 + 64, wc * d1);
@@ -252,7 +257,7 @@ int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, cons
 
 int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
                        float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
-                       int64_t gs_bs, int wps, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
+                       int64_t gs_bs, int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
                        float slope, hipStream_t stream) {
   if (!gs || !flow || !hid || !w1 || !g_logits) return GFLA_ERR_NULL_POINTER;
   if (int rc = smp_check(B, H, W, k)) return rc;
@@ -261,10 +266,10 @@ int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, con
   const unsigned lds = (unsigned)((kSmpPix * kSmpPitch + kFcHidden * k * k + 4 * kFcHidden) * sizeof(float));
   if (k == 3)
     fc_tail_bwd_kernel<3><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
   else
     fc_tail_bwd_kernel<5><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
   return launch_status();
 }
 
@@ -326,23 +331,36 @@ int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, 
   return launch_status();
 }
 
-// out[c] = scale * sum_r partials[r][c]
+// out[c] = scale * sum_r partials[r][c].  Two passes when there are many rows: kRedSplits row ranges are summed by
+// separate workgroups into tmp (kRedSplits x cols floats), then added up (a single pass over 1408 rows x 128
+// columns ran on 2 workgroups: 40 us).
+constexpr int kRedSplits = 32;
+
 __global__ __launch_bounds__(256) void fc_reduce_rows_kernel(const float *__restrict__ partials, float *__restrict__ out,
                                                             int64_t rows, int cols, float scale) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int64_t r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
   float s = 0.f;
   if (c < cols)
-    for (int64_t r = slice; r < rows; r += 4) s += partials[r * cols + c];
+    for (int64_t r = r0 + slice; r < r1; r += 4) s += partials[r * cols + c];
   red[slice][lane] = s;
   __syncthreads();
-  if (slice == 0 && c < cols) out[c] = scale * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (slice == 0 && c < cols)
+    out[(int64_t)blockIdx.y * cols + c] = scale * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
-int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, hipStream_t stream) {
+int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, float *tmp,
+                   hipStream_t stream) {
   if (cols <= 0) return GFLA_OK;
-  fc_reduce_rows_kernel<<<dim3((unsigned)ceil_div(cols, 64)), 256, 0, stream>>>(partials, out, rows, cols, scale);
+  const unsigned gx = (unsigned)ceil_div(cols, 64);
+  if (tmp && rows >= 4 * kRedSplits) {
+    fc_reduce_rows_kernel<<<dim3(gx, kRedSplits), 256, 0, stream>>>(partials, tmp, rows, cols, 1.f);
+    fc_reduce_rows_kernel<<<dim3(gx, 1), 256, 0, stream>>>(tmp, out, kRedSplits, cols, scale);
+  } else {
+    fc_reduce_rows_kernel<<<dim3(gx, 1), 256, 0, stream>>>(partials, out, rows, cols, scale);
+  }
   return launch_status();
 }
 

@@ -112,8 +112,12 @@ def test_geometry_has_the_slack_the_kernels_read():
         for src in (0, 1):
             g = _geometry(H, W, k, src)
             halo = (k - 1) * (g["Wp"] + 1)
-            assert g["lead"] == halo and g["Mg"] % 128 == 0 and g["Mdg"] % 128 == 0
-            assert g["Sx"] >= g["Mg"] + halo            # the convolution's last input tile
-            assert g["Sz"] >= g["Mdg"] + halo           # the transposed convolution's last input tile
+            assert g["lead"] == halo and g["Mg"] >= g["Ho"] * g["Wo"] and g["Mdg"] >= g["Md"]
+            # the convolution's largest row tile (256 outputs) starts at most at the last valid output's pixel and
+            # reads its rows' span (256 + one wrap of k-1 pixels per row crossed) + the tap halo
+            span = 256 + (255 // g["Wo"] + 1) * (k - 1)
+            last = (g["Ho"] - 1) * g["Wp"] + g["Wo"] - 1
+            assert last + halo + 1 == g["Md"] and g["Sx"] >= last + span + halo
+            assert g["Sz"] >= g["Md"] + 256 + halo      # the transposed convolution's last input tile
             assert g["Sz"] >= g["lead"] + (g["M"] + 63) // 64 * 64   # the weight gradient's last K step
             assert g["Ho"] == (H + k - 1 if src else H) and g["Wo"] == (W + k - 1 if src else W)
