@@ -21,6 +21,9 @@
 
 namespace gfla {
 
+constexpr int kFcMinRowBlocks = 2, kFcMaxRowBlocks = 8;
+constexpr int kFcPrefetch = 8;  // 16-byte input-tile pieces per thread held in registers across a chunk (mode 0)
+
 template <int MODE>
 __device__ __forceinline__ void load_b_frags(Frag<MODE> (&fb)[Fc<MODE>::KB], const unsigned char *p, int64_t split_stride) {
   if constexpr (MODE == 0) {
@@ -30,6 +33,17 @@ __device__ __forceinline__ void load_b_frags(Frag<MODE> (&fb)[Fc<MODE>::KB], con
 #pragma unroll
     for (int sp = 0; sp < Fc<MODE>::NS; ++sp) fb[0].s[sp] = *reinterpret_cast<const f16x8 *>(p + sp * split_stride);
   }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // a native vector: stays in registers as an array element
+
+// Mode 0 (one term, 4 pieces per 64-byte pixel record): thread t owns piece t & 3 of pixels (t >> 2) + 64*q, so pass q of
+// the input-tile staging is one base address + q times a uniform stride on both sides.
+__device__ __forceinline__ void fc_prefetch_pieces(u32x4 (&pf)[kFcPrefetch], const unsigned char *src, int x_ps, int pix0,
+                                                   int tmh) {
+#pragma unroll
+  for (int q = 0; q < kFcPrefetch; ++q)  // pixel clamped: the load is always legal, the LDS store is predicated
+    pf[q] = *reinterpret_cast<const u32x4 *>(src + (int64_t)min(pix0 + 64 * q, tmh - 1) * x_ps);
 }
 
 template <int MODE, int KS, int NMB>
@@ -72,13 +86,31 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
   const int x_total = per * F::NS;
   const int xplane = tmh * PITCH;
 
+  // Input tile staging.  Mode 0: the first 64*kFcPrefetch pixels of a chunk's tile are loaded into registers while
+  // the PREVIOUS chunk is being multiplied and only written to LDS at the chunk boundary, so the boundary costs two
+  // barriers and the LDS writes, not a global-memory round trip.  (Modes 2/3, and tile pixels beyond the register
+  // budget: loaded at the boundary.)
+  constexpr int PF = kFcPrefetch;
+  constexpr bool kPrefetch = MODE == 0;
+  u32x4 pf[PF];
+  const int pix0 = t >> 2;
+  const unsigned char *pf_src = xg + (t & 3) * 16;
+  unsigned char *pf_dst = xs + (size_t)pix0 * PITCH + (t & 3) * 16;
+  const int x_first = kPrefetch ? min(x_total, 256 * PF) : 0;  // pieces covered by the register path
+
   Frag<MODE> cur[F::KB], nxt[F::KB];
   load_b_frags<MODE>(cur, wg, w_split_stride);
+  if constexpr (kPrefetch) fc_prefetch_pieces(pf, pf_src, x_ps, pix0, tmh);
   for (int cc = 0; cc < nch; ++cc) {
     __syncthreads();  // every wave is done with the previous chunk's tile
-    {  // input tile of this chunk: x_total 16-byte pieces, 4 loads in flight per thread
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+        if (pix0 + 64 * q < tmh) *reinterpret_cast<u32x4 *>(pf_dst + (size_t)q * 64 * PITCH) = pf[q];
+    }
+    if (x_first < x_total) {
       const unsigned char *src = xg + (int64_t)cc * x_cs;
-      for (int base = t; base < x_total; base += 256 * 4) {
+      for (int base = x_first + t; base < x_total; base += 256 * 4) {
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
 #define GFLA_X_SP(idx_) (((idx_) >= per) + ((idx_) >= 2 * per))
 #define GFLA_X_REM(idx_) ((idx_)-GFLA_X_SP(idx_) * per)
@@ -109,6 +141,9 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
 #pragma unroll
         for (int q = 0; q < F::KB; ++q) nxt[q] = cur[q];
         if (lin < nch * KK) load_b_frags<MODE>(nxt, wg + (int64_t)lin * kWTile, w_split_stride);
+        if constexpr (kPrefetch)
+          if (tap == 0 && cc + 1 < nch)  // behind the weight slice: its wait leaves these in flight
+            fc_prefetch_pieces(pf, pf_src + (int64_t)(cc + 1) * x_cs, x_ps, pix0, tmh);
       }
       const int i = tap / KS, j = tap - i * KS;
       const unsigned char *xa = xs + (size_t)(i * Wp + j) * PITCH;
@@ -147,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
   }
 }
 
-constexpr int kFcMinRowBlocks = 2, kFcMaxRowBlocks = 8;
+
 
 // pixels of the LDS input tile for 32*mb output rows: the rows' own span + the tap halo
 inline int fc_conv_tile_pixels(int mb, int Wv, int Wp, int k) {

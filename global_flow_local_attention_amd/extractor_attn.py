@@ -274,6 +274,73 @@ def _mfma_mode(self, source, target, flow_field, conv0, act, conv1, k):
     return mode if fc_mfma.supported(source.size(1), source.size(2), source.size(3), k, mode) else None
 
 
+class FusedAttnFunction(Function):
+    """ExtractorAttn.forward with softmax=True (base_function.py:804-810) as ONE autograd node on the MFMA path:
+    (source, target, flow, conv0.weight, conv0.bias, conv1.weight, conv1.bias) -> (result, attn).
+
+    One node instead of FcMfmaFunction + LocalAttnAggregateFunction lets the backward write each gradient once:
+    the aggregation's d/d logits first, then the FC layers' backward, then the aggregation's (source, flow) scatter
+    ACCUMULATES into the tensors the FC backward just wrote -- no zero fills, no autograd add kernels.
+    `attn` (what hook_attn_param returns as attn_param_) is not differentiable here."""
+
+    @staticmethod
+    def forward(ctx, source, target, flow, w0, b0, w1, b1, kernel_size, slope, mode):
+        k, mode = int(kernel_size), int(mode)
+        fc_mfma._check(source, target, flow, w0, w1, k)
+        source, target, flow = source.contiguous(), target.contiguous(), flow.contiguous()
+        w0c, w1c = w0.contiguous(), w1.reshape(k * k, 128).contiguous()
+        b0c = None if b0 is None else b0.contiguous()
+        b1c = None if b1 is None else b1.contiguous()
+        B, C, H, W = source.shape
+        ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=source.device)
+        logits = source.new_empty((B, k * k, H, W))
+        _lib.call("gfla_fc_forward_f32", source, _lib.ptr(source), _lib.ptr(target), _lib.ptr(flow), _lib.ptr(w0c),
+                  _lib.ptr(b0c), _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(ws), _lib.ptr(logits), B, C, H, W, k,
+                  float(slope), mode)
+        out = source.new_empty((B, C, H, W))
+        attn = torch.empty_like(logits)
+        _lib.call("gfla_local_attn_aggregate_fwd_f32", source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(logits),
+                  _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
+        ctx.save_for_backward(source, flow, attn, w1c, ws)
+        ctx.dims = (B, C, H, W, k, float(slope), mode)
+        ctx.w_shapes = (w0.shape, w1.shape, b0 is not None, b1 is not None)
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        source, flow, attn, w1c, ws = ctx.saved_tensors
+        B, C, H, W, k, slope, mode = ctx.dims
+        w0_shape, w1_shape, has_b0, has_b1 = ctx.w_shapes
+        need = ctx.needs_input_grad
+        g_out = g_out.contiguous()
+        dev = source.device
+
+        def out(shape, wanted):
+            return torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
+
+        agg = "gfla_local_attn_aggregate_bwd_f32"
+        need_fc = any(need[i] for i in (1, 3, 4, 5, 6)) or need[0] or need[2]
+        g_logits = torch.zeros_like(attn)  # accumulated with atomics by the kernel
+        _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out), None, None,
+                  _lib.ptr(g_logits), B, C, H, W, H, W, k, 1)
+        g_source, g_target = out((B, C, H, W), need[0]), out((B, C, H, W), need[1])
+        g_flow = out((B, 2, H, W), need[2])
+        g_w0 = out(w0_shape, need[3])
+        g_b0 = out((128,), need[4] and has_b0)
+        g_w1 = out(w1_shape, need[5])
+        g_b1 = out((k * k,), need[6] and has_b1)
+        if need_fc:
+            scratch = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
+            _lib.call("gfla_fc_backward_f32", flow, _lib.ptr(ws), _lib.ptr(flow), _lib.ptr(w1c), _lib.ptr(g_logits),
+                      _lib.ptr(scratch), _lib.ptr(g_source), _lib.ptr(g_target), _lib.ptr(g_flow), _lib.ptr(g_w0),
+                      _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode)
+        if need[0] or need[2]:  # += the aggregation's own (source, flow) gradient
+            _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out),
+                      _lib.ptr(g_source), _lib.ptr(g_flow), None, B, C, H, W, H, W, k, 1)
+        return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
@@ -289,6 +356,10 @@ def _fused_attention(self, source, target, flow_field):
     mode = _mfma_mode(self, source_c, target, flow_c, conv0, act, conv1, k)
     if mode is not None:
         # both FC layers on the matrix cores: no block tensor, no library GEMM / convolution (fc_mfma.py)
+        if isinstance(last, nn.Softmax) and last.dim == 1 and getattr(self, "single_node", True):
+            result, attn = FusedAttnFunction.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
+                                                   conv1.bias, k, _tail_slope(act), mode)
+            return attn, result
         logits = fc_mfma.FcMfmaFunction.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
                                               conv1.bias, k, _tail_slope(act), mode)
         return _aggregate(source_c, flow_c, logits, last, k, None)
