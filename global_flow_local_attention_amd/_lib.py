@@ -45,11 +45,14 @@ _SINGLE = {
     "gfla_fc_supported": [_i64] * 3 + [_int, _int],
     "gfla_fc_workspace_bytes": [_i64] * 4 + [_int] * 3,
     "gfla_fc_forward_f32": [_ptr] * 9 + [_i64] * 4 + [_int, ctypes.c_double, _int, _ptr],
-    "gfla_fc_backward_f32": [_ptr] * 12 + [_i64] * 4 + [_int, ctypes.c_double, _int, _ptr],
+    "gfla_fc_backward_f32": [_ptr] * 12 + [_i64] * 4 + [_int, ctypes.c_double, _int, _int, _ptr],
     "gfla_fc_geometry": [_i64, _i64, _int, _int, _ptr],
     "gfla_fc_conv_fwd_f32": [_ptr, _ptr, _int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_fc_conv_bwd_f32": [_ptr, _int, _ptr, _ptr, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_fc_tr_probe": [_ptr, _int, _ptr, _ptr, _ptr],
+    "gfla_scatter_workspace_bytes": [_i64] * 3 + [_int],
+    "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_resample2d_bwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _int, _ptr],
 }
 _FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
                   "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}
@@ -105,11 +108,22 @@ def lib():
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 
-def suffix(t, what):
+def suffix(t, what, allow_bf16=True):
+    """Entry-point suffix for t's dtype.  bfloat16 storage exists for the forward entry points only: backward
+    callers pass allow_bf16=False and get a clear error instead of a missing-symbol AttributeError."""
     try:
-        return _SUFFIX[t.dtype]
+        sfx = _SUFFIX[t.dtype]
     except KeyError:
         raise TypeError("%s: unsupported dtype %s (float32, float64, bfloat16 forward)" % (what, t.dtype))
+    if sfx == "bf16" and not allow_bf16:
+        raise TypeError("%s: bfloat16 is forward-only in this library (use float32 for training)" % what)
+    return sfx
+
+
+def scatter_workspace(ref_tensor, B, H, W, entries):
+    """Scratch for the matrix-core scatter paths (csrc/patch_mfma.hip): the patch table of one op invocation."""
+    n = lib().gfla_scatter_workspace_bytes(int(B), int(H), int(W), int(entries))
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=ref_tensor.device)
 
 
 def require_gpu(*tensors):

@@ -129,7 +129,7 @@ static int fc_forward(const float *source, const float *target, const float *flo
 // Z-layout gradient map
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
                             float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode,
-                            hipStream_t stream) {
+                            hipStream_t stream, int acc_x = 0) {
   const bool want_w = g_w0 != nullptr;
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const int nch_h = kFcHidden / kFcChunk;
@@ -152,7 +152,7 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
     const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
     GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
                      g.Wp, k, mode, a_z, a_w, stream));
-    GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, 0, stream));
+    GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
@@ -170,7 +170,7 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
 
 static int fc_backward(void *ws_, const float *flow, const float *w1, const float *g_logits, void *scratch_,
                        float *g_source, float *g_target, float *g_flow, float *g_w0, float *g_b0, float *g_w1,
-                       float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode,
+                       float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode, int flags,
                        hipStream_t stream) {
   if (!ws_ || !flow || !w1 || !g_logits || !scratch_) return GFLA_ERR_NULL_POINTER;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
@@ -189,7 +189,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const int64_t tiles = ceil_div((int64_t)H * W, 64);
   GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
                               L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
-                              stream));
+                              flags & GFLA_FC_ACCUMULATE_FLOW, stream));
   float *red = reinterpret_cast<float *>(sc + L.red);
   float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
   if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, red_tmp, stream));
@@ -202,7 +202,9 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
     if (g_b1 && hipMemcpyAsync(g_b1, red + 32 * kFcHidden, (size_t)L.KK * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return GFLA_ERR_LAUNCH;
   }
-  if (need_s) GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode, stream));
+  if (need_s)
+    GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode, stream,
+                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0));
   if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode, stream));
   if (g_w0 && mode != 0) {
     const uint32_t *a = mode ? amax : nullptr;
@@ -239,9 +241,9 @@ int gfla_fc_forward_f32(const float *source, const float *target, const float *f
 int gfla_fc_backward_f32(void *workspace, const float *flow, const float *w1, const float *grad_logits,
                          void *scratch, float *grad_source, float *grad_target, float *grad_flow, float *grad_w0,
                          float *grad_b0, float *grad_w1, float *grad_b1, int64_t B, int64_t C, int64_t H, int64_t W,
-                         int kernel_size, double slope, int mode, gfla_stream_t stream) {
+                         int kernel_size, double slope, int mode, int flags, gfla_stream_t stream) {
   return fc_backward(workspace, flow, w1, grad_logits, scratch, grad_source, grad_target, grad_flow, grad_w0, grad_b0,
-                     grad_w1, grad_b1, B, (int)C, (int)H, (int)W, kernel_size, (float)slope, mode,
+                     grad_w1, grad_b1, B, (int)C, (int)H, (int)W, kernel_size, (float)slope, mode, flags,
                      static_cast<hipStream_t>(stream));
 }
 

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     const float *__restrict__ gs, const float *__restrict__ flow, const float *__restrict__ hid,
     const float *__restrict__ w1, const float *__restrict__ g_logits, float *__restrict__ dzs,
     float *__restrict__ dzt, float *__restrict__ gflow, float *__restrict__ b0_partials, int H, int W, int64_t gs_bs,
-    int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope) {
+    int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope, int acc_flow) {
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][129]: hidden pre-activations, then their gradient
@@ -217,9 +217,10 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       float gy = d0 * (c.xl * (a10 - a00) + c.xr * (a11 - a01)) + d1 * (c.xl * (e10 - e00) + c.xr * (e11 - e01));
       gx = wave_sum_f(gx);
       gy = wave_sum_f(gy);
-      if (lane == 0) {
-        gflow[(b * 2 + 0) * HW + p] = gx;
-        gflow[(b * 2 + 1) * HW + p] = gy;
+      if (lane == 0) {  // this workgroup is the only writer of its pixels
+        float *fxp = gflow + (b * 2 + 0) * HW + p, *fyp = gflow + (b * 2 + 1) * HW + p;
+        *fxp = acc_flow ? *fxp + gx : gx;
+        *fyp = acc_flow ? *fyp + gy : gy;
       }
     }
   }
@@ -258,7 +259,7 @@ int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, cons
 int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
                        float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
                        int64_t gs_bs, int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
-                       float slope, hipStream_t stream) {
+                       float slope, int acc_flow, hipStream_t stream) {
   if (!gs || !flow || !hid || !w1 || !g_logits) return GFLA_ERR_NULL_POINTER;
   if (int rc = smp_check(B, H, W, k)) return rc;
   if (B == 0) return GFLA_OK;
@@ -266,10 +267,10 @@ int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, con
   const unsigned lds = (unsigned)((kSmpPix * kSmpPitch + kFcHidden * k * k + 4 * kFcHidden) * sizeof(float));
   if (k == 3)
     fc_tail_bwd_kernel<3><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow);
   else
     fc_tail_bwd_kernel<5><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow);
   return launch_status();
 }
 

@@ -13,8 +13,11 @@
 // bilinear weights into a (k+1)x(k+1) coefficient patch (all taps of one pixel share the same
 // fractional offset, so they read a dense patch), and then walks a chunk of channels doing
 // (k+1)^2 loads + FMAs each.
+#include <type_traits>
+
 #include "gfla_common.h"
 #include "be_bwd_lds.h"
+#include "patch_mfma.h"
 
 namespace gfla {
 
@@ -400,8 +403,8 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
 template <typename T, int K>
 __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ glogits, int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles,
-    int total) {
+    T *__restrict__ glogits, const T *__restrict__ attn, T *__restrict__ gflow, int C, int Hs, int Ws, int H,
+    int W, int G, int nsuper, int CS, int ntiles, int total) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
@@ -442,7 +445,11 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
   const A inv_kk = (A)1 / (A)KK;
   const int cs0 = sg * CS;
   const int cs1 = min(C, cs0 + CS);
-  T *gl = glogits + (int64_t)b * KK * HW + pc;
+  T *gl = glogits ? glogits + (int64_t)b * KK * HW + pc : nullptr;
+  // d/d flow (block_extractor_kernel.cu:163-164) is linear in the same patch sums P, weighted by the attention:
+  // computed here when asked for (attn, gflow non-NULL), one atomic pair per pixel and channel super-group
+  const T *at = attn ? attn + (int64_t)b * KK * HW + pc : nullptr;
+  A gx_acc = 0, gy_acc = 0;
   for (int cb = cs0; cb < cs1; cb += G) {
     const int gc = min(G, cs1 - cb);
     __syncthreads();  // previous sub-group fully consumed
@@ -476,11 +483,17 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
             const A fdx = floor_t<A>(dx);
             const int xL = clampi((int)fdx, 0, Ws - 1), xR = clampi((int)(fdx + 1), 0, Ws - 1);
             const A xR_P = dx - fdx, xL_P = 1 - xR_P;
-            A bs = (xL_P * yT_P) * pl[yT + xL];
-            bs += (xR_P * yT_P) * pl[yT + xR];
-            bs += (xL_P * yB_P) * pl[yB + xL];
-            bs += (xR_P * yB_P) * pl[yB + xR];
-            atomic_add(gl + (int64_t)(i * K + j) * HW, (T)(go * bs));
+            const A vTL = pl[yT + xL], vTR = pl[yT + xR], vBL = pl[yB + xL], vBR = pl[yB + xR];
+            A bs = (xL_P * yT_P) * vTL;
+            bs += (xR_P * yT_P) * vTR;
+            bs += (xL_P * yB_P) * vBL;
+            bs += (xR_P * yB_P) * vBR;
+            if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)(go * bs));
+            if (gflow) {
+              const A gv = Num<T>::ld(at + (int64_t)(i * K + j) * HW) * go;
+              gy_acc += gv * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
+              gx_acc += gv * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+            }
           }
         }
       }
@@ -497,9 +510,20 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
         ga += (xR_P * yT_P) * P[i * (K + 1) + j + 1];
         ga += (xL_P * yB_P) * P[(i + 1) * (K + 1) + j];
         ga += (xR_P * yB_P) * P[(i + 1) * (K + 1) + j + 1];
-        atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga);
+        if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga);
+        if (gflow) {
+          const A a_ij = Num<T>::ld(at + (int64_t)(i * K + j) * HW);
+          const A pTL = P[i * (K + 1) + j], pTR = P[i * (K + 1) + j + 1];
+          const A pBL = P[(i + 1) * (K + 1) + j], pBR = P[(i + 1) * (K + 1) + j + 1];
+          gy_acc += a_ij * (-xL_P * pTL - xR_P * pTR + xL_P * pBL + xR_P * pBR);
+          gx_acc += a_ij * (-yT_P * pTL - yB_P * pBL + yT_P * pTR + yB_P * pBR);
+        }
       }
     }
+  }
+  if (active && gflow) {
+    atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, (T)gx_acc);
+    atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, (T)gy_acc);
   }
 }
 
@@ -584,16 +608,63 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
   return launch_status();
 }
 
+// (2) d/d a_ij [+ d/d flow when gflow != NULL], then (3) the softmax Jacobian in place
+template <typename T>
+static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *gout, T *glogits, T *gflow, int64_t B,
+                         int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm, hipStream_t stream) {
+  using A = typename Num<T>::acc;
+  const int threads = 512;
+  const int64_t ntiles = ceil_div(H * W, threads);
+  int64_t G = kLdsBudget / (Hs * Ws * (int64_t)sizeof(A));
+  if (G < 1) return GFLA_ERR_UNSUPPORTED;
+  if (G > C) G = C;
+  int64_t nsuper = 1;  // split the channels until the launch has >= 4 workgroups per CU
+  while (B * ntiles * nsuper < 4 * kNumCU && nsuper * 2 * G <= C) nsuper *= 2;
+  const int64_t CS = ceil_div(C, nsuper);
+  nsuper = ceil_div(C, CS);
+  if (G > CS) G = CS;
+  const int64_t blocks = B * nsuper * ntiles;
+  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  const unsigned lds = (unsigned)(G * Hs * Ws * sizeof(A));
+  const int64_t padded = ceil_div(blocks, kNumXCD) * kNumXCD;  // the XCD remap needs a multiple of 8
+  GFLA_K_SWITCH(k, agg_ga_lds_kernel<T, K><<<dim3((unsigned)padded), dim3(threads), lds, stream>>>(
+                       src, flow, gout, glogits, gflow ? attn : nullptr, gflow, (int)C, (int)Hs, (int)Ws, (int)H, (int)W,
+                       (int)G, (int)nsuper, (int)CS, (int)ntiles, (int)blocks));
+  int st = launch_status();
+  if (st == GFLA_OK && sm && glogits) {
+    const int64_t n = B * H * W;
+    GFLA_K_SWITCH(k, agg_softmax_bwd_kernel<T, K><<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, stream>>>(
+                         attn, glogits, n, (int)(H * W)));
+    st = launch_status();
+  }
+  return st;
+}
+
+// All three outputs are ACCUMULATED into (the caller zeroes them, or passes partial gradients to add to).
+// workspace (gfla_scatter_workspace_bytes, may be NULL): enables the matrix-core scatter for d/d source (f32).
 template <typename T>
 static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *gout, T *gsrc, T *gflow,
                          T *glogits, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W,
-                         int k, int sm, gfla_stream_t stream_) {
+                         int k, int sm, gfla_stream_t stream_, void *workspace = nullptr) {
   if (!src || !flow || !attn || !gout) return GFLA_ERR_NULL_POINTER;
   int st = agg_check(B, C, Hs, Ws, H, W, k);
   if (st != GFLA_OK) return st;
   if (!gsrc && !gflow && !glogits) return GFLA_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
+  const bool planes_fit = Hs * Ws * (int64_t)sizeof(A) <= kLdsBudget;
+  if constexpr (std::is_same<T, float>::value) {
+    // d/d source as a block-sparse product on the matrix cores (patch_mfma.hip); d/d flow then comes out of the
+    // d/d a_ij pass, which holds the patch sums it needs
+    if (workspace && tuning(3) != 1 && (planes_fit || (!gflow && !glogits))) {
+      st = gsrc ? agg_source_bwd_mfma(flow, attn, gout, gsrc, workspace, B, C, Hs, Ws, H, W, k, 1, stream) : GFLA_OK;
+      if (st == GFLA_OK) {
+        if (gflow || glogits) st = launch_agg_ga<T>(src, flow, attn, gout, glogits, gflow, B, C, Hs, Ws, H, W, k, sm, stream);
+        return st;
+      }
+      if (st != GFLA_ERR_UNSUPPORTED) return st;
+    }
+  }
   if (tuning(3) != 1 && Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) <= kLdsBudget) {
     // (1) grad_source + grad_flow: block_extractor backward of the factored gradient a_ij*g_c/k^2
     if (gsrc || gflow) {
@@ -602,32 +673,7 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
       if (st != GFLA_OK) return st;
       if (!done) return GFLA_ERR_UNSUPPORTED;
     }
-    // (2) d/d a_ij, then (3) the softmax Jacobian in place
-    if (glogits) {
-      const int threads = 512;
-      const int64_t ntiles = ceil_div(H * W, threads);
-      int64_t G = kLdsBudget / (Hs * Ws * (int64_t)sizeof(A));
-      if (G > C) G = C;
-      int64_t nsuper = 1;  // split the channels until the launch has >= 4 workgroups per CU
-      while (B * ntiles * nsuper < 4 * kNumCU && nsuper * 2 * G <= C) nsuper *= 2;
-      const int64_t CS = ceil_div(C, nsuper);
-      nsuper = ceil_div(C, CS);
-      if (G > CS) G = CS;
-      const int64_t blocks = B * nsuper * ntiles;
-      if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      const unsigned lds = (unsigned)(G * Hs * Ws * sizeof(A));
-      const int64_t padded = ceil_div(blocks, kNumXCD) * kNumXCD;  // the XCD remap needs a multiple of 8
-      GFLA_K_SWITCH(k, agg_ga_lds_kernel<T, K><<<dim3((unsigned)padded), dim3(threads), lds, stream>>>(
-                           src, flow, gout, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, (int)G, (int)nsuper, (int)CS, (int)ntiles,
-                           (int)blocks));
-      st = launch_status();
-      if (st == GFLA_OK && sm) {
-        const int64_t n = B * H * W;
-        GFLA_K_SWITCH(k, agg_softmax_bwd_kernel<T, K><<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, stream>>>(
-                             attn, glogits, n, (int)(H * W)));
-        st = launch_status();
-      }
-    }
+    if (glogits) st = launch_agg_ga<T>(src, flow, attn, gout, glogits, (T *)nullptr, B, C, Hs, Ws, H, W, k, sm, stream);
     return st;
   }
   AggGeo g = agg_geometry(B, C, H, W, 32, 2 * kNumCU * kWavesPerCU);
@@ -687,6 +733,11 @@ int gfla_local_attn_aggregate_bwd_f32(const float *s, const float *f, const floa
                                       float *gs, float *gf, float *gl, int64_t B, int64_t C, int64_t Hs,
                                       int64_t Ws, int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
   return gfla::aggregate_bwd<float>(s, f, a, go, gs, gf, gl, B, C, Hs, Ws, H, W, k, sm, st);
+}
+int gfla_local_attn_aggregate_bwd_ws_f32(const float *s, const float *f, const float *a, const float *go, float *gs,
+                                         float *gf, float *gl, void *workspace, int64_t B, int64_t C, int64_t Hs,
+                                         int64_t Ws, int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
+  return gfla::aggregate_bwd<float>(s, f, a, go, gs, gf, gl, B, C, Hs, Ws, H, W, k, sm, st, workspace);
 }
 int gfla_local_attn_aggregate_bwd_f64(const double *s, const double *f, const double *a, const double *go,
                                       double *gs, double *gf, double *gl, int64_t B, int64_t C,

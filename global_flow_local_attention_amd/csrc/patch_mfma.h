@@ -1,0 +1,17 @@
+// Matrix-core scatter paths (patch_mfma.hip).  Both return GFLA_ERR_UNSUPPORTED without launching anything when the
+// shape is outside the path; the target is accumulated into (+=) when accumulate != 0, overwritten otherwise.
+#pragma once
+
+#include "gfla_common.h"
+
+namespace gfla {
+
+int agg_source_bwd_mfma(const float *flow, const float *attn, const float *gout, float *gsrc, void *workspace,
+                        int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int accumulate,
+                        hipStream_t stream);
+int rs_input1_bwd_mfma(const float *in2, const float *gout, float *gin1, void *workspace, int64_t B, int64_t C,
+                       int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int trunc, int accumulate,
+                       hipStream_t stream);
+int64_t pm_workspace_bytes(int64_t B, int64_t H, int64_t W, int entries);
+
+}  // namespace gfla

@@ -14,88 +14,10 @@
 #include <type_traits>
 
 #include "lds_plane.h"
+#include "rs_taps.h"
+#include "patch_mfma.h"
 
 namespace gfla {
-
-constexpr double kEps = 1e-8;  // resample2d_kernel.cu:14
-
-// SAFE_DIV(a,b) with a,b in the arithmetic type, value in double (resample2d_kernel.cu:15).
-template <typename A>
-__device__ __forceinline__ double safe_div(A a, A b) {
-  return (b == 0) ? ((double)a / kEps) : (double)(a / b);
-}
-
-template <typename A>
-__device__ __forceinline__ A gauss(A dist, A sigma) {
-  return (A)exp(safe_div<A>(-dist * dist, 2 * sigma * sigma));  // :75-78
-}
-// Single-precision exp for the LDS-plane kernels, where the weights are recomputed once per channel
-// GROUP and eight double-precision exps per lane would dominate the instruction stream.  expf is
-// within 1 ulp of the reference's (float)exp((double)q): a 6e-8 relative change of a weight.
-template <typename A>
-__device__ __forceinline__ A gauss_fast(A dist, A sigma) {
-  return gauss<A>(dist, sigma);
-}
-template <>
-__device__ __forceinline__ float gauss_fast<float>(float dist, float sigma) {
-  const float num = -dist * dist, den = 2 * sigma * sigma;
-  return (den == 0) ? (float)exp((double)num / kEps) : expf(num / den);
-}
-
-// Per-pixel state shared by all three kernels: tap row/column offsets and 1-D weights.
-template <typename A, int KH>
-struct Taps {
-  int xL[KH], xR[KH], yT[KH], yB[KH];  // yT/yB pre-multiplied by the row pitch
-  A xLd[KH], xRd[KH], yTd[KH], yBd[KH];  // distances
-  A xLp[KH], xRp[KH], yTp[KH], yBp[KH];  // Gaussian weights
-  A sum;
-  A sigma;
-  int ix0, iy0;  // (int)floor(x + dx), (int)floor(y + dy)
-
-  // The 2*KH tap rows / columns as flat lists ordered by position when dilation == 1:
-  // index r < KH -> the "top"/"left" tap KH-1-r (above/left of the sample), r >= KH -> "bottom"/"right" tap r-KH.
-  __device__ __forceinline__ int row_off(int r) const { return r < KH ? yT[KH - 1 - r] : yB[r - KH]; }
-  __device__ __forceinline__ A row_w(int r) const { return r < KH ? yTp[KH - 1 - r] : yBp[r - KH]; }
-  __device__ __forceinline__ A row_d(int r) const { return r < KH ? yTd[KH - 1 - r] : yBd[r - KH]; }
-  __device__ __forceinline__ int col_off(int q) const { return q < KH ? xL[KH - 1 - q] : xR[q - KH]; }
-  __device__ __forceinline__ A col_w(int q) const { return q < KH ? xLp[KH - 1 - q] : xRp[q - KH]; }
-  __device__ __forceinline__ A col_d(int q) const { return q < KH ? xLd[KH - 1 - q] : xRd[q - KH]; }
-
-  // floor_alpha: fractional part from floor (forward, input2 gradient) or from int() truncation
-  // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
-  template <bool FAST = false>
-  __device__ __forceinline__ void init(A dx, A dy, A sg, int x, int y, int Hi, int Wi, int dil,
-                                       bool trunc_alpha) {
-    sigma = sg;
-    const A xf = (A)x + dx, yf = (A)y + dy;  // :52-53
-    const A fxf = floor_t<A>(xf), fyf = floor_t<A>(yf);
-    ix0 = (int)fxf;
-    iy0 = (int)fyf;
-    const A alpha = trunc_alpha ? xf - (A)(int)xf : xf - fxf;
-    const A beta = trunc_alpha ? yf - (A)(int)yf : yf - fyf;
-    sum = 0;
-#pragma unroll
-    for (int f = 0; f < KH; ++f) {
-      yT[f] = clampi((int)(fyf - (A)(f * dil)), 0, Hi - 1) * Wi;         // :62-63
-      yB[f] = clampi((int)(fyf + (A)((f + 1) * dil)), 0, Hi - 1) * Wi;
-      xL[f] = clampi((int)(fxf - (A)(f * dil)), 0, Wi - 1);              // :66-67
-      xR[f] = clampi((int)(fxf + (A)((f + 1) * dil)), 0, Wi - 1);
-      xLd[f] = (A)(f * dil) + alpha;                                     // :70-73
-      xRd[f] = (A)((1. + f) * dil) - alpha;
-      yTd[f] = (A)(f * dil) + beta;
-      yBd[f] = (A)((1. + f) * dil) - beta;
-      xLp[f] = FAST ? gauss_fast<A>(xLd[f], sg) : gauss<A>(xLd[f], sg);
-      xRp[f] = FAST ? gauss_fast<A>(xRd[f], sg) : gauss<A>(xRd[f], sg);
-      yTp[f] = FAST ? gauss_fast<A>(yTd[f], sg) : gauss<A>(yTd[f], sg);
-      yBp[f] = FAST ? gauss_fast<A>(yBd[f], sg) : gauss<A>(yBd[f], sg);
-    }
-#pragma unroll
-    for (int fy = 0; fy < KH; ++fy)
-#pragma unroll
-      for (int fx = 0; fx < KH; ++fx)  // :89
-        sum += (yTp[fy] * xLp[fx] + yTp[fy] * xRp[fx] + yBp[fy] * xLp[fx] + yBp[fy] * xRp[fx]);
-  }
-};
 
 __device__ __forceinline__ bool decode(int sp_blocks, int ncg, int HW, int W, int &b, int &cg, int &y,
                                        int &x) {
@@ -530,6 +452,22 @@ int gfla_resample2d_fwd_bf16(const uint16_t *a, const uint16_t *b, uint16_t *o, 
 int gfla_resample2d_bwd_f32(const float *a, const float *b, const float *go, float *g1, float *g2,
                             int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,
                             int d, int trunc, gfla_stream_t st) {
+  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st);
+}
+/* As gfla_resample2d_bwd_f32 with scratch (gfla_scatter_workspace_bytes(B, H, W, k*k), may be NULL): d/d input1 runs as
+ * a block-sparse product on the matrix cores (patch_mfma.hip) when dilation == 1 and the shape allows, else as before. */
+int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, float *g1, float *g2, void *workspace,
+                               int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int d,
+                               int trunc, gfla_stream_t st) {
+  if (g1 && workspace && d == 1 && gfla::tuning(6) != 1) {
+    int rc = gfla::check<float>(a, b, B, C, Hi, Wi, H, W, k, d);
+    if (rc != GFLA_OK) return rc;
+    if (!go) return GFLA_ERR_NULL_POINTER;
+    rc = gfla::rs_input1_bwd_mfma(b, go, g1, workspace, B, C, Hi, Wi, H, W, k, trunc, 1, static_cast<hipStream_t>(st));
+    if (rc == GFLA_OK) g1 = nullptr;  // done; the rest of the call only has d/d input2 left
+    else if (rc != GFLA_ERR_UNSUPPORTED) return rc;
+    if (!g1 && !g2) return GFLA_OK;
+  }
   return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st);
 }
 int gfla_resample2d_bwd_f64(const double *a, const double *b, const double *go, double *g1, double *g2,

@@ -90,10 +90,16 @@ class LocalAttnAggregateFunction(Function):
         gf = torch.zeros_like(flow_field) if nf else None
         gl = torch.zeros_like(attn) if nl else None
         if ns or nf or nl:
-            _lib.call("gfla_local_attn_aggregate_bwd_" + _lib.suffix(source, "local_attn_aggregate backward"),
-                      source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(attn), _lib.ptr(grad_out),
-                      _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl),
-                      b, c, hs, ws, h, w, ctx.kernel_size, 1 if ctx.apply_softmax else 0)
+            sfx = _lib.suffix(source, "local_attn_aggregate backward", allow_bf16=False)
+            tail = (b, c, hs, ws, h, w, ctx.kernel_size, 1 if ctx.apply_softmax else 0)
+            if sfx == "f32" and ns:  # d/d source as a block-sparse product on the matrix cores (csrc/patch_mfma.hip)
+                scratch = _lib.scatter_workspace(source, b, h, w, (ctx.kernel_size + 1) ** 2)
+                _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", source, _lib.ptr(source), _lib.ptr(flow_field),
+                          _lib.ptr(attn), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl),
+                          _lib.ptr(scratch), *tail)
+            else:
+                _lib.call("gfla_local_attn_aggregate_bwd_" + sfx, source, _lib.ptr(source), _lib.ptr(flow_field),
+                          _lib.ptr(attn), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl), *tail)
         return gs, gf, gl, None, None, None
 
 
@@ -139,11 +145,11 @@ class BlockExtractorUnfoldFunction(Function):
         if ns or nf:
             if parked is not None:  # FC-operand gradient + attention-aggregation gradient in one pass
                 attn, g_small = parked
-                _lib.call("gfla_local_attn_source_bwd_" + _lib.suffix(source, "local_attn_source backward"), source,
+                _lib.call("gfla_local_attn_source_bwd_" + _lib.suffix(source, "local_attn_source backward", allow_bf16=False), source,
                           _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(attn), _lib.ptr(g_small),
                           _lib.ptr(gs), _lib.ptr(gf), b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
             else:
-                _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
+                _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward", allow_bf16=False),
                           source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
                           b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
         return gs, gf, None, None, None
@@ -319,25 +325,26 @@ class FusedAttnFunction(Function):
         def out(shape, wanted):
             return torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
 
-        agg = "gfla_local_attn_aggregate_bwd_f32"
-        need_fc = any(need[i] for i in (1, 3, 4, 5, 6)) or need[0] or need[2]
+        agg = "gfla_local_attn_aggregate_bwd_ws_f32"
+        table = _lib.scatter_workspace(source, B, H, W, (k + 1) ** 2)
         g_logits = torch.zeros_like(attn)  # accumulated with atomics by the kernel
-        _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out), None, None,
-                  _lib.ptr(g_logits), B, C, H, W, H, W, k, 1)
+        g_flow = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev) if need[2] else None
+        # d/d logits and, out of the same patch sums, the aggregation's d/d flow
+        _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out), None, _lib.ptr(g_flow),
+                  _lib.ptr(g_logits), _lib.ptr(table), B, C, H, W, H, W, k, 1)
         g_source, g_target = out((B, C, H, W), need[0]), out((B, C, H, W), need[1])
-        g_flow = out((B, 2, H, W), need[2])
         g_w0 = out(w0_shape, need[3])
         g_b0 = out((128,), need[4] and has_b0)
         g_w1 = out(w1_shape, need[5])
         g_b1 = out((k * k,), need[6] and has_b1)
-        if need_fc:
-            scratch = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
-            _lib.call("gfla_fc_backward_f32", flow, _lib.ptr(ws), _lib.ptr(flow), _lib.ptr(w1c), _lib.ptr(g_logits),
-                      _lib.ptr(scratch), _lib.ptr(g_source), _lib.ptr(g_target), _lib.ptr(g_flow), _lib.ptr(g_w0),
-                      _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode)
-        if need[0] or need[2]:  # += the aggregation's own (source, flow) gradient
+        scratch = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
+        _lib.call("gfla_fc_backward_f32", flow, _lib.ptr(ws), _lib.ptr(flow), _lib.ptr(w1c), _lib.ptr(g_logits),
+                  _lib.ptr(scratch), _lib.ptr(g_source), _lib.ptr(g_target), _lib.ptr(g_flow), _lib.ptr(g_w0),
+                  _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode,
+                  2 if need[2] else 0)  # GFLA_FC_ACCUMULATE_FLOW
+        if need[0]:  # += the aggregation's own source gradient (matrix-core scatter)
             _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out),
-                      _lib.ptr(g_source), _lib.ptr(g_flow), None, B, C, H, W, H, W, k, 1)
+                      _lib.ptr(g_source), None, None, _lib.ptr(table), B, C, H, W, H, W, k, 1)
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
 
 

@@ -93,5 +93,5 @@ class FcMfmaFunction(Function):
         scratch = torch.empty(workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
         _lib.call("gfla_fc_backward_f32", flow, _lib.ptr(ws), _lib.ptr(flow), _lib.ptr(w1c), _lib.ptr(g_logits),
                   _lib.ptr(scratch), _lib.ptr(g_source), _lib.ptr(g_target), _lib.ptr(g_flow), _lib.ptr(g_w0),
-                  _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode)
+                  _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode, 0)
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None

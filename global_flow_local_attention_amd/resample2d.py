@@ -51,13 +51,19 @@ class Resample2dFunction(Function):
         if (want1 or want2) and grad_warped.numel() > 0 and input1.numel() > 0:
             _, C, Hi, Wi = input1.shape
             B, _, H, W = input2.shape
-            entry = "gfla_resample2d_bwd_" + _lib.suffix(input1, "resample2d backward")
+            sfx = _lib.suffix(input1, "resample2d backward", allow_bf16=False)
+            entry = "gfla_resample2d_bwd_" + sfx
             tail = (B, C, Hi, Wi, H, W, ctx.kernel_size, ctx.dilation, 1 if TRUNC_COMPAT else 0)
             # two independent kernels (scatter into input1 / reduction for (dx, dy, sigma)): one C-ABI
             # call each keeps them separately visible to profilers
             if want1:
-                _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
-                          _lib.ptr(g1), None, *tail)
+                if sfx == "f32":  # d/d input1 as a block-sparse product on the matrix cores when the shape allows
+                    ws = _lib.scatter_workspace(input1, B, H, W, ctx.kernel_size * ctx.kernel_size)
+                    _lib.call("gfla_resample2d_bwd_ws_f32", input1, _lib.ptr(input1), _lib.ptr(input2),
+                              _lib.ptr(grad_warped), _lib.ptr(g1), None, _lib.ptr(ws), *tail)
+                else:
+                    _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
+                              _lib.ptr(g1), None, *tail)
             if want2:
                 _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
                           None, _lib.ptr(g2), *tail)

@@ -205,6 +205,26 @@ GFLA_DECL_AGGREGATE_BWD(f32, float)
 GFLA_DECL_AGGREGATE_BWD(f64, double)
 #undef GFLA_DECL_AGGREGATE_BWD
 
+/* ---- scatters as block-sparse products on the matrix cores (csrc/patch_mfma.hip) -----------------------------
+ * The two backward passes that scatter into a feature plane -- the aggregation's d/d source and resample2d's
+ * d/d input1 (resample2d_kernel.cu:98-202; replaces its atomicAdd scatter) -- spread each flow pixel's gradient over
+ * a dense patch with channel-independent weights: a sparse x dense product.  The *_ws entry points take scratch for
+ * the per-pixel patch table (gfla_scatter_workspace_bytes(B, H, W, entries): entries = (k+1)^2 for the aggregation,
+ * k*k for resample2d; 256-byte aligned; may be NULL = the LDS-atomic kernels of the plain entry points) and multiply
+ * the tiled sparse matrix on v_mfma_f32_32x32x2_f32 with output-stationary accumulators: no atomics, fixed summation
+ * order.  With a workspace the aggregation's d/d flow comes out of the d/d logits pass.  Same accumulate-into
+ * contract as the plain entry points; unsupported shapes (plane rows wider than 192, dilation != 1) fall back.   */
+int64_t gfla_scatter_workspace_bytes(int64_t B, int64_t H, int64_t W, int patch_entries);
+int gfla_local_attn_aggregate_bwd_ws_f32(const float *source, const float *flow, const float *attn,
+                                         const float *grad_out, float *grad_source, float *grad_flow,
+                                         float *grad_logits, void *workspace, int64_t B, int64_t C, int64_t Hs,
+                                         int64_t Ws, int64_t H, int64_t W, int kernel_size, int apply_softmax,
+                                         gfla_stream_t stream);
+int gfla_resample2d_bwd_ws_f32(const float *in1, const float *in2, const float *grad_out, float *grad_in1,
+                               float *grad_in2, void *workspace, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
+                               int64_t H, int64_t W, int kernel_size, int dilation, int trunc_compat,
+                               gfla_stream_t stream);
+
 /* ---- everything in ExtractorAttn that flows back into block_source(source, flow), in ONE pass ----------
  * block_source receives two gradient streams (base_function.py:805-809): through the first FC layer
  * (grad_unfold, in the unfold layout above; may be NULL) and through the attention-weighted aggregation
@@ -262,8 +282,12 @@ GFLA_DECL_FC_TAIL(f64, double)
  *   workspace: gfla_fc_workspace_bytes(..., which = 0) bytes, 256-byte aligned; forward fills it and backward
  *   reads it (packed inputs, convolved source map, hidden activations).  scratch: (..., which = 1) bytes.
  * backward: given grad_logits, overwrites whichever of grad_source, grad_target (B,C,H,W), grad_flow (B,2,H,W),
- *   grad_w0, grad_b0, grad_w1, grad_b1 is not NULL (no buffer needs zeroing).
+ *   grad_w0, grad_b0, grad_w1, grad_b1 is not NULL (no buffer needs zeroing).  flags: GFLA_FC_ACCUMULATE_SOURCE /
+ *   GFLA_FC_ACCUMULATE_FLOW add into grad_source / grad_flow instead (they then hold the gradient another path of the
+ *   same block already produced, e.g. the aggregation's).
  * gfla_fc_supported(C, H, W, k, mode): 1 if the shape is handled (the convolution's input tile must fit LDS).  */
+#define GFLA_FC_ACCUMULATE_SOURCE 1
+#define GFLA_FC_ACCUMULATE_FLOW 2
 int gfla_fc_supported(int64_t C, int64_t H, int64_t W, int kernel_size, int mode);
 int64_t gfla_fc_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, int mode,
                                 int which);
@@ -274,10 +298,10 @@ int gfla_fc_forward_f32(const float *source, const float *target, const float *f
 int gfla_fc_backward_f32(void *workspace, const float *flow, const float *w1, const float *grad_logits,
                          void *scratch, float *grad_source, float *grad_target, float *grad_flow, float *grad_w0,
                          float *grad_b0, float *grad_w1, float *grad_b1, int64_t B, int64_t C, int64_t H,
-                         int64_t W, int kernel_size, double slope, int mode, gfla_stream_t stream);
+                         int64_t W, int kernel_size, double slope, int mode, int flags, gfla_stream_t stream);
 /* Pieces of the above for the parity tests.  gfla_fc_geometry: out[0..12] = Hp, Wp, Ho, Wo, pad_top, pad_left, M,
  * Md, lead, Sx, Sz, Mg, Mdg of one half (is_source: the source half is extended by k-1, the target half padded by
- * k/2).  gfla_fc_conv_fwd: out (B, Mg, 128) = the convolved map of one half, row yo*Wp + xo.  gfla_fc_conv_bwd:
+ * k/2).  gfla_fc_conv_fwd: out (B, Mg, 128) = the convolved map of one half, row yo*Wo + xo.  gfla_fc_conv_bwd:
  * from z (B, Sz, 128), the gradient of that map in "Z layout" (row lead + yo*Wp + xo, zero elsewhere), grad_x
  * (B,C,H,W) and grad_w0 (128,2C,k,k; the other half zero); needs the workspace of gfla_fc_conv_fwd.
  * gfla_fc_tr_probe: raw result of ds_read_b64_tr_b16 for an LDS image and 64 per-lane byte offsets.            */
