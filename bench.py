@@ -20,9 +20,19 @@ The stock convolutions/normalisations of the rest of PoseGenerator are out of sc
 and the reference network code does not exist on the GPU box, so `value` is images/s THROUGH THE
 HOT PATH, not end-to-end generator throughput.  Inputs are resident in HBM before timing starts.
 
+The FC layers of ExtractorAttn (base_function.py:799-807) run on this library's own f32 MFMA kernels
+(csrc/fc_*.hip): no vendor GEMM / convolution is called anywhere in the step.  `--fc-mode 0` (default, the headline)
+is exact f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32); modes 3 / 2 (f16-split operands, f32 accumulation) are
+labelled experiments, reported under "variants".
+
 Rank 0 prints ONE JSON line (contract in the task statement) that additionally carries
-  "roofline":     the dominant gfx950 kernel of the step, algorithmic bytes / HIP-event duration
-  "kernels":      the same figure for every C-ABI entry point the step calls
+  "roofline":     the dominant gfx950 kernel of the step -- an MFMA kernel: algorithmic FLOPs / HIP-event duration
+                  against the 157.3 TFLOP/s f32 matrix-core peak
+  "kernels":      per C-ABI entry point of the step: HIP-event time, algorithmic bytes and FLOPs; and per internal
+                  kernel of the FC path (timed alone through gfla_fc_kernel_f32)
+  "oracle_check": forward + input gradients of sample 0 of the timed configuration against the CPU oracle,
+                  asserted before anything is timed (rank 0, N=1)
+  "variants":     the same step with the f16-split FC arithmetic (labelled experiments, not the headline)
   "cpu_baseline": the reference composition with the CPU oracle kernels on the host cores,
                   timed on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -41,6 +51,7 @@ import global_flow_local_attention_amd as gfla  # noqa: E402
 from global_flow_local_attention_amd import _lib, dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input matrix cores = the f32 vector rate (MI355X_MICROARCH.md)
 
 LAYERS = (  # (name, C, H, W, k) for a 256x176 input, layers=3, ngf=64
     ("attn3", 256, 32, 22, 3),
@@ -76,6 +87,7 @@ class HotPath:
             flow = smooth_flow(B, H, W, device, gen).requires_grad_()
             self.inputs.append((src, tgt, flow))
         self.upstream = None
+        self.reducer = None
         for (name, C, H, W) in VGG:
             feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_(vgg_grad)
             self.vgg.append(feat)
@@ -94,9 +106,11 @@ class HotPath:
             self.upstream = [torch.randn(o.shape, device=o.device, generator=gen) / o[0].numel() for o in outs]
         for t in [x for tup in self.inputs for x in tup] + self.vgg + self.params():
             t.grad = None
+        if allreduce and self.reducer is None:  # bucketed all-reduce launched from autograd hooks (overlaps backward)
+            self.reducer = gdist.GradBucketReducer(self.params())
         torch.autograd.backward(outs, self.upstream)
         if allreduce:
-            gdist.allreduce_grads(self.params())
+            self.reducer.finish()
         return outs
 
 
@@ -161,6 +175,32 @@ def algorithmic_bytes(name, a, esz=4):
         B, Hc, HW, KK = a[11:15]
         writes = 1 + (a[8] is not None) + (a[9] is not None)
         return esz * ((2 + writes) * B * Hc * HW + B * KK * HW)
+    if base == "gfla_local_attn_aggregate_bwd_ws":  # (s, f, a, go, gs, gf, gl, ws, B, C, Hs, Ws, H, W, k, sm)
+        return algorithmic_bytes("gfla_local_attn_aggregate_bwd_f32", a[:7] + a[8:], esz)
+    if base == "gfla_resample2d_bwd_ws":  # (in1, in2, go, g1, g2, ws, B, C, Hi, Wi, H, W, k, d, trunc)
+        return algorithmic_bytes("gfla_resample2d_bwd_f32", a[:5] + a[6:], esz)
+    if base == "gfla_fc_forward":  # (src, tgt, flow, w0, b0, w1, b1, ws, logits, B, C, H, W, k, slope, mode)
+        B, C, H, W, k = a[9:14]
+        return esz * (2 * B * C * H * W + 2 * B * H * W + B * k * k * H * W + 128 * (2 * C * k * k + k * k))
+    if base == "gfla_fc_backward":  # (ws, flow, w1, gl, scratch, gs, gt, gf, gw0, gb0, gw1, gb1, B, C, H, W, k, slope, mode, flags)
+        B, C, H, W, k = a[12:17]
+        n = 2 * B * C * H * W + 2 * B * H * W + B * k * k * H * W  # saved inputs + grad_logits
+        n += (B * C * H * W if a[5] is not None else 0) + (B * C * H * W if a[6] is not None else 0)
+        n += (2 * B * H * W if a[7] is not None else 0) + 2 * 128 * (2 * C * k * k + k * k)
+        return esz * n
+    return 0
+
+
+def algorithmic_flops(name, a):
+    """FLOPs of the reference's formulation of an FC-path call (base_function.py:799-807): conv0 is 2C*k*k -> 128 per
+    position, conv1 128 -> k*k; backward = data gradient + weight gradient of both.  0 for the memory-bound entries."""
+    base = name.rsplit("_", 1)[0]
+    if base == "gfla_fc_forward":
+        B, C, H, W, k = a[9:14]
+        return 2 * B * H * W * 128 * (2 * C * k * k + k * k)
+    if base == "gfla_fc_backward":
+        B, C, H, W, k = a[12:17]
+        return 2 * 2 * B * H * W * 128 * (2 * C * k * k + k * k)
     return 0
 
 
@@ -220,6 +260,19 @@ def pmc_traffic(entry, dims, ptrs=""):
     return total
 
 
+def pmc_traffic_kernel(kernel_label):
+    """HBM bytes per launch of one kernel from the committed PMC profile, matched by the kernel's template name."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    name = kernel_label.split("<")[0]
+    rows = [r for key, rs in table.items() if key.startswith(name) for r in rs]
+    if not rows:
+        return None
+    return max(r["traffic_bytes"] for r in rows)
+
+
 class KernelTimer:
     """Brackets every C-ABI call with HIP events on the stream the kernels are launched on."""
 
@@ -254,19 +307,112 @@ class KernelTimer:
             ptrs = "".join("0" if x is None else "1" for x in args if not isinstance(x, int))
             key = (name, ptrs) + tuple(x for x in args if isinstance(x, int))
             ent = agg.setdefault(key, {"name": name, "ptrs": ptrs, "calls": 0, "ms": 0.0,
-                                       "bytes": algorithmic_bytes(name, args)})
+                                       "bytes": algorithmic_bytes(name, args), "flops": algorithmic_flops(name, args)})
             ent["calls"] += 1
             ent["ms"] += e0.elapsed_time(e1)
         rows = []
         for key, ent in agg.items():
             avg_ms = ent["ms"] / ent["calls"]
             gbs = ent["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            rows.append({"entry": ent["name"], "dims": list(key[2:]), "ptrs": ent["ptrs"], "calls": ent["calls"],
-                         "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ent["ms"], 3),
-                         "alg_MB": round(ent["bytes"] / 1e6, 3), "GBps": round(gbs, 1),
-                         "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+            row = {"entry": ent["name"], "dims": list(key[2:]), "ptrs": ent["ptrs"], "calls": ent["calls"],
+                   "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ent["ms"], 3),
+                   "alg_MB": round(ent["bytes"] / 1e6, 3), "GBps": round(gbs, 1),
+                   "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            if ent["flops"]:
+                tf = ent["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+                row.update({"alg_GFLOP": round(ent["flops"] / 1e9, 2), "TFLOPs": round(tf, 1),
+                            "frac_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+            rows.append(row)
         rows.sort(key=lambda r: -r["total_ms"])
         return rows
+
+
+def fc_kernel_probes(hp, iters=10):
+    """Each internal kernel of the FC path timed alone (HIP events around gfla_fc_kernel_f32 on the launch stream), on
+    the state one forward + backward of the bench's own inputs leaves behind.  FLOPs: the reference formulation's
+    (2 * B*H*W * C*k*k * 128 per half and pass) -- the kernels multiply somewhat more (the source half's map is
+    (H+k-1) x (W+k-1), the data gradient runs on the padded domain), which is NOT counted as achieved work."""
+    from global_flow_local_attention_amd import fc_mfma
+    names = ("conv fwd source", "conv fwd target", "data-grad source", "data-grad target", "weight-grad source",
+             "weight-grad target")
+    rows = []
+    for mod, (src, tgt, flow) in zip(hp.attn, hp.inputs):
+        mode = getattr(mod, "fc_mode", None)
+        mode = fc_mfma.DEFAULT_MODE if mode is None else int(mode)
+        B, C, H, W = src.shape
+        k = mod.kernel_size
+        if getattr(mod, "fc_impl", "mfma") != "mfma" or not fc_mfma.supported(C, H, W, k, mode):
+            continue
+        fc = mod.fully_connect_layer
+        with torch.no_grad():
+            s, t, f = src.detach().contiguous(), tgt.detach().contiguous(), flow.detach().contiguous()
+            w0, w1 = fc[0].weight.detach().contiguous(), fc[2].weight.detach().reshape(k * k, 128).contiguous()
+            ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=s.device)
+            sc = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=s.device)
+            logits = s.new_empty(B, k * k, H, W)
+            gl = torch.randn_like(logits) * 1e-3
+            gs, gt, gf = torch.empty_like(s), torch.empty_like(t), torch.empty_like(f)
+            gw0 = torch.empty_like(w0)
+            _lib.call("gfla_fc_forward_f32", s, _lib.ptr(s), _lib.ptr(t), _lib.ptr(f), _lib.ptr(w0), _lib.ptr(fc[0].bias),
+                      _lib.ptr(w1), _lib.ptr(fc[2].bias), _lib.ptr(ws), _lib.ptr(logits), B, C, H, W, k, 0.1, mode)
+            _lib.call("gfla_fc_backward_f32", s, _lib.ptr(ws), _lib.ptr(f), _lib.ptr(w1), _lib.ptr(gl), _lib.ptr(sc),
+                      _lib.ptr(gs), _lib.ptr(gt), _lib.ptr(gf), _lib.ptr(gw0), None, None, None, B, C, H, W, k, 0.1, mode, 0)
+            stream = torch.cuda.current_stream(s.device)
+            flops = 2.0 * B * H * W * C * k * k * 128
+            for which, nm in enumerate(names):
+                for _ in range(2):
+                    _lib.call("gfla_fc_kernel_f32", s, which, _lib.ptr(ws), _lib.ptr(sc), B, C, H, W, k, mode)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(iters):
+                    _lib.call("gfla_fc_kernel_f32", s, which, _lib.ptr(ws), _lib.ptr(sc), B, C, H, W, k, mode)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / iters * 1e3
+                tf = flops / (us * 1e-6) / 1e12
+                kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
+                rows.append({"kernel": "%s<mode %d, k %d>: %s" % (kern, mode, k, nm), "dims": [B, C, H, W, k],
+                             "avg_us": round(us, 1), "alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(tf, 1),
+                             "frac_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+    return rows
+
+
+def oracle_check(hp, resample, tol=1e-4):
+    """Sample 0 of the timed configuration through the reference composition with the CPU oracle kernels (the checker
+    only): forward outputs and the gradients of source, target, flow and the warped VGG features of that sample
+    (every op on the path is per-sample, so they do not depend on the rest of the batch).  Raises on a mismatch."""
+    from oracle import cpu_modules, cpu_oracle
+    cpu_oracle.build()
+    outs = hp.step(resample, allreduce=False)
+    report = {}
+
+    def cmp(name, got, want):
+        want = want.detach().double()
+        err = (got.detach().double().cpu() - want).abs().max().item() / max(1e-30, want.abs().max().item())
+        report[name] = float("%.2e" % err)
+        if not err <= tol:
+            raise SystemExit("bench.py: %s of the timed configuration differs from the CPU oracle: rel err %.3e" % (name, err))
+
+    rs = cpu_modules.Resample2dCPU(4, 1, 2)
+    for i, (mod, (src, tgt, flow)) in enumerate(zip(hp.attn, hp.inputs)):
+        name, C, H, W, k = LAYERS[i]
+        ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+        ref.load_state_dict({kk: v.detach().cpu() for kk, v in mod.state_dict().items()})
+        a = [x[:1].detach().cpu().clone().requires_grad_() for x in (src, tgt, flow)]
+        want = ref(*a)
+        want.backward(hp.upstream[i][:1].cpu())
+        cmp(name + " out", outs[i][:1], want)
+        # the layer's flow also warps the VGG features of the same resolution (HotPath.step): its gradient is the sum
+        feat, j = hp.vgg[i], len(hp.attn) + i
+        f1 = feat[:1].detach().cpu().clone().requires_grad_(feat.requires_grad)
+        warped = rs(f1, a[2])
+        warped.backward(hp.upstream[j][:1].cpu())
+        cmp(VGG[i][0] + " warp", outs[j][:1], warped)
+        for nm, x, w in zip(("grad source", "grad target", "grad flow (attention + warp)"), (src, tgt, flow), a):
+            cmp(name + " " + nm, x.grad[:1], w.grad)
+        if feat.requires_grad:
+            cmp(VGG[i][0] + " grad input1", feat.grad[:1], f1.grad)
+    return {"tolerance": tol, "max_rel_err": report}
 
 
 def cpu_baseline(budget_s=20.0):
@@ -296,72 +442,66 @@ def cpu_baseline(budget_s=20.0):
                       "kernels with OpenMP + torch CPU convolutions), %.1f s" % (n, b, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-vgg-grad", action="store_true",
-                    help="treat the VGG features fed to Resample2d as constants (what the reference's training step "
-                         "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
-    ap.add_argument("--no-gemm-tuning", action="store_true",
-                    help="leave the FC-layer GEMMs to hipBLASLt's default heuristics (no TunableOp)")
-    ap.add_argument("--fc-impl", choices=("mfma", "library"), default="mfma",
-                    help="FC layers of ExtractorAttn: this library's MFMA kernels (default) or round 1's vendor GEMM/conv path")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
-                    help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
-                         "f16 terms per operand with f32 accumulation (labelled experiments)")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
-    # GFLA_DIST_BACKEND / GFLA_DEVICE: test hooks (e.g. two gloo ranks sharing the one GPU of a test box)
-    rank, world, local = gdist.init_from_env(os.environ.get("GFLA_DIST_BACKEND"))
-    local = int(os.environ.get("GFLA_DEVICE", local))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True  # as the reference does (options/base_options.py:83)
-
-    # FC layers = library GEMMs; let torch pick the fastest rocBLAS/hipBLASLt solution per shape.  The tuning
-    # happens inside the priming step below (a few seconds per new shape), never in the timed region.
-    if not args.no_gemm_tuning:  # same idea for MIOpen: recorded find results / kernel parameters for the FC convs
-        gfla.seed_conv_db(os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_miopen_db_rank%d" % rank))
-    gemm_tuning = (not args.no_gemm_tuning) and gfla.enable_gemm_tuning(
-        os.path.join(os.environ.get("GFLA_TUNE_DIR", "/tmp"), "gfla_tunableop_rank%d.csv" % rank))
-    hp = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
-                 fc_mode=args.fc_mode)
-    resample = gfla.Resample2d(4, 1, 2)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    hp.step(resample)  # priming step: library autotuning (MIOpen find, hipBLASLt) and lazy init, never timed
-    for _ in range(args.warmup):
-        hp.step(resample)
+def timed_steps(step, steps, warmup, barrier, world, device):
+    """The contract's timing: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks."""
+    for _ in range(warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.step(resample)
+    for _ in range(steps):
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    return elapsed
 
-    # instrumented pass: the same K steps with every C-ABI call bracketed by HIP events
-    with KernelTimer() as kt:
-        for _ in range(args.steps):
-            hp.step(resample)
-    rows = kt.summary()
-    dom = rows[0]
+
+def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
+    """Everything after process-group / device setup; `make_hotpath(fc_mode)` builds the per-rank workload.  Split from
+    main() so that the N>1 control flow can be exercised on CPU under gloo with a stand-in workload
+    (tests/test_dist_cpu.py): a typo must not burn the one multi-GPU hardware run."""
+    hp = make_hotpath(args.fc_mode)
+    resample = make_resample()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    check = None
+    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline:
+        check = oracle_check(hp, resample)  # asserts; before anything is timed
+    hp.step(resample)  # priming step: lazy initialisation, never timed
+    elapsed = timed_steps(lambda: hp.step(resample), args.steps, args.warmup, barrier, world, device)
+
+    rows, probes = [], []
+    if on_gpu:
+        # instrumented pass: the same K steps with every C-ABI call bracketed by HIP events
+        with KernelTimer() as kt:
+            for _ in range(args.steps):
+                hp.step(resample)
+        rows = kt.summary()
+        if args.fc_impl == "mfma":
+            probes = fc_kernel_probes(hp)
+
+    variants = {}
+    if on_gpu and args.fc_impl == "mfma" and not args.no_variants:
+        for mode, label in ((3, "fc_mode3_f16x3_split"), (2, "fc_mode2_f16x2_split")):
+            if mode == args.fc_mode:
+                continue
+            hv = make_hotpath(mode)
+            hv.step(resample)
+            n = max(3, args.steps // 2)
+            ev = timed_steps(lambda: hv.step(resample), n, 2, barrier, world, device)
+            variants[label] = {"value": round(args.batch * world * n / ev, 2), "unit": "images/s",
+                               "ms_per_step": round(ev / n * 1e3, 3),
+                               "note": "labelled experiment, not the headline: FC operands split into %d f16 terms, f32 "
+                                       "accumulation in the MFMA; the parity tests hold it to the same bars as exact f32" % mode}
+            del hv
 
     line = {
         "metric": "images/sec (fwd+bwd) PoseGenerator 256x176 attn_layer=2,3 -- feature-warping hot path",
@@ -372,28 +512,92 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
-                               "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. FC convs, "
+                               "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. both FC layers, "
                                "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)"
                                + ("" if not args.no_vgg_grad else " with constant VGG features (no d/d input1)"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "parallelism": "dp%d (batch shards, flat-bucket all-reduce of ExtractorAttn grads)" % world,
-                   "fc_gemms": "torch TunableOp (rocBLAS/hipBLASLt solution per shape; shipped results for the FC "
-                               "shapes, anything else tuned in the priming step); MIOpen user db seeded with the recorded "
-                               "find results for the FC convolutions"
-                               if gemm_tuning else "hipBLASLt default heuristics"},
-        "roofline": {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"],
-                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"],
-                     "avg_us": dom["avg_us"], "alg_MB_per_launch": dom["alg_MB"],
-                     "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"]),
-                     "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
-                                       "of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
-                     "timing": "HIP events around each C-ABI call on the launch stream, instrumented pass of the same %d steps" % args.steps},
+                   "parallelism": "dp%d (batch shards; ExtractorAttn gradients all-reduced in one flat bucket launched "
+                                  "from autograd hooks, overlapping backward)" % world,
+                   "fc_layers": ("this library's MFMA kernels, arithmetic mode %d (%s); no vendor GEMM / convolution in the step"
+                                 % (args.fc_mode, "exact f32" if args.fc_mode == 0 else "f16-split operands, f32 accumulate"))
+                   if args.fc_impl == "mfma" else "round 1's vendor-library path (torch.mm / F.conv2d)"},
         "kernels": rows,
+        "fc_kernels": probes,
     }
+    if probes:
+        # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
+        # with the longest launch
+        dom = max(probes, key=lambda r: r["avg_us"])
+        line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "dims": dom["dims"],
+                            "achieved": dom["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
+                            "alg_GFLOP_per_launch": dom["alg_GFLOP"],
+                            "traffic": pmc_traffic_kernel(dom["kernel"]),
+                            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                                              "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
+                            "flops": "reference formulation (2*B*H*W*C*k*k*128 per half and pass); work the kernel adds on "
+                                     "top (extended / padded domains) is not counted",
+                            "timing": "HIP events around 10 back-to-back launches of the kernel alone "
+                                      "(gfla_fc_kernel_f32) on the launch stream"}
+    elif rows:
+        dom = rows[0]
+        line["roofline"] = {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["GBps"],
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"], "avg_us": dom["avg_us"],
+                            "alg_MB_per_launch": dom["alg_MB"], "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"])}
+    if variants:
+        line["variants"] = variants
+    if check is not None:
+        line["oracle_check"] = check
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and on_gpu and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(line), flush=True)
+    return line
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle check + baseline)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the labelled f16-split variants")
+    ap.add_argument("--no-vgg-grad", action="store_true",
+                    help="treat the VGG features fed to Resample2d as constants (what the reference's training step "
+                         "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
+    ap.add_argument("--fc-impl", choices=("mfma", "library"), default="mfma",
+                    help="FC layers of ExtractorAttn: this library's MFMA kernels (default) or round 1's vendor GEMM/conv path")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
+                    help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
+                         "f16 terms per operand with f32 accumulation (labelled experiments)")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
+    # bind the device BEFORE anything touches the GPU or the process group (RCCL communicators are per device)
+    local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    # GFLA_DIST_BACKEND / GFLA_DEVICE: test hooks (e.g. two gloo ranks sharing the one GPU of a test box)
+    rank, world, _ = gdist.init_from_env(os.environ.get("GFLA_DIST_BACKEND"), device=local)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    device = torch.device("cuda", local)
+    if args.fc_impl == "library":  # round 1's path: let the vendor libraries pick / load their tuned kernels
+        torch.backends.cudnn.benchmark = True
+        tune_dir = os.environ.get("GFLA_TUNE_DIR", "/tmp")
+        gfla.seed_conv_db(os.path.join(tune_dir, "gfla_miopen_db_rank%d" % rank))
+        gfla.enable_gemm_tuning(os.path.join(tune_dir, "gfla_tunableop_rank%d.csv" % rank))
+
+    def make_hotpath(fc_mode):
+        return HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
+                       fc_mode=fc_mode)
+
+    run(args, make_hotpath, lambda: gfla.Resample2d(4, 1, 2), rank, world, device)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -63,9 +63,16 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
     const T *__restrict__ attn, const T *__restrict__ gout2, T *__restrict__ gsrc, T *__restrict__ gflow,
     int C, int Hs, int Ws, int Hf, int Wf, int G, int ngroups, int split, int per, int margin, int64_t u_cs,
-    int64_t u_bs) {
+    int64_t u_bs, const unsigned *__restrict__ skip_stat, unsigned skip_limit) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  // adaptive dispatch (patch_mfma.hip): the matrix-core path took this launch when its statistic is within the limit
+  if (skip_stat) {  // the statistic is a sum over 32 counters (patch_mfma.hip: kPmStatSlots)
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tot += skip_stat[i];
+    if (tot <= skip_limit) return;
+  }
   int bid = blockIdx.x;
   const int sp = bid % split;
   bid /= split;
@@ -292,7 +299,7 @@ template <typename T, int K>
 static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gout, const T *attn, T *gsrc,
                              T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                              hipStream_t stream, bool *done, int64_t u_cs = 0, int64_t u_bs = 0,
-                             const T *gout2 = nullptr) {
+                             const T *gout2 = nullptr, const unsigned *skip_stat = nullptr, unsigned skip_limit = 0) {
   using A = typename Num<T>::acc;
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
@@ -307,11 +314,11 @@ static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gou
   if (AT == kGoutTensor && g.margin >= 0)                                                            \
     launch_lds(be_bwd_lds_kernel<T, K, S, F, kGoutTensor, true>, grid, blk, g.lds_bytes, stream,             \
         src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups,     \
-        g.split, g.per, g.margin, u_cs, u_bs);                                                       \
+        g.split, g.per, g.margin, u_cs, u_bs, skip_stat, skip_limit);                                \
   else                                                                                               \
     launch_lds(be_bwd_lds_kernel<T, K, S, F, AT, false>, grid, blk, g.lds_bytes, stream,                     \
       src, flow, gout, attn, gout2, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split,   \
-      g.per, g.margin, u_cs, u_bs)
+      g.per, g.margin, u_cs, u_bs, skip_stat, skip_limit)
   if (mode == kGoutUnfoldAttn) {
     if (gsrc && gflow) GFLA_BE_BWD_LAUNCH(true, true, kGoutUnfoldAttn);
     else if (gsrc) GFLA_BE_BWD_LAUNCH(true, false, kGoutUnfoldAttn);

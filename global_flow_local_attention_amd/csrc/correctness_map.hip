@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void correctness_map_bwd_kernel(const float *_
   if (!GX && !GT) return;
   const float nxc = fmaxf(nx, eps_cos), ntc = fmaxf(nt, eps_cos);
   const float cross = gcos / (nxc * ntc);
-  const float selfx = nx > 0.f ? gcos * cosv / (nx * nxc) : 0.f;
-  const float selft = nt > 0.f ? gcos * cosv / (nt * ntc) : 0.f;
+  // d/dx of max(|x|, eps) is x/|x| above eps and 0 below it (torch's clamp_min): no self term for a sub-eps norm
+  const float selfx = nx > eps_cos ? gcos * cosv / (nx * nxc) : 0.f;
+  const float selft = nt > eps_cos ? gcos * cosv / (nt * ntc) : 0.f;
   const int64_t base = b * C * (int64_t)N + n;
 #pragma unroll 4
   for (int c = slice; c < C; c += kSlices) {

@@ -319,6 +319,44 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
   return GFLA_OK;
 }
 
+/* ONE internal kernel of the path, on the state a forward + backward of the same shape left in workspace / scratch:
+ * per-kernel timing for bench.py and the profiles (results land in scratch areas the next real call overwrites).
+ * which: 0 / 1 convolution forward source / target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient. */
+int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C_, int64_t H_, int64_t W_,
+                       int kernel_size, int mode, gfla_stream_t stream_) {
+  if (!workspace || !scratch) return GFLA_ERR_NULL_POINTER;
+  if (which < 0 || which > 5) return GFLA_ERR_BAD_SHAPE;
+  const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  if (B == 0) return GFLA_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  const bool source = (which & 1) == 0;
+  const FcHalf &g = source ? L.hs : L.ht;
+  unsigned char *ws = static_cast<unsigned char *>(workspace), *sc = static_cast<unsigned char *>(scratch);
+  uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  const uint32_t *a_x = mode ? amax + (source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;
+  const uint32_t *a_z = mode ? amax + (source ? kAmaxZs : kAmaxZt) : nullptr;
+  const int nch_h = kFcHidden / kFcChunk;
+  const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
+  const PackedDesc Z = mode ? fc_desc_packed(sc + (source ? L.zs_pk : L.zt_pk), B, nch_h, g.Sz, mode)
+                            : fc_desc_nhwc(reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz, kFcHidden);
+  if (which < 2) {
+    const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
+    return fc_conv(X, ws + (source ? L.wf_s : L.wf_t), wsplit_f, reinterpret_cast<float *>(ws + (source ? L.gs : L.gt)),
+                   g.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, g.Mv, g.Wo, g.Wp, k, mode, a_x, a_w, stream);
+  }
+  if (which < 4) {
+    const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
+    return fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)),
+                   g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp, g.Wp, k, mode, a_z, a_w, stream);
+  }
+  if (mode == 0)
+    return fc_wgrad_f32(X, Z, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
+  return fc_wgrad(X, Z, g.lead, reinterpret_cast<float *>(sc + (source ? L.dw_s : L.dw_t)), L.cpad, B, g.M, g.Wp, k, mode,
+                  stream);
+}
+
 int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out, gfla_stream_t stream) {
   if (!image || !offsets || !out) return GFLA_ERR_NULL_POINTER;
   return fc_tr_probe(image, n_halves, offsets, out, static_cast<hipStream_t>(stream));

@@ -163,7 +163,8 @@ inline void launch_lds(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned
 template <typename T, typename A>
 __device__ __forceinline__ void stage_planes(const T *__restrict__ g, A *lds, int n) {
   if constexpr (sizeof(T) == 4 && sizeof(A) == 4) {
-    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    // both sides 16-byte aligned (the LDS side is not when a plane has an odd number of elements and is not the first)
+    if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(lds)) & 15) == 0) {
       const int n4 = n >> 2;
       const float4 *g4 = reinterpret_cast<const float4 *>(g);
       float4 *l4 = reinterpret_cast<float4 *>(lds);

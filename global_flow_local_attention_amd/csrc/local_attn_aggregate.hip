@@ -656,9 +656,21 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
   if constexpr (std::is_same<T, float>::value) {
     // d/d source as a block-sparse product on the matrix cores (patch_mfma.hip); d/d flow then comes out of the
     // d/d a_ij pass, which holds the patch sums it needs
-    if (workspace && tuning(3) != 1 && (planes_fit || (!gflow && !glogits))) {
-      st = gsrc ? agg_source_bwd_mfma(flow, attn, gout, gsrc, workspace, B, C, Hs, Ws, H, W, k, 1, stream) : GFLA_OK;
+    if (gsrc && workspace && tuning(3) != 1 && (planes_fit || (!gflow && !glogits))) {
+      // the LDS-atomic kernel is the device-side fallback for flows that spread the patches too far
+      const bool lds_fallback = Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) <= kLdsBudget;
+      const unsigned *skip_stat = nullptr;
+      unsigned skip_limit = 0;
+      st = agg_source_bwd_mfma(flow, attn, gout, gsrc, workspace, B, C, Hs, Ws, H, W, k, 1, lds_fallback ? 1 : 0, &skip_stat,
+                               &skip_limit, stream);
       if (st == GFLA_OK) {
+        if (lds_fallback && skip_limit != 0xffffffffu) {
+          bool done = false;
+          GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutAttn, src, flow, gout, attn, gsrc, (T *)nullptr, B, C, Hs, Ws, H, W,
+                                                        stream, &done, 0, 0, (const T *)nullptr, skip_stat, skip_limit));
+          if (st != GFLA_OK) return st;
+          if (!done) return GFLA_ERR_UNSUPPORTED;
+        }
         if (gflow || glogits) st = launch_agg_ga<T>(src, flow, attn, gout, glogits, gflow, B, C, Hs, Ws, H, W, k, sm, stream);
         return st;
       }

@@ -6,12 +6,15 @@
 
 namespace gfla {
 
+// adaptive != 0: the kernels decide ON THE DEVICE (from how far the flow spreads the patches) whether they run;
+// *skip_stat / *skip_limit receive the predicate the caller's LDS-atomic kernel has to be launched with right behind
+// (it returns at once when *skip_stat <= skip_limit, i.e. when the matrix-core path did the work).
 int agg_source_bwd_mfma(const float *flow, const float *attn, const float *gout, float *gsrc, void *workspace,
                         int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int accumulate,
-                        hipStream_t stream);
+                        int adaptive, const unsigned **skip_stat, unsigned *skip_limit, hipStream_t stream);
 int rs_input1_bwd_mfma(const float *in2, const float *gout, float *gin1, void *workspace, int64_t B, int64_t C,
-                       int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int trunc, int accumulate,
-                       hipStream_t stream);
+                       int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int trunc, int accumulate, int adaptive,
+                       const unsigned **skip_stat, unsigned *skip_limit, hipStream_t stream);
 int64_t pm_workspace_bytes(int64_t B, int64_t H, int64_t W, int entries);
 
 }  // namespace gfla

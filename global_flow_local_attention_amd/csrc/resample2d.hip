@@ -254,10 +254,18 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
                                                             const T *__restrict__ gout, T *__restrict__ outp,
                                                             int C, int Hi, int Wi, int H, int W, int dil,
                                                             int trunc, int G, int ngroups, int split, int per,
-                                                            int margin) {
+                                                            int margin, const unsigned *__restrict__ skip_stat,
+                                                            unsigned skip_limit) {
   using A = typename Num<T>::acc;
   using PT = typename std::conditional<MODE == 1, lds_acc_t, A>::type;  // scatter planes are double
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  // adaptive dispatch (patch_mfma.hip): the matrix-core path took this launch when its statistic is within the limit
+  if (skip_stat) {  // the statistic is a sum over 32 counters (patch_mfma.hip: kPmStatSlots)
+    unsigned tot = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) tot += skip_stat[i];
+    if (tot <= skip_limit) return;
+  }
   PT *planes = reinterpret_cast<PT *>(gfla_smem);
   int bid = blockIdx.x;
   const int sp = bid % split;
@@ -372,8 +380,8 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
     if (pg.G > 0) {
       const int64_t blocks = B * pg.ngroups * pg.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg.margin < 0) launch_lds(rs_lds_kernel<T, KH, 0, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin);
-                                else launch_lds(rs_lds_kernel<T, KH, 0, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg.margin < 0) launch_lds(rs_lds_kernel<T, KH, 0, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin, nullptr, 0u);
+                                else launch_lds(rs_lds_kernel<T, KH, 0, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg.lds_bytes, stream, in1, in2, nullptr, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, 0, pg.G, pg.ngroups, pg.split, pg.per, pg.margin, nullptr, 0u));
       return launch_status();
     }
   }
@@ -386,7 +394,8 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
 template <typename T>
 static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T *gin2, int64_t B,
                           int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int dil,
-                          int trunc, gfla_stream_t stream_) {
+                          int trunc, gfla_stream_t stream_, const unsigned *skip_stat = nullptr,
+                          unsigned skip_limit = 0) {
   int st = check<T>(in1, in2, B, C, Hi, Wi, H, W, k, dil);
   if (st != GFLA_OK) return st;
   if (!gout) return GFLA_ERR_NULL_POINTER;
@@ -398,16 +407,16 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) launch_lds(rs_lds_kernel<T, KH, 1, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin);
-                                else launch_lds(rs_lds_kernel<T, KH, 1, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) launch_lds(rs_lds_kernel<T, KH, 1, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit);
+                                else launch_lds(rs_lds_kernel<T, KH, 1, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit));
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
     if (gin2) {
       const int64_t blocks = B * pg2.ngroups * pg2.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) launch_lds(rs_lds_kernel<T, KH, 2, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin);
-                                else launch_lds(rs_lds_kernel<T, KH, 2, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin));
+      GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) launch_lds(rs_lds_kernel<T, KH, 2, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin, nullptr, 0u);
+                                else launch_lds(rs_lds_kernel<T, KH, 2, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin, nullptr, 0u));
       st = launch_status();
     }
     return st;
@@ -459,16 +468,27 @@ int gfla_resample2d_bwd_f32(const float *a, const float *b, const float *go, flo
 int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, float *g1, float *g2, void *workspace,
                                int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int d,
                                int trunc, gfla_stream_t st) {
+  const unsigned *skip_stat = nullptr;
+  unsigned skip_limit = 0;
   if (g1 && workspace && d == 1 && gfla::tuning(6) != 1) {
     int rc = gfla::check<float>(a, b, B, C, Hi, Wi, H, W, k, d);
     if (rc != GFLA_OK) return rc;
     if (!go) return GFLA_ERR_NULL_POINTER;
-    rc = gfla::rs_input1_bwd_mfma(b, go, g1, workspace, B, C, Hi, Wi, H, W, k, trunc, 1, static_cast<hipStream_t>(st));
-    if (rc == GFLA_OK) g1 = nullptr;  // done; the rest of the call only has d/d input2 left
-    else if (rc != GFLA_ERR_UNSUPPORTED) return rc;
+    // adaptive only where the LDS-atomic kernel exists as the device-side fallback
+    const bool lds_fallback = gfla::lds_geometry(Hi, Wi, sizeof(gfla::lds_acc_t), B, C, H, W, (k - 1) * d + 1).G > 0 &&
+                              gfla::lds_geometry(Hi, Wi, sizeof(float), B, C, H, W, (k - 1) * d + 1).G > 0;
+    rc = gfla::rs_input1_bwd_mfma(b, go, g1, workspace, B, C, Hi, Wi, H, W, k, trunc, 1, lds_fallback ? 1 : 0, &skip_stat,
+                                  &skip_limit, static_cast<hipStream_t>(st));
+    if (rc == GFLA_OK) {
+      if (!lds_fallback || skip_limit == 0xffffffffu) g1 = nullptr, skip_stat = nullptr;  // done unconditionally
+    } else if (rc != GFLA_ERR_UNSUPPORTED) {
+      return rc;
+    } else {
+      skip_stat = nullptr;
+    }
     if (!g1 && !g2) return GFLA_OK;
   }
-  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st);
+  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st, skip_stat, skip_limit);
 }
 int gfla_resample2d_bwd_f64(const double *a, const double *b, const double *go, double *g1, double *g2,
                             int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,

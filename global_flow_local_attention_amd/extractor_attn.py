@@ -29,20 +29,28 @@ _FUSED_MAX_K = 5  # kernel sizes the fused tail is instantiated for
 
 
 class _SourceGradLink(object):
-    """Joins the two backward nodes that scatter into (source, flow) inside one ExtractorAttn call.
-    The aggregation's backward runs first (its grad_logits is what eventually produces the FC
-    operand's gradient), so it parks (attn, grad_out) here instead of scattering; the unfold node's
-    backward then scatters both gradient streams in one kernel pass."""
+    """Joins the two backward nodes that scatter into (source, flow) inside one ExtractorAttn call (library FC path).
+    The aggregation's backward runs first (its grad_logits is what eventually produces the FC operand's gradient), so
+    it parks (attn, grad_out) here instead of scattering; the unfold node's backward then scatters both gradient
+    streams in one kernel pass.  If the engine never runs the unfold node in that pass (torch.autograd.grad with
+    `inputs=` that prune it), the parked contribution would be lost: a callback queued on the autograd engine checks
+    at the end of the backward pass and raises."""
 
     def __init__(self):
         self.pending = None       # (attn, grad_out) parked by the aggregation's backward
         self.unfold_alive = False  # an unfold node that will consume `pending` is in the graph
 
-    def __del__(self):
-        if self.pending is not None:  # never consumed: a gradient contribution would be lost
-            import warnings
-            warnings.warn("ExtractorAttn: parked aggregation gradient was never scattered "
-                          "(backward through the FC operand did not run)")
+    def park(self, attn, grad_out):
+        self.pending = (attn, grad_out)
+        torch.autograd.Variable._execution_engine.queue_callback(self._check_consumed)
+
+    def _check_consumed(self):
+        if self.pending is not None:
+            self.pending = None
+            raise RuntimeError("ExtractorAttn (fuse_source_backward): the aggregation's (source, flow) gradient was parked "
+                               "for the FC operand's backward node, which did not run in this backward pass -- the "
+                               "gradient would be incomplete.  Set module.fuse_source_backward = False for backward "
+                               "passes that prune part of the block (torch.autograd.grad(..., inputs=...)).")
 
 
 class LocalAttnAggregateFunction(Function):
@@ -84,7 +92,7 @@ class LocalAttnAggregateFunction(Function):
         link = ctx.link
         if link is not None and link.unfold_alive and nl and (ns or nf):
             # park the (source, flow) contribution; the unfold node scatters it together with its own
-            link.pending = (attn, grad_out)
+            link.park(attn, grad_out)
             ns = nf = False
         gs = torch.zeros_like(source) if ns else None
         gf = torch.zeros_like(flow_field) if nf else None
@@ -325,14 +333,16 @@ class FusedAttnFunction(Function):
         def out(shape, wanted):
             return torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
 
-        agg = "gfla_local_attn_aggregate_bwd_ws_f32"
-        table = _lib.scatter_workspace(source, B, H, W, (k + 1) ** 2)
-        g_logits = torch.zeros_like(attn)  # accumulated with atomics by the kernel
-        g_flow = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev) if need[2] else None
-        # d/d logits and, out of the same patch sums, the aggregation's d/d flow
-        _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out), None, _lib.ptr(g_flow),
-                  _lib.ptr(g_logits), _lib.ptr(table), B, C, H, W, H, W, k, 1)
-        g_source, g_target = out((B, C, H, W), need[0]), out((B, C, H, W), need[1])
+        # the aggregation's own gradients first (d/d logits feeds the FC backward; source / flow are accumulated into by
+        # its kernels, so they start at zero), then the FC layers' backward ADDS its source / flow gradients on top
+        zeros = lambda shape, wanted: torch.zeros(shape, dtype=torch.float32, device=dev) if wanted else None
+        g_source, g_flow = zeros((B, C, H, W), need[0]), zeros((B, 2, H, W), need[2])
+        g_logits = torch.zeros_like(attn)
+        table = _lib.scatter_workspace(source, B, H, W, (k + 1) ** 2) if need[0] else None
+        _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn),
+                  _lib.ptr(g_out), _lib.ptr(g_source), _lib.ptr(g_flow), _lib.ptr(g_logits), _lib.ptr(table),
+                  B, C, H, W, H, W, k, 1)
+        g_target = out((B, C, H, W), need[1])
         g_w0 = out(w0_shape, need[3])
         g_b0 = out((128,), need[4] and has_b0)
         g_w1 = out(w1_shape, need[5])
@@ -341,10 +351,7 @@ class FusedAttnFunction(Function):
         _lib.call("gfla_fc_backward_f32", flow, _lib.ptr(ws), _lib.ptr(flow), _lib.ptr(w1c), _lib.ptr(g_logits),
                   _lib.ptr(scratch), _lib.ptr(g_source), _lib.ptr(g_target), _lib.ptr(g_flow), _lib.ptr(g_w0),
                   _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode,
-                  2 if need[2] else 0)  # GFLA_FC_ACCUMULATE_FLOW
-        if need[0]:  # += the aggregation's own source gradient (matrix-core scatter)
-            _lib.call(agg, source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(g_out),
-                      _lib.ptr(g_source), None, None, _lib.ptr(table), B, C, H, W, H, W, k, 1)
+                  3)  # GFLA_FC_ACCUMULATE_SOURCE | GFLA_FC_ACCUMULATE_FLOW
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
 
 
@@ -423,8 +430,18 @@ def _forward(self, source, target, flow_field):
 
 
 def _hook_attn_param(self, source, target, flow_field):
-    fn = _fused_attention if _use_fused(self) else _unfused_attention
-    return fn(self, source, target, flow_field)
+    """(attn_param_, result) as base_function.py:812-818.  In the fused evaluation with softmax=True attn_param_ (the
+    post-softmax attention map) is a by-product of the aggregation kernel and NOT differentiable: a loss placed on it
+    gets no gradient.  Use module.fused = False for that (the reference's op-by-op composition)."""
+    if _use_fused(self):
+        attn, result = _fused_attention(self, source, target, flow_field)
+        if torch.is_grad_enabled() and not attn.requires_grad and result.requires_grad and not getattr(self, "_attn_warned", False):
+            import warnings
+            warnings.warn("ExtractorAttn.hook_attn_param: the returned attention map is not differentiable in the fused "
+                          "evaluation; set module.fused = False if a loss is placed on it")
+            self._attn_warned = True
+        return attn, result
+    return _unfused_attention(self, source, target, flow_field)
 
 
 class ExtractorAttn(nn.Module):

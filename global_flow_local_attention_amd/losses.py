@@ -8,17 +8,14 @@ weights 1/0), and avg_pool of the product is u.(M u)/k^2.  So the whole chain is
 
         loss_axis = mean over (b, valid positions) of  u^T M u ,      M = K^T K  (k^2 x k^2, fixed)
 
-one unfold + one small GEMM + one reduction, with no custom-op launches at all.  The op-by-op
-composition through BlockExtractor / LocalAttnReshape stays available (`collapsed=False`) and is
-what the tests compare against.
+one unfold + one small GEMM + one reduction, with no custom-op launches at all.  The reference's op-by-op
+composition lives in oracle/cpu_modules.py (AffineRegularizationLossOpByOp, test infrastructure); goldens produced by
+the reference's own class pin both (tests/golden/make_affine_golden.py).
 """
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
-from .block_extractor import BlockExtractor
-from .local_attn_reshape import LocalAttnReshape
 
 
 def affine_projector(kz):
@@ -36,13 +33,10 @@ def affine_projector(kz):
 class AffineRegularizationLoss(nn.Module):
     """Same constructor/call as the reference (external_function.py:31-77)."""
 
-    def __init__(self, kz, collapsed=True):
+    def __init__(self, kz):
         super(AffineRegularizationLoss, self).__init__()
         self.kz = kz
-        self.collapsed = collapsed
-        self.extractor = BlockExtractor(kernel_size=kz)
-        self.reshape = LocalAttnReshape()
-        self.kernel = affine_projector(kz).unsqueeze(1).view(kz ** 2, kz, kz).unsqueeze(1)
+        self.kernel = affine_projector(kz).view(kz ** 2, kz ** 2)
 
     def __call__(self, flow_fields):
         grid = self.flow2grid(flow_fields)
@@ -52,18 +46,9 @@ class AffineRegularizationLoss(nn.Module):
         return loss_x + loss_y
 
     def calculate_loss(self, grid, weights):
-        if self.collapsed:
-            kz = self.kz
-            u = F.unfold(grid, kz)                                   # (B, kz^2, L) valid patches
-            mu = torch.matmul(weights.view(kz * kz, kz * kz), u)     # (M u)
-            return (u * mu).sum(1).mean()
-        results = F.conv2d(grid, weights)                            # external_function.py:61-69
-        b, c, h, w = results.size()
-        kernels_new = self.reshape(results, self.kz)
-        f = torch.zeros(b, 2, h, w).type_as(kernels_new) + float(int(self.kz / 2))
-        grid_h = self.extractor(grid, f)
-        result = F.avg_pool2d(grid_h * kernels_new, self.kz, self.kz)
-        return torch.mean(result) * self.kz ** 2
+        u = F.unfold(grid, self.kz)          # (B, kz^2, L): the valid kz x kz patches
+        mu = torch.matmul(weights, u)        # M u
+        return (u * mu).sum(1).mean()
 
     def flow2grid(self, flow_field):
         b, c, h, w = flow_field.size()
@@ -76,12 +61,12 @@ class AffineRegularizationLoss(nn.Module):
 class MultiAffineRegularizationLoss(nn.Module):
     """external_function.py:12-27: one AffineRegularizationLoss per attention layer."""
 
-    def __init__(self, kz_dic, collapsed=True):
+    def __init__(self, kz_dic):
         super(MultiAffineRegularizationLoss, self).__init__()
         self.kz_dic = kz_dic
         self.method_dic = {}
         for key in kz_dic:
-            self.method_dic[key] = AffineRegularizationLoss(kz_dic[key], collapsed=collapsed)
+            self.method_dic[key] = AffineRegularizationLoss(kz_dic[key])
         self.layers = sorted(kz_dic, reverse=True)
 
     def __call__(self, flow_fields):

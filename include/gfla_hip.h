@@ -311,6 +311,11 @@ int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *w
 int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *scratch, float *grad_x,
                          float *grad_w0, int64_t B, int64_t C, int64_t H, int64_t W, int kernel_size, int mode,
                          gfla_stream_t stream);
+/* gfla_fc_kernel: ONE internal kernel of the path on the state a forward + backward of the same shape left in
+ * workspace / scratch, for per-kernel timing (bench.py, profiles).  which: 0 / 1 convolution forward of the source /
+ * target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient.                                          */
+int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C, int64_t H, int64_t W,
+                       int kernel_size, int mode, gfla_stream_t stream);
 int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out,
                      gfla_stream_t stream);
 

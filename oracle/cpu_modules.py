@@ -117,3 +117,42 @@ class PerceptualCorrectnessCPU(nn.Module):
             return torch.mean(loss_map) - e1
         mask = F.interpolate(mask, size=(h, w)).view(-1, h * w)
         return torch.sum(mask * (loss_map - e1)) / (torch.sum(mask) + self.eps)
+
+
+class AffineRegularizationLossOpByOp(nn.Module):
+    """external_function.py:31-77 op by op: conv2d with the (k^2,1,k,k) projector -> LocalAttnReshape ->
+    BlockExtractor(grid, constant flow k//2) -> multiply -> avg_pool2d -> mean * k^2.  `extractor(source, flow)` /
+    `reshape(x, k)` default to the CPU oracle's ops; the GPU tests pass the library's modules instead to exercise them
+    in this composition (Hs != Hf, C = 1)."""
+
+    def __init__(self, kz, extractor=None, reshape=None):
+        super().__init__()
+        import numpy as np
+        self.kz = kz
+        self.extractor = extractor or (lambda s, f: _BlockExtractorCPU.apply(s, f, kz))
+        self.reshape = reshape or (lambda x, k: _LocalAttnReshapeCPU.apply(x, k))
+        temp = np.arange(kz)
+        A = np.ones([kz * kz, 3])
+        A[:, 0] = temp.repeat(kz)
+        A[:, 1] = temp.repeat(kz).reshape((kz, kz)).transpose().reshape(kz ** 2)
+        AH = A.transpose()
+        k = np.dot(A, np.dot(np.linalg.inv(np.dot(AH, A)), AH)) - np.identity(kz ** 2)
+        k = np.dot(k.transpose(), k)
+        self.kernel = torch.from_numpy(k).unsqueeze(1).view(kz ** 2, kz, kz).unsqueeze(1)
+
+    def forward(self, flow_fields):
+        b, c, h, w = flow_fields.size()
+        x = torch.arange(w).view(1, -1).expand(h, -1).type_as(flow_fields).float()
+        y = torch.arange(h).view(-1, 1).expand(-1, w).type_as(flow_fields).float()
+        grid = flow_fields + torch.stack([x, y], dim=0).unsqueeze(0).expand(b, -1, -1, -1)
+        weights = self.kernel.type_as(flow_fields)
+        return self._axis(grid[:, 0:1], weights) + self._axis(grid[:, 1:2], weights)
+
+    def _axis(self, grid, weights):
+        results = F.conv2d(grid, weights)
+        b, c, h, w = results.size()
+        kernels_new = self.reshape(results.contiguous(), self.kz)
+        f = torch.zeros(b, 2, h, w).type_as(kernels_new) + float(int(self.kz / 2))
+        grid_h = self.extractor(grid.contiguous(), f)
+        result = F.avg_pool2d(grid_h * kernels_new, self.kz, self.kz)
+        return torch.mean(result) * self.kz ** 2

@@ -59,3 +59,112 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ------------------------------------------------------------------ overlapped bucketed reducer + bench control flow
+def _reducer_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from global_flow_local_attention_amd import dist as gd
+    import torch.distributed as dist
+    gd.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    unused = torch.nn.Parameter(torch.ones(7))                     # never receives a gradient: counts as zero
+    params = list(net.parameters()) + [unused]
+    red = gd.GradBucketReducer(params, bucket_mb=100e-6)           # ~100-byte buckets: several buckets, hooks fire mid-backward
+    assert len(red.buckets) > 2
+    for step in range(2):                                          # second step: bucket state resets
+        for p in params:
+            p.grad = None
+        x = torch.full((2, 6), float(rank + 1 + step))
+        net(x).sum().backward()
+        red.finish()
+        # reference: plain single-process average of the two ranks' gradients
+        want = []
+        for rr in range(world):
+            ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+            ref.load_state_dict(net.state_dict())
+            ref(torch.full((2, 6), float(rr + 1 + step))).sum().backward()
+            want.append([p.grad.clone() for p in ref.parameters()])
+        for i, p in enumerate(net.parameters()):
+            assert torch.allclose(p.grad, (want[0][i] + want[1][i]) / 2, atol=1e-6), (step, i)
+        assert torch.equal(unused.grad, torch.zeros(7))
+    red.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = True
+
+
+def test_grad_bucket_reducer_world2():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)
+
+
+class _StubHotPath(object):
+    """Stands in for bench.HotPath on CPU: same step()/params() surface, a tiny torch model, the same reducer."""
+
+    def __init__(self, rank):
+        from global_flow_local_attention_amd import dist as gd
+        torch.manual_seed(1234)
+        self.net = torch.nn.Linear(8, 4)
+        self.x = torch.full((3, 8), float(rank + 1))
+        self.reducer = None
+        self.gd = gd
+
+    def params(self):
+        return list(self.net.parameters())
+
+    def step(self, resample, allreduce=True):
+        for p in self.params():
+            p.grad = None
+        if allreduce and self.reducer is None:
+            self.reducer = self.gd.GradBucketReducer(self.params())
+        out = resample(self.net(self.x))
+        out.sum().backward()
+        if allreduce:
+            self.reducer.finish()
+        return [out]
+
+
+def _bench_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import bench
+    from global_flow_local_attention_amd import dist as gd
+    import torch.distributed as dist
+    r, w, _ = gd.init_from_env(backend="gloo")
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"])
+    line = bench.run(args, lambda mode: _StubHotPath(r), lambda: (lambda t: t * 2.0), r, w, torch.device("cpu"),
+                     on_gpu=False)
+    assert line["n_gpus"] == world and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["global_batch"] == 4 * world and line["value"] > 0 and line["scaling"] == "weak"
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = line["value"]
+
+
+def test_bench_control_flow_world2_gloo():
+    """bench.py's N>1 path (barriers, MAX-over-ranks timing, hook-launched all-reduce, rank-0 JSON) on two gloo ranks
+    with a stand-in workload: the part of the multi-GPU run that does not need a GPU."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29700 + os.getpid() % 190
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)
+    assert abs(ret[0] - ret[1]) < 1e-6 * ret[0]        # both ranks computed the same MAX-over-ranks time

@@ -452,9 +452,11 @@ def test_affine_regularization_loss_collapsed_vs_op_by_op(gfla, kz):
     # external_function.py:31-77 through BlockExtractor/LocalAttnReshape (Hs != Hf, C = 1, constant flow)
     # against the collapsed quadratic form, values and gradients w.r.t. the flow field
     flow = make_flow("coherent", 3, 32, 22, seed=80).to(DEV)
+    from oracle.cpu_modules import AffineRegularizationLossOpByOp
     f1, f2 = flow.clone().requires_grad_(), flow.clone().requires_grad_()
-    l1 = gfla.AffineRegularizationLoss(kz, collapsed=True)(f1)
-    l2 = gfla.AffineRegularizationLoss(kz, collapsed=False)(f2)
+    l1 = gfla.AffineRegularizationLoss(kz)(f1)
+    # the reference's op-by-op composition (oracle/cpu_modules.py) running on THIS library's GPU ops
+    l2 = AffineRegularizationLossOpByOp(kz, gfla.BlockExtractor(kz), gfla.LocalAttnReshape())(f2)
     assert abs(l1.item() - l2.item()) <= 2e-4 * max(1.0, abs(l2.item()))
     l1.backward()
     l2.backward()
@@ -462,6 +464,24 @@ def test_affine_regularization_loss_collapsed_vs_op_by_op(gfla, kz):
     multi = gfla.MultiAffineRegularizationLoss({'2': 5, '3': 3})
     fl = [make_flow("coherent", 2, 32, 22, seed=81).to(DEV), make_flow("coherent", 2, 64, 44, seed=82).to(DEV)]
     assert torch.isfinite(multi(fl))
+
+
+def test_affine_regularization_loss_reference_golden_gpu(gfla):
+    """Value and d/d flow against what the reference's own class produced (tests/golden/make_affine_golden.py), for
+    the collapsed form and for the op-by-op composition on this library's GPU ops."""
+    from oracle.cpu_modules import AffineRegularizationLossOpByOp
+    z = np.load(os.path.join(GOLDEN, "affine_golden.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        kz = int(name[2])
+        want, want_g = float(z[name + "/loss"]), torch.from_numpy(z[name + "/g_flow"])
+        for impl in ("collapsed", "op_by_op"):
+            f = torch.from_numpy(z[name + "/flow"]).to(DEV).requires_grad_()
+            mod = gfla.AffineRegularizationLoss(kz) if impl == "collapsed" else \
+                AffineRegularizationLossOpByOp(kz, gfla.BlockExtractor(kz), gfla.LocalAttnReshape())
+            loss = mod(f)
+            loss.backward()
+            assert abs(loss.item() - want) <= 2e-5 * max(1.0, abs(want)), (name, impl, loss.item(), want)
+            assert_close(f.grad.cpu(), want_g, 1e-4, "%s %s d loss / d flow" % (name, impl))
 
 
 def test_hipgraph_captured_inference_matches_eager(gfla, kernel_variant):

@@ -171,3 +171,25 @@ def test_affine_regularization_collapses_to_a_quadratic_form(oracle, kz):
         grid_h = oracle.block_extractor_fwd(g, f, kz)
         want = want + F.avg_pool2d(grid_h * kernels_new, kz, kz).mean() * kz ** 2
     assert abs(got.item() - want.item()) <= 1e-10 * max(1.0, abs(want.item()))
+
+
+def test_affine_regularization_loss_reference_golden(oracle):
+    """tests/golden/affine_golden.npz holds what the REFERENCE's own AffineRegularizationLoss class computed
+    (external_function.py:31-77, run on the host by tests/golden/make_affine_golden.py): value and d/d flow.  Both the
+    collapsed quadratic form (losses.py, the product) and the op-by-op restatement (oracle/cpu_modules.py) must match."""
+    import os
+    import numpy as np
+    from global_flow_local_attention_amd.losses import AffineRegularizationLoss
+    from oracle.cpu_modules import AffineRegularizationLossOpByOp
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "affine_golden.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    assert len(names) == 3
+    for name in names:
+        kz = int(name[2])
+        want, want_g = float(z[name + "/loss"]), torch.from_numpy(z[name + "/g_flow"])
+        for mod in (AffineRegularizationLoss(kz), AffineRegularizationLossOpByOp(kz)):
+            f = torch.from_numpy(z[name + "/flow"]).clone().requires_grad_()
+            loss = mod(f)
+            loss.backward()
+            assert abs(loss.item() - want) <= 2e-5 * max(1.0, abs(want)), (name, type(mod).__name__, loss.item(), want)
+            assert (f.grad - want_g).abs().max().item() <= 1e-4 * max(1.0, want_g.abs().max().item())

@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rows", default="0,1,2,4")
-    ap.add_argument("--flows", default="smooth,coherent,wild")
+    ap.add_argument("--flows", default="zero,smooth,coherent,wild")
     args = ap.parse_args()
     lib = _lib.lib()
     B = 32
@@ -42,10 +42,15 @@ def main():
                 _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(attn),
                           _lib.ptr(go), _lib.ptr(gs), None, None, _lib.ptr(w), *tail)
             row = {"op": "aggregate d/d source", "shape": name, "flow": kind, "lds_atomic_us": round(time_fn(lambda: run(None), args.iters), 1)}
+            row["adaptive_us"] = round(time_fn(lambda: run(ws), args.iters), 1)
+            torch.cuda.synchronize()
+            row["rows_per_tile"] = round(int(ws[-256:-128].view(torch.int32).sum().item()) / (B * ((H * W + 31) // 32)), 2)
+            lib.gfla_set_tuning(15, 100000)  # always the matrix-core path
             for r in args.rows.split(","):
                 lib.gfla_set_tuning(13, int(r))
                 row["mfma_R%s_us" % r] = round(time_fn(lambda: run(ws), args.iters), 1)
             lib.gfla_set_tuning(13, 0)
+            lib.gfla_set_tuning(15, 0)
             print(json.dumps(row), flush=True)
         for (name, C, H, W) in (("relu3_1", 256, 64, 44), ("relu4_1", 512, 32, 22)):
             i1 = torch.randn(B, C, H, W, device=DEV)
@@ -60,10 +65,15 @@ def main():
                 _lib.call("gfla_resample2d_bwd_ws_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(g1), None,
                           _lib.ptr(w), *tail)
             row = {"op": "resample2d d/d input1", "shape": name, "flow": kind, "lds_atomic_us": round(time_fn(lambda: run(None), args.iters), 1)}
+            row["adaptive_us"] = round(time_fn(lambda: run(ws), args.iters), 1)
+            torch.cuda.synchronize()
+            row["rows_per_tile"] = round(int(ws[-256:-128].view(torch.int32).sum().item()) / (B * ((H * W + 31) // 32)), 2)
+            lib.gfla_set_tuning(15, 100000)
             for r in args.rows.split(","):
                 lib.gfla_set_tuning(13, int(r))
                 row["mfma_R%s_us" % r] = round(time_fn(lambda: run(ws), args.iters), 1)
             lib.gfla_set_tuning(13, 0)
+            lib.gfla_set_tuning(15, 0)
             print(json.dumps(row), flush=True)
 
 
