@@ -72,7 +72,7 @@ def smooth_flow(B, H, W, device, gen):
 class HotPath:
     """Synthetic inputs + modules of one rank."""
 
-    def __init__(self, B, device, seed, modules=None, vgg_grad=True, fc_impl=None, fc_mode=None):
+    def __init__(self, B, device, seed, modules=None, vgg_grad=True, fc_impl=None, fc_mode=None, with_losses=False):
         gen = torch.Generator(device=device).manual_seed(seed)
         self.B, self.device = B, device
         self.attn, self.inputs, self.vgg = [], [], []
@@ -91,6 +91,14 @@ class HotPath:
         for (name, C, H, W) in VGG:
             feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_(vgg_grad)
             self.vgg.append(feat)
+        # --with-losses (BASELINE config 4's loss side): the sampling-correctness loss consumes the warps (its
+        # best-match cosine similarity is the library's streaming max-GEMM on MFMA) and the affine regulariser reads
+        # the flow fields -- external_function.py:223-279, 12-77.  Frozen-VGG features: constants, as in training.
+        self.losses = None
+        if with_losses:
+            self.losses = (gfla.PerceptualCorrectness(), gfla.MultiAffineRegularizationLoss({"2": 5, "3": 3}))
+            self.vgg_target = [torch.randn(B, C, H, W, device=device, generator=gen).relu() for (_, C, H, W) in VGG]
+            self.vgg = [v.detach().relu() for v in self.vgg]
 
     def params(self):
         return [p for m in self.attn for p in m.parameters()]
@@ -100,7 +108,15 @@ class HotPath:
         upstream gradients (what the rest of the generator / the losses would send back) -- no
         synthetic loss kernels inside the timed region."""
         outs = [mod(src, tgt, flow) for mod, (src, tgt, flow) in zip(self.attn, self.inputs)]
-        outs += [resample(feat, flow) for feat, (_, _, flow) in zip(self.vgg, self.inputs)]
+        if self.losses is not None:
+            corr, reg = self.losses
+            corr.source_vgg = {n: f for (n, _, _, _), f in zip(VGG, self.vgg)}
+            corr.target_vgg = {n: f for (n, _, _, _), f in zip(VGG, self.vgg_target)}
+            flows = [flow for (_, _, flow) in self.inputs]
+            loss = sum(corr.calculate_loss(fl, n) for fl, (n, _, _, _) in zip(flows, VGG)) + 0.0025 * reg(flows)
+            outs.append(loss.reshape(1))
+        else:
+            outs += [resample(feat, flow) for feat, (_, _, flow) in zip(self.vgg, self.inputs)]
         if self.upstream is None:
             gen = torch.Generator(device=outs[0].device).manual_seed(4321)
             self.upstream = [torch.randn(o.shape, device=o.device, generator=gen) / o[0].numel() for o in outs]
@@ -514,7 +530,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
                                "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. both FC layers, "
                                "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)"
-                               + ("" if not args.no_vgg_grad else " with constant VGG features (no d/d input1)"),
+                               + ("" if not args.no_vgg_grad else " with constant VGG features (no d/d input1)")
+                               + ("" if not getattr(args, "with_losses", False) else
+                                  "; --with-losses: the warps run inside PerceptualCorrectness.calculate_loss (max-cosine "
+                                  "MFMA kernel + fused loss map) and MultiAffineRegularizationLoss reads the flows"),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "dp%d (batch shards; ExtractorAttn gradients all-reduced in one flat bucket launched "
                                   "from autograd hooks, overlapping backward)" % world,
@@ -571,8 +590,15 @@ def parse_args(argv=None):
     ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
                     help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
                          "f16 terms per operand with f32 accumulation (labelled experiments)")
+    ap.add_argument("--with-losses", action="store_true",
+                    help="replace the bare Resample2d sites by the losses that contain them in training (BASELINE "
+                         "config 4): PerceptualCorrectness.calculate_loss on synthetic VGG-shaped features + "
+                         "MultiAffineRegularizationLoss on the flow fields (no oracle check / CPU baseline for this leg)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.with_losses:
+        args.no_cpu_baseline = True
+    return args
 
 
 def main():
@@ -595,7 +621,7 @@ def main():
 
     def make_hotpath(fc_mode):
         return HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
-                       fc_mode=fc_mode)
+                       fc_mode=fc_mode, with_losses=args.with_losses)
 
     run(args, make_hotpath, lambda: gfla.Resample2d(4, 1, 2), rank, world, device)
     if world > 1:

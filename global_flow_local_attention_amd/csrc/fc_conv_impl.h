@@ -46,20 +46,47 @@ __device__ __forceinline__ void fc_prefetch_pieces(u32x4 (&pf)[kFcPrefetch], con
     pf[q] = *reinterpret_cast<const u32x4 *>(src + (int64_t)min(pix0 + 64 * q, tmh - 1) * x_ps);
 }
 
+// Row tiling of one launch.  Every sample's ceil(M / 32) row blocks are cut into T tiles: `rem` "heavy" ones of
+// base + 1 blocks and T - rem "light" ones of base blocks, so that B * T workgroups fill the 2 x 256 workgroup slots
+// of the chip in ONE round with at most one block of imbalance.  Heavy tiles take the low workgroup ids; when the
+// launch fits one round, ids >= 256 are mirrored (id -> N - 1 - (id - 256)) so that the workgroups a CU gets in the
+// first and second dispatch wave (ids w and w + 256 land on the same CU in practice) are a large and a small one.
+// (Placement is an optimisation only: any dispatch order computes the same result.)
+struct ConvTiling {
+  int T, base, rem, heavy, per_ntile;  // heavy = B * rem tiles of base + 1 blocks; per_ntile = B * T
+};
+
 template <int MODE, int KS, int NMB>
 __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const unsigned char *__restrict__ Wk,
                                                         int64_t w_split_stride, float *__restrict__ out,
                                                         int64_t out_bs, int ldo, int n_valid, int M, int Wv, int Wp,
-                                                        int nch, int tmh, const uint32_t *__restrict__ amax_x,
+                                                        int nch, int tmh, ConvTiling tl,
+                                                        const uint32_t *__restrict__ amax_x,
                                                         const uint32_t *__restrict__ amax_w) {
   using F = Fc<MODE>;
   constexpr int KK = KS * KS, PITCH = F::PITCH, STEPS = F::KB * NMB;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   unsigned char *xs = gfla_smem;  // [NS][tmh][PITCH]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * 32 * NMB;
-  const int64_t b = blockIdx.y;
-  const int ntile = blockIdx.z;
+  // workgroup -> (channel tile, sample, first row block, row blocks): see ConvTiling
+  int wid = blockIdx.x;
+  const int ntile = wid / tl.per_ntile;
+  wid -= ntile * tl.per_ntile;
+  if (tl.per_ntile <= 2 * kNumCU && wid >= kNumCU) wid = tl.per_ntile - 1 - (wid - kNumCU);  // pair large with small
+  else if (tl.per_ntile <= kNumCU && (ntile & 1)) wid = tl.per_ntile - 1 - wid;            // (across channel tiles too)
+  int64_t b;
+  int first, nblk;
+  if (wid < tl.heavy) {
+    b = wid / tl.rem;
+    first = (wid - (int)b * tl.rem) * (tl.base + 1);
+    nblk = tl.base + 1;
+  } else {
+    const int u = wid - tl.heavy, per = tl.T - tl.rem;
+    b = u / per;
+    first = tl.rem * (tl.base + 1) + (u - (int)b * per) * tl.base;
+    nblk = tl.base;
+  }
+  const int m0 = first * 32;
   const int y0 = m0 / Wv, p0 = y0 * Wp + (m0 - y0 * Wv);  // first input pixel of the row tile
   const int64_t x_ss = X.split_stride, x_cs = X.chunk_stride;
   const int x_ps = X.pix_stride;
@@ -159,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
         else
           fa = load_frag<MODE>(xa_next + a_off[0], xplane, 0, kh);
         __builtin_amdgcn_sched_barrier(0);  // keep the LDS read ahead of the MFMAs it overlaps with
-        acc[mb] = mma<MODE>(fc, cur[kb], acc[mb]);
+        if (mb + 1 < NMB || nblk == NMB)    // a "light" tile has one row block fewer (wave-uniform)
+          acc[mb] = mma<MODE>(fc, cur[kb], acc[mb]);
       }
 #pragma unroll
       for (int q = 0; q < F::KB; ++q) cur[q] = nxt[q];
@@ -173,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
   if (col < n_valid) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
+      if (mb >= nblk) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -190,49 +219,60 @@ inline int fc_conv_tile_pixels(int mb, int Wv, int Wp, int k) {
   return tm + ((tm - 1) / Wv + 1) * (Wp - Wv) + (k - 1) * (Wp + 1);
 }
 
-// Row blocks per workgroup: all row tiles cost the same, so the launch takes ceil(tiles / slots) rounds of
-// (mb + staging) block-times; take the mb that minimises that (ties: the larger tile re-reads the weights less).
-inline int pick_row_blocks(int M, int64_t B, int ntiles_n, int Wv, int Wp, int k, int mode) {
+// Tiles per sample: as many as fill the chip's workgroup slots once (2 per CU when two tiles' LDS fit), never more
+// than kFcMaxRowBlocks row blocks per tile.  Returns the template's NMB (= the heavy tile's blocks), 0 = does not fit.
+inline int pick_conv_tiling(int M, int64_t B, int ntiles_n, int Wv, int Wp, int k, int mode, ConvTiling *tl) {
   const int ns = fc_nsplit(mode), pitch = mode ? 48 : 80;
-  int best = 0;
-  double best_cost = 1e300;
+  const int nb = (int)ceil_div(M, 32);
   const int forced = tuning(11);
-  for (int mb = kFcMinRowBlocks; mb <= kFcMaxRowBlocks; ++mb) {
-    if (forced >= kFcMinRowBlocks && forced <= kFcMaxRowBlocks && mb != forced) continue;
-    const int64_t lds = (int64_t)ns * fc_conv_tile_pixels(mb, Wv, Wp, k) * pitch;
-    if (lds > 156 * 1024) continue;
-    const int w = lds * 2 <= 160 * 1024 ? 2 : 1;
-    const int64_t tiles = ceil_div(M, 32 * mb) * B * ntiles_n;
-    const int64_t rounds = ceil_div(tiles, (int64_t)kNumCU * w);
-    const double cost = (double)rounds * (mb + 0.35) * (w == 1 ? 1.12 : 1.0);
-    if (cost <= best_cost) best_cost = cost, best = mb;
+  int64_t T = (2 * kNumCU) / (B * ntiles_n);
+  if (T < 1) T = 1;
+  if (T > nb) T = nb;
+  if (ceil_div(nb, T) > kFcMaxRowBlocks) T = ceil_div(nb, kFcMaxRowBlocks);
+  if (forced >= kFcMinRowBlocks && forced <= kFcMaxRowBlocks) T = ceil_div(nb, forced);
+  // LDS: shrink tiles until one fits; two per CU preferred
+  for (;; ++T) {
+    const int nmb = (int)ceil_div(nb, T);
+    const int64_t lds = (int64_t)ns * fc_conv_tile_pixels(nmb < kFcMinRowBlocks ? kFcMinRowBlocks : nmb, Wv, Wp, k) * pitch;
+    if (lds <= 156 * 1024) break;
+    if (nmb <= kFcMinRowBlocks) return 0;
   }
-  return best;
+  tl->T = (int)T;
+  tl->base = nb / (int)T;
+  tl->rem = nb % (int)T;
+  tl->heavy = (int)B * tl->rem;
+  tl->per_ntile = (int)(B * T);
+  int nmb = tl->base + (tl->rem ? 1 : 0);
+  if (nmb < kFcMinRowBlocks) {  // tiny problems: the smallest instantiation, its spare blocks masked off
+    nmb = kFcMinRowBlocks;
+  }
+  return nmb;
 }
 
 template <int MODE, int KS, int NMB>
 static int launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,
-                       int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const uint32_t *amax_x,
-                       const uint32_t *amax_w, hipStream_t stream) {
+                       int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const ConvTiling &tl,
+                       const uint32_t *amax_x, const uint32_t *amax_w, hipStream_t stream) {
   using F = Fc<MODE>;
   const int tmh = fc_conv_tile_pixels(NMB, Wv, Wp, KS);
   const unsigned lds = (unsigned)(F::NS * tmh * F::PITCH);
-  const dim3 grid((unsigned)ceil_div(M, 32 * NMB), (unsigned)B, (unsigned)ceil_div(n_valid, kFcTN));
+  const int64_t wgs = (int64_t)tl.per_ntile * ceil_div(n_valid, kFcTN);
+  if (wgs > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
   auto kern = fc_conv_kernel<MODE, KS, NMB>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<grid, 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs, ldo,
-                                   n_valid, M, Wv, Wp, nch, tmh, amax_x, amax_w);
+  kern<<<dim3((unsigned)wgs), 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs,
+                                                  ldo, n_valid, M, Wv, Wp, nch, tmh, tl, amax_x, amax_w);
   return launch_status();
 }
 
 template <int MODE, int KS>
 static int dispatch_conv(int nmb, const PackedDesc &X, const void *wk, int64_t wss, float *out, int64_t out_bs, int ldo,
-                         int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const uint32_t *ax, const uint32_t *aw,
-                         hipStream_t s) {
+                         int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const ConvTiling &tl, const uint32_t *ax,
+                         const uint32_t *aw, hipStream_t s) {
   switch (nmb) {
 #define GFLA_CASE(N_) \
-  case N_: return launch_conv<MODE, KS, N_>(X, wk, wss, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, ax, aw, s)
+  case N_: return launch_conv<MODE, KS, N_>(X, wk, wss, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, tl, ax, aw, s)
     GFLA_CASE(2);
     GFLA_CASE(3);
     GFLA_CASE(4);
@@ -256,13 +296,14 @@ int fc_conv_mode(const PackedDesc &X, const void *wk, int64_t w_split_stride, fl
   int fc_conv_mode<MODE_>(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,    \
                           int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k,                     \
                           const uint32_t *amax_x, const uint32_t *amax_w, hipStream_t stream) {                       \
-    const int nmb = pick_row_blocks(M, B, (int)ceil_div(n_valid, kFcTN), Wv, Wp, k, MODE_);                            \
+    ConvTiling tl;                                                                                                    \
+    const int nmb = pick_conv_tiling(M, B, (int)ceil_div(n_valid, kFcTN), Wv, Wp, k, MODE_, &tl);                      \
     if (nmb == 0) return GFLA_ERR_UNSUPPORTED;                                                                        \
     if (k == 3)                                                                                                       \
-      return dispatch_conv<MODE_, 3>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, amax_x, \
-                                     amax_w, stream);                                                                 \
-    return dispatch_conv<MODE_, 5>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, amax_x,   \
-                                   amax_w, stream);                                                                   \
+      return dispatch_conv<MODE_, 3>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, tl,     \
+                                     amax_x, amax_w, stream);                                                         \
+    return dispatch_conv<MODE_, 5>(nmb, X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, tl,       \
+                                   amax_x, amax_w, stream);                                                           \
   }
 
 }  // namespace gfla

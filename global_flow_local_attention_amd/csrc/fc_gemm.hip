@@ -106,13 +106,20 @@ __global__ __launch_bounds__(256) void fc_maxabs_kernel(const float *__restrict_
     m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot, m);
+  // ONE atomic per workgroup: thousands of atomics on a single address serialise at ~12 ns each
+  __shared__ uint32_t s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    if (m) atomicMax(slot, m);
+  }
 }
 
 int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream) {
   if (n <= 0) return GFLA_OK;
   int64_t blocks = ceil_div(n, 256 * 16);
-  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
   fc_maxabs_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(x, n, slot);
   return launch_status();
 }
@@ -211,22 +218,31 @@ int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_
 // Forward tiles   wf[term][0][chunk][tap][n = 0..127][16 c]      = W[n][off + 16*chunk + c][i][j]
 // data-grad tiles wd[term][ntile][chunk][tap'][c_out = 0..127][16 n] = W[16*chunk + n][off + 128*ntile + c_out][k-1-i'][k-1-j']
 // (the transposed convolution as a convolution with flipped taps and swapped channel roles).
+struct PackWJob {
+  unsigned char *dst;
+  int c_off, dgrad, nch;
+  int64_t total_pieces, split_stride;
+};
+struct PackWJobs {
+  PackWJob j[4];
+};
+
+// grid (blocks, 4 jobs): forward / data-gradient tiles of the target / source half in ONE launch
 template <int MODE>
 __global__ __launch_bounds__(256) void fc_pack_w_kernel(const float *__restrict__ w0, const uint32_t *__restrict__ amax,
-                                                       unsigned char *__restrict__ dst, int C, int c_off, int k,
-                                                       int dgrad, int nch, int64_t total_pieces,
-                                                       int64_t split_stride) {
+                                                       PackWJobs jobs, int C, int k) {
   using F = Fc<MODE>;
+  const PackWJob jb = jobs.j[blockIdx.y];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (ntile, chunk, tap, row, half)
-  if (idx >= total_pieces) return;
+  if (!jb.dst || idx >= jb.total_pieces) return;
   const int half = (int)(idx & 1);
   const int row = (int)((idx >> 1) & 127);
   int64_t rest = idx >> 8;
   const int KK = k * k;
   const int tap = (int)(rest % KK);
   rest /= KK;
-  const int cc = (int)(rest % nch);
-  const int ntile = (int)(rest / nch);
+  const int cc = (int)(rest % jb.nch);
+  const int ntile = (int)(rest / jb.nch);
   const int i = tap / k, j = tap - i * k;
   const float s = MODE == 0 ? 1.f : fc_scale(amax);
   float v[8];
@@ -234,38 +250,41 @@ __global__ __launch_bounds__(256) void fc_pack_w_kernel(const float *__restrict_
   for (int e = 0; e < 8; ++e) {
     const int kc = cc * kFcChunk + half * 8 + e;
     float val = 0.f;
-    if (!dgrad) {
+    if (!jb.dgrad) {
       const int n = ntile * kFcTN + row;
-      if (n < kFcHidden && kc < C) val = w0[(((int64_t)n * 2 * C + c_off + kc) * k + i) * k + j];
+      if (n < kFcHidden && kc < C) val = w0[(((int64_t)n * 2 * C + jb.c_off + kc) * k + i) * k + j];
     } else {
       const int co = ntile * kFcTN + row;
-      if (co < C && kc < kFcHidden) val = w0[(((int64_t)kc * 2 * C + c_off + co) * k + (k - 1 - i)) * k + (k - 1 - j)];
+      if (co < C && kc < kFcHidden) val = w0[(((int64_t)kc * 2 * C + jb.c_off + co) * k + (k - 1 - i)) * k + (k - 1 - j)];
     }
     v[e] = val;
   }
-  store_pieces<MODE>(v, s, dst + (idx >> 1) * (int64_t)F::REC + half * 8 * F::ESZ, split_stride);
+  store_pieces<MODE>(v, s, jb.dst + (idx >> 1) * (int64_t)F::REC + half * 8 * F::ESZ, jb.split_stride);
 }
 
 int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
                     int k, int mode, hipStream_t stream) {
   const int nch_c = (int)ceil_div(C, kFcChunk), nch_h = kFcHidden / kFcChunk, nt_d = (int)ceil_div(C, kFcTN);
-  struct Job {
+  struct Spec {
     void *dst;
     int c_off, dgrad, ntiles, nch;
-  } jobs[4] = {{wf_t, 0, 0, 1, nch_c}, {wf_s, C, 0, 1, nch_c}, {wd_t, 0, 1, nt_d, nch_h}, {wd_s, C, 1, nt_d, nch_h}};
-  for (const Job &jb : jobs) {
-    if (!jb.dst) continue;
-    const int64_t pieces = (int64_t)jb.ntiles * jb.nch * k * k * kFcTN * 2;
-    const int64_t split_stride = pieces / 2 * kFcChunk * fc_esz(mode);
-    const dim3 grid((unsigned)ceil_div(pieces, 256));
-    unsigned char *d = static_cast<unsigned char *>(jb.dst);
-    if (mode == 0)
-      fc_pack_w_kernel<0><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
-    else if (mode == 2)
-      fc_pack_w_kernel<2><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
-    else
-      fc_pack_w_kernel<3><<<grid, 256, 0, stream>>>(w0, amax, d, C, jb.c_off, k, jb.dgrad, jb.nch, pieces, split_stride);
+  } specs[4] = {{wf_t, 0, 0, 1, nch_c}, {wf_s, C, 0, 1, nch_c}, {wd_t, 0, 1, nt_d, nch_h}, {wd_s, C, 1, nt_d, nch_h}};
+  PackWJobs jobs;
+  int64_t most = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int64_t pieces = (int64_t)specs[q].ntiles * specs[q].nch * k * k * kFcTN * 2;
+    jobs.j[q] = PackWJob{static_cast<unsigned char *>(specs[q].dst), specs[q].c_off, specs[q].dgrad, specs[q].nch, pieces,
+                         pieces / 2 * kFcChunk * fc_esz(mode)};
+    if (specs[q].dst && pieces > most) most = pieces;
   }
+  if (most == 0) return GFLA_OK;
+  const dim3 grid((unsigned)ceil_div(most, 256), 4);
+  if (mode == 0)
+    fc_pack_w_kernel<0><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
+  else if (mode == 2)
+    fc_pack_w_kernel<2><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
+  else
+    fc_pack_w_kernel<3><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
   return launch_status();
 }
 
@@ -496,7 +515,7 @@ __device__ __forceinline__ void lds_dma16(const unsigned char *gsrc, unsigned ch
 }
 
 template <int KS>
-__global__ __launch_bounds__(512, 2) void fc_wgrad_f32_kernel(PackedDesc X, PackedDesc Y, int64_t y_lead,
+__global__ __launch_bounds__(512, 4) void fc_wgrad_f32_kernel(PackedDesc X, PackedDesc Y, int64_t y_lead,
                                                              float *__restrict__ part, int cpad, int Wp, int nblk,
                                                              int64_t total_blocks, int nsplit) {
   constexpr int KK = KS * KS, KC = kWgKC, YB = KC * kFcHidden * 4;  // bytes of one Z block
@@ -543,28 +562,29 @@ __global__ __launch_bounds__(512, 2) void fc_wgrad_f32_kernel(PackedDesc X, Pack
     if (blk + 1 < blk1) issue(blk + 1, buf ^ 1);
     const unsigned char *xb = xs + buf * xbytes + xa;
     const unsigned char *ybp = ys + buf * YB + yb;
-    float an[KS];
+    // Rows of work = (K step s4, tap row i), KS MFMAs each.  Fully unrolled with two explicit register sets: the
+    // LDS reads of row r + 1 are issued ahead of the MFMAs of row r and land in the OTHER set, so the wait the
+    // compiler puts in front of a row's MFMAs only covers reads issued a whole row (KS MFMAs) earlier.
+    constexpr int ROWS = (KC / 4) * KS;
+    float abuf[2][KS], bbuf[2];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const float *>(xb + j * 64);
-    float bn = *reinterpret_cast<const float *>(ybp);
-#pragma unroll 2
-    for (int s4 = 0; s4 < KC / 4; ++s4) {
-      const float bc = bn;
-      bn = *reinterpret_cast<const float *>(ybp + (s4 + 1 < KC / 4 ? s4 + 1 : s4) * 2048);
+    for (int j = 0; j < KS; ++j) abuf[0][j] = *reinterpret_cast<const float *>(xb + j * 64);
+    bbuf[0] = *reinterpret_cast<const float *>(ybp);
 #pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        float ac[KS];
+    for (int r = 0; r < ROWS; ++r) {
+      const int s4 = r / KS, i = r - s4 * KS, cur = r & 1;
+      if (r + 1 < ROWS) {
+        const int s4n = (r + 1) / KS, in = (r + 1) - s4n * KS;
+        const unsigned char *nx_row = xb + s4n * 256 + in * row_pitch;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) ac[j] = an[j];
-        // next tap row (of this K step, or the first row of the next one; past the last step: a harmless in-bounds read)
-        const unsigned char *nx_row = i + 1 < KS ? xb + s4 * 256 + (i + 1) * row_pitch : xb + (s4 + 1) * 256;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const float *>(nx_row + j * 64);
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs they overlap with
-#pragma unroll
-        for (int j = 0; j < KS; ++j)
-          acc[i * KS + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j], bc, acc[i * KS + j], 0, 0, 0);
+        for (int j = 0; j < KS; ++j) abuf[cur ^ 1][j] = *reinterpret_cast<const float *>(nx_row + j * 64);
+        if (in == 0) bbuf[s4n & 1] = *reinterpret_cast<const float *>(ybp + s4n * 2048);
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs they overlap with
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+        acc[i * KS + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[cur][j], bbuf[s4 & 1], acc[i * KS + j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + r

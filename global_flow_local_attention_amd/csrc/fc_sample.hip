@@ -178,15 +178,19 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     }
   }
   __syncthreads();
-  // phase 2: lanes = hidden channels (lane, lane + 64); a wave walks 16 positions
+  // phase 2: lanes = hidden channels (lane, lane + 64); a wave walks 16 CONSECUTIVE positions.  The right-hand corners
+  // of position p are the left-hand corners of p + 1 whenever the flow moves both by the same whole step (the common
+  // case for a smooth flow), so the wave keeps the right column's two sums pending and folds the next position's left
+  // column into them: 4 atomics per position and channel half instead of 8.  (Indices are wave-uniform: no divergence.)
   const float *gsb = gs + b * gs_bs;
   float *zsb = dzs ? dzs + b * zs_bs : nullptr;
   float *ztb = dzt ? dzt + b * zt_bs : nullptr;
   float s0 = 0.f, s1 = 0.f;
-#pragma unroll 2
+  int pend_t = -1, pend_b = -1;                // Z-layout indices of the pending column (-1: none)
+  float pt0 = 0.f, pt1 = 0.f, pb0 = 0.f, pb1 = 0.f;  // its sums: (top, bottom) x (channel lane, lane + 64)
   for (int it = 0; it < kSmpPix / 4; ++it) {
-    const int pp = wave + 4 * it, p = p0 + pp;
-    if (p >= HW) continue;
+    const int pp = wave * (kSmpPix / 4) + it, p = p0 + pp;
+    if (p >= HW) break;
     const float d0 = tile[pp * kSmpPitch + lane], d1 = tile[pp * kSmpPitch + lane + 64];
     s0 += d0;
     s1 += d1;
@@ -200,12 +204,19 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     const Corner c = corners<KS>(fx, fy, x, y, H, W, wps, wpz);
     if (zsb) {
       const float wa = c.xl * c.yt, wb = c.xr * c.yt, wc = c.xl * c.yb, wd = c.xr * c.yb;
-      float *z00 = zsb + (int64_t)(lead_s + c.z00) * kFcHidden + lane, *z01 = zsb + (int64_t)(lead_s + c.z01) * kFcHidden + lane;
-      float *z10 = zsb + (int64_t)(lead_s + c.z10) * kFcHidden + lane, *z11 = zsb + (int64_t)(lead_s + c.z11) * kFcHidden + lane;
-      atomic_add(z00, wa * d0); atomic_add(z00 + 64, wa * d1);
-      atomic_add(z01, wb * d0); atomic_add(z01 + 64, wb * d1);
-      atomic_add(z10, wc * d0); atomic_add(z10 + 64, wc * d1);
-      atomic_add(z11, wd * d0); atomic_add(z11 + 64, wd * d1);
+      float lt0 = wa * d0, lt1 = wa * d1, lb0 = wc * d0, lb1 = wc * d1;  // this position's left column
+      if (pend_t == c.z00 && pend_b == c.z10) {
+        lt0 += pt0, lt1 += pt1, lb0 += pb0, lb1 += pb1;
+      } else if (pend_t >= 0) {
+        float *zt = zsb + (int64_t)(lead_s + pend_t) * kFcHidden + lane, *zb = zsb + (int64_t)(lead_s + pend_b) * kFcHidden + lane;
+        atomic_add(zt, pt0); atomic_add(zt + 64, pt1);
+        atomic_add(zb, pb0); atomic_add(zb + 64, pb1);
+      }
+      float *z00 = zsb + (int64_t)(lead_s + c.z00) * kFcHidden + lane, *z10 = zsb + (int64_t)(lead_s + c.z10) * kFcHidden + lane;
+      atomic_add(z00, lt0); atomic_add(z00 + 64, lt1);
+      atomic_add(z10, lb0); atomic_add(z10 + 64, lb1);
+      pend_t = c.z01, pend_b = c.z11;
+      pt0 = wb * d0, pt1 = wb * d1, pb0 = wd * d0, pb1 = wd * d1;
     }
     if (gflow) {
       const float *g00 = gsb + (int64_t)c.i00 * kFcHidden + lane, *g01 = gsb + (int64_t)c.i01 * kFcHidden + lane;
@@ -223,6 +234,11 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
         *fyp = acc_flow ? *fyp + gy : gy;
       }
     }
+  }
+  if (zsb && pend_t >= 0) {
+    float *zt = zsb + (int64_t)(lead_s + pend_t) * kFcHidden + lane, *zb = zsb + (int64_t)(lead_s + pend_b) * kFcHidden + lane;
+    atomic_add(zt, pt0); atomic_add(zt + 64, pt1);
+    atomic_add(zb, pb0); atomic_add(zb + 64, pb1);
   }
   if (b0_partials) {
     bsum[wave * kFcHidden + lane] = s0;
