@@ -492,7 +492,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
     if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline:
         check = oracle_check(hp, resample)  # asserts; before anything is timed
     hp.step(resample)  # priming step: lazy initialisation, never timed
-    elapsed = timed_steps(lambda: hp.step(resample), args.steps, args.warmup, barrier, world, device)
+    # (Capturing the whole step -- forward + backward, ~90 launches -- into one hipGraph was measured and dropped: 7.146 ms
+    # replayed vs 7.147 ms eager; the step is not launch-bound.)
+    step = lambda: hp.step(resample)
+    elapsed = timed_steps(step, args.steps, args.warmup, barrier, world, device)
 
     rows, probes = [], []
     if on_gpu:
@@ -512,7 +515,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             hv = make_hotpath(mode)
             hv.step(resample)
             n = max(3, args.steps // 2)
-            ev = timed_steps(lambda: hv.step(resample), n, 2, barrier, world, device)
+            vstep = lambda: hv.step(resample)
+            ev = timed_steps(vstep, n, 2, barrier, world, device)
             variants[label] = {"value": round(args.batch * world * n / ev, 2), "unit": "images/s",
                                "ms_per_step": round(ev / n * 1e3, 3),
                                "note": "labelled experiment, not the headline: FC operands split into %d f16 terms, f32 "

@@ -14,6 +14,7 @@ from .losses import AffineRegularizationLoss, MultiAffineRegularizationLoss  # n
 from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401
 from .graphs import GraphedCall, graphed_inference  # noqa: F401
 from .install import install  # noqa: F401
+from .trainer import TrainerShell, load_reference_checkpoint  # noqa: F401
 from .tuning import enable_gemm_tuning, gemm_tuning_results, seed_conv_db  # noqa: F401
 
 __version__ = "0.1.0"

@@ -36,3 +36,4 @@ def graphed_inference(module, example_inputs, warmup=3):
     """hipGraph-captured `module.forward` for fixed input shapes (inference only)."""
     module.eval()
     return GraphedCall(module, example_inputs, warmup)
+

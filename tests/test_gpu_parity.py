@@ -721,3 +721,4 @@ def test_fc_tail_matches_torch_ops(gfla, kernel_variant, dtype, KK, Hc, slope, b
     for a, b_ in zip(g_got, g_want):
         assert a.shape == b_.shape
         assert_close(a, b_, t * 10, "fc tail gradient")
+
