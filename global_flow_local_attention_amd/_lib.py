@@ -55,8 +55,9 @@ _SINGLE = {
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_resample2d_bwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _int, _ptr],
 }
-_FWD_ONLY_BF16 = {"gfla_block_extractor_bwd", "gfla_block_extractor_unfold_bwd", "gfla_resample2d_bwd",
-                  "gfla_local_attn_aggregate_bwd", "gfla_local_attn_source_bwd"}
+# bf16 storage exists for every entry point below; the backward ones return the reductions over channels (grad_flow,
+# grad_logits, grad_in2) in float32 (include/gfla_hip.h)
+_FWD_ONLY_BF16 = set()
 
 
 def exported_symbols():
@@ -110,8 +111,8 @@ _SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
 
 
 def suffix(t, what, allow_bf16=True):
-    """Entry-point suffix for t's dtype.  bfloat16 storage exists for the forward entry points only: backward
-    callers pass allow_bf16=False and get a clear error instead of a missing-symbol AttributeError."""
+    """Entry-point suffix for t's dtype.  allow_bf16=False: entry points without bfloat16 storage raise a clear
+    TypeError instead of a missing-symbol AttributeError."""
     try:
         sfx = _SUFFIX[t.dtype]
     except KeyError:
@@ -119,6 +120,12 @@ def suffix(t, what, allow_bf16=True):
     if sfx == "bf16" and not allow_bf16:
         raise TypeError("%s: bfloat16 is forward-only in this library (use float32 for training)" % what)
     return sfx
+
+
+def reduction_like(t):
+    """Zeroed buffer for a gradient that is a reduction over channels (grad_flow, grad_logits, grad_in2): float32 when the
+    storage type is bfloat16 (the bf16 backward entry points accumulate these in float32), t's dtype otherwise."""
+    return torch.zeros(t.shape, dtype=torch.float32 if t.dtype == torch.bfloat16 else t.dtype, device=t.device)
 
 
 def scatter_workspace(ref_tensor, B, H, W, entries):

@@ -53,7 +53,7 @@ class BlockExtractorFunction(Function):
         source, flow_field = ctx.saved_tensors
         want_source, want_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_source = torch.zeros_like(source) if want_source else None
-        g_flow = torch.zeros_like(flow_field) if want_flow else None
+        g_flow = _lib.reduction_like(flow_field) if want_flow else None  # float32 accumulator for bf16 storage
         grad_patches = grad_patches.contiguous()  # the reference drops this result (:32-33)
         if (want_source or want_flow) and grad_patches.numel() > 0 and source.numel() > 0:
             B, C, Hs, Ws = source.shape
@@ -61,6 +61,8 @@ class BlockExtractorFunction(Function):
             _lib.call(_ENTRY_BWD + _lib.suffix(source, "block_extractor backward"), source,
                       _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_patches),
                       _lib.ptr(g_source), _lib.ptr(g_flow), B, C, Hs, Ws, Hf, Wf, ctx.kernel_size)
+        if g_flow is not None and g_flow.dtype != flow_field.dtype:
+            g_flow = g_flow.to(flow_field.dtype)
         return g_source, g_flow, None
 
 

@@ -61,7 +61,8 @@ struct GoutRow {
 template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, int MODE, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    const T *__restrict__ attn, const T *__restrict__ gout2, T *__restrict__ gsrc, T *__restrict__ gflow,
+    const T *__restrict__ attn, const T *__restrict__ gout2, T *__restrict__ gsrc,
+    typename Num<T>::acc *__restrict__ gflow,  // a reduction over channel groups: float even for bf16 storage
     int C, int Hs, int Ws, int Hf, int Wf, int G, int ngroups, int split, int per, int margin, int64_t u_cs,
     int64_t u_bs, const unsigned *__restrict__ skip_stat, unsigned skip_limit) {
   using A = typename Num<T>::acc;
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
       }
     }
     if (NEED_FLOW) {
-      atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, (T)gx_acc);
-      atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, (T)gy_acc);
+      atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, gx_acc);
+      atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, gy_acc);
     }
   }
   if (NEED_SRC) {
@@ -297,15 +298,16 @@ __global__ __launch_bounds__(kLdsThreads) void be_bwd_lds_kernel(
 // planes do not fit in LDS.
 template <typename T, int K>
 static int launch_be_bwd_lds(int mode, const T *src, const T *flow, const T *gout, const T *attn, T *gsrc,
-                             T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                             typename Num<T>::acc *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                              hipStream_t stream, bool *done, int64_t u_cs = 0, int64_t u_bs = 0,
                              const T *gout2 = nullptr, const unsigned *skip_stat = nullptr, unsigned skip_limit = 0) {
   using A = typename Num<T>::acc;
   *done = false;
   const int bytes = (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(A) : 0);
   // the factored / unfold forms are only produced for planes that fit; the tensor form may window
-  PlaneGeo g = mode == kGoutTensor ? lds_geometry(Hs, Ws, bytes, B, C, Hf, Wf, K + 3, 1)
-                                   : plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, true, 1);
+  constexpr bool kBf16 = sizeof(T) == 2;  // bf16 storage: whole planes, one owner per plane (no atomics on the planes)
+  PlaneGeo g = (mode == kGoutTensor && !kBf16) ? lds_geometry(Hs, Ws, bytes, B, C, Hf, Wf, K + 3, 1)
+                                               : plane_geometry(Hs * Ws, bytes, B, C, Hf * Wf, !kBf16, 1);
   if (g.G == 0) return GFLA_OK;
   const int64_t blocks = B * g.ngroups * g.split;
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;

@@ -377,14 +377,18 @@ __global__ __launch_bounds__(kBlock) void be_bwd_elem_kernel(
 }
 
 template <typename T, int K>
-static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
-                          int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, typename Num<T>::acc *gflow,
+                          int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                           hipStream_t stream) {
-  if (tuning(2) != 1) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  if (tuning(2) != 1 || kBf16) {
     bool done = false;
     int st = launch_be_bwd_lds<T, K>(kGoutTensor, src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
     if (done || st != GFLA_OK) return st;
   }
+  if constexpr (kBf16) {
+    return GFLA_ERR_UNSUPPORTED;  // bf16 storage: the planes-in-LDS kernel only (global atomics need f32 / f64)
+  } else {
   const int64_t sp_blocks = ceil_div(Hf * Wf, kBlock);
   int cpt = tuning(1) > 0 ? tuning(1) : pick_channels_per_thread(sp_blocks * kBlock, C, B, 16, 2 * kNumCU * kWavesPerCU);
   if (cpt > C) cpt = (int)C;
@@ -395,11 +399,12 @@ static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, T
                      flow, gout, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, cpt,
                      (int)ncg, (int)sp_blocks);
   return launch_status();
+  }
 }
 
 template <typename T>
-static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
-                               int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gsrc, typename Num<T>::acc *gflow,
+                               int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
                                gfla_stream_t stream_) {
   if (!src || !flow || !gout) return GFLA_ERR_NULL_POINTER;
   if (B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || Hf <= 0 || Wf <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
@@ -413,12 +418,16 @@ static int block_extractor_bwd(const T *src, const T *flow, const T *gout, T *gs
     case 5: return launch_bwd_pix<T, 5>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream);
     default: break;
   }
-  const int64_t n = B * C * (k * Hf) * (k * Wf);
-  const int64_t blocks = ceil_div(n, kBlock);
-  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((be_bwd_elem_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, flow,
-                     gout, gsrc, gflow, n, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
-  return launch_status();
+  if constexpr (sizeof(T) == 2) {
+    return GFLA_ERR_UNSUPPORTED;
+  } else {
+    const int64_t n = B * C * (k * Hf) * (k * Wf);
+    const int64_t blocks = ceil_div(n, kBlock);
+    if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((be_bwd_elem_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src, flow,
+                       gout, gsrc, gflow, n, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
+    return launch_status();
+  }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -579,9 +588,9 @@ static int block_extractor_unfold_fwd(const T *src, const T *flow, T *out, int64
 }
 
 template <typename T>
-static int block_extractor_unfold_bwd(const T *src, const T *flow, const T *gout, T *gsrc, T *gflow, int64_t B,
-                                      int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
-                                      int layout, gfla_stream_t stream_) {
+static int block_extractor_unfold_bwd(const T *src, const T *flow, const T *gout, T *gsrc,
+                                      typename Num<T>::acc *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                                      int64_t Hf, int64_t Wf, int k, int layout, gfla_stream_t stream_) {
   using A = typename Num<T>::acc;
   if (!src || !flow || !gout) return GFLA_ERR_NULL_POINTER;
   int st = unfold_check(B, C, Hs, Ws, Hf, Wf, k, sizeof(lds_acc_t) + sizeof(A));
@@ -624,6 +633,15 @@ int gfla_block_extractor_bwd_f32(const float *s, const float *f, const float *go
                                  int64_t Wf, int k, gfla_stream_t st) {
   return gfla::block_extractor_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, st);
 }
+/* bf16 storage: grad_source bf16 (accumulated into, exclusive owner per plane); grad_flow FLOAT32 -- a sum over all
+ * channels and taps, accumulated across channel groups with atomics */
+int gfla_block_extractor_bwd_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *go, uint16_t *gs, float *gf,
+                                  int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k,
+                                  gfla_stream_t st) {
+  return gfla::block_extractor_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
+                                           reinterpret_cast<const bf16_t *>(go), reinterpret_cast<bf16_t *>(gs), gf, B, C,
+                                           Hs, Ws, Hf, Wf, k, st);
+}
 int gfla_block_extractor_bwd_f64(const double *s, const double *f, const double *go, double *gs,
                                  double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
                                  int64_t Hf, int64_t Wf, int k, gfla_stream_t st) {
@@ -654,6 +672,13 @@ int gfla_block_extractor_unfold_bwd_f32(const float *s, const float *f, const fl
                                         int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                                         int k, int layout, gfla_stream_t st) {
   return gfla::block_extractor_unfold_bwd<float>(s, f, go, gs, gf, B, C, Hs, Ws, Hf, Wf, k, layout, st);
+}
+int gfla_block_extractor_unfold_bwd_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *go, uint16_t *gs,
+                                         float *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                         int64_t Wf, int k, int layout, gfla_stream_t st) {
+  return gfla::block_extractor_unfold_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
+                                                  reinterpret_cast<const bf16_t *>(go), reinterpret_cast<bf16_t *>(gs), gf,
+                                                  B, C, Hs, Ws, Hf, Wf, k, layout, st);
 }
 int gfla_block_extractor_unfold_bwd_f64(const double *s, const double *f, const double *go, double *gs,
                                         double *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,

@@ -17,6 +17,14 @@ constexpr int kWavesPerCU = 32;
 // f32 and bf16 storage compute in float (the reference's float instantiation), f64 in double.
 struct bf16_t {
   uint16_t bits;
+  bf16_t() = default;
+  // (T)x in the shared templates: round-to-nearest-even conversion (defined below, after Num<bf16_t>)
+  __host__ __device__ explicit bf16_t(float v);
+  static __host__ __device__ __forceinline__ bf16_t from_bits(uint16_t b) {
+    bf16_t r;
+    r.bits = b;
+    return r;
+  }
 };
 
 template <typename T>
@@ -39,14 +47,16 @@ struct Num<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t *p) {
     return __uint_as_float(static_cast<uint32_t>(p->bits) << 16);
   }
-  static __device__ __forceinline__ uint16_t pack(float v) {  // round-to-nearest-even
-    uint32_t u = __float_as_uint(v);
+  static __host__ __device__ __forceinline__ uint16_t pack(float v) {  // round-to-nearest-even
+    uint32_t u;
+    __builtin_memcpy(&u, &v, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x0040u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return static_cast<uint16_t>(u >> 16);
   }
-  static __device__ __forceinline__ bf16_t from(float v) { return bf16_t{pack(v)}; }
+  static __device__ __forceinline__ bf16_t from(float v) { return bf16_t::from_bits(pack(v)); }
 };
+__host__ __device__ inline bf16_t::bf16_t(float v) : bits(Num<bf16_t>::pack(v)) {}
 
 // Vector of V storage elements written with ONE store instruction (V*sizeof(T) in {4,8,16}).
 template <typename T, int V>
@@ -70,6 +80,11 @@ __device__ __forceinline__ void atomic_add(float *p, float v) {
 __device__ __forceinline__ void atomic_add(double *p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// bf16 storage has no atomic add.  The bf16 backward entry points only exist for the "planes in LDS" kernels, where
+// feature-map gradients leave through an exclusive read-modify-write and every cross-workgroup reduction (flow,
+// logits, (dx,dy,sigma)) targets a float32 buffer; the host side returns GFLA_ERR_UNSUPPORTED for anything else.
+// This overload only lets the shared templates compile.
+__device__ __forceinline__ void atomic_add(bf16_t *, bf16_t) { __builtin_trap(); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -403,8 +403,8 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
 template <typename T, int K>
 __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout,
-    T *__restrict__ glogits, const T *__restrict__ attn, T *__restrict__ gflow, int C, int Hs, int Ws, int H,
-    int W, int G, int nsuper, int CS, int ntiles, int total) {
+    typename Num<T>::acc *__restrict__ glogits, const T *__restrict__ attn, typename Num<T>::acc *__restrict__ gflow,
+    int C, int Hs, int Ws, int H, int W, int G, int nsuper, int CS, int ntiles, int total) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
   const A inv_kk = (A)1 / (A)KK;
   const int cs0 = sg * CS;
   const int cs1 = min(C, cs0 + CS);
-  T *gl = glogits ? glogits + (int64_t)b * KK * HW + pc : nullptr;
+  A *gl = glogits ? glogits + (int64_t)b * KK * HW + pc : nullptr;
   // d/d flow (block_extractor_kernel.cu:163-164) is linear in the same patch sums P, weighted by the attention:
   // computed here when asked for (attn, gflow non-NULL), one atomic pair per pixel and channel super-group
   const T *at = attn ? attn + (int64_t)b * KK * HW + pc : nullptr;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
             bs += (xR_P * yT_P) * vTR;
             bs += (xL_P * yB_P) * vBL;
             bs += (xR_P * yB_P) * vBR;
-            if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)(go * bs));
+            if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, go * bs);
             if (gflow) {
               const A gv = Num<T>::ld(at + (int64_t)(i * K + j) * HW) * go;
               gy_acc += gv * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
         ga += (xR_P * yT_P) * P[i * (K + 1) + j + 1];
         ga += (xL_P * yB_P) * P[(i + 1) * (K + 1) + j];
         ga += (xR_P * yB_P) * P[(i + 1) * (K + 1) + j + 1];
-        if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, (T)ga);
+        if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, ga);
         if (gflow) {
           const A a_ij = Num<T>::ld(at + (int64_t)(i * K + j) * HW);
           const A pTL = P[i * (K + 1) + j], pTR = P[i * (K + 1) + j + 1];
@@ -522,15 +522,16 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     }
   }
   if (active && gflow) {
-    atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, (T)gx_acc);
-    atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, (T)gy_acc);
+    atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, gx_acc);
+    atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, gy_acc);
   }
 }
 
 // In place: glogits holds ga (d/d a_ij); turn it into d/d logit_ij = a_ij * (ga_ij - sum_mn a_mn ga_mn).
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void agg_softmax_bwd_kernel(const T *__restrict__ attn,
-                                                                T *__restrict__ glogits, int64_t n, int HW) {
+                                                                typename Num<T>::acc *__restrict__ glogits, int64_t n,
+                                                                int HW) {
   using A = typename Num<T>::acc;
   constexpr int KK = K * K;
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // over (b, p)
@@ -538,17 +539,17 @@ __global__ __launch_bounds__(kBlock) void agg_softmax_bwd_kernel(const T *__rest
   const int64_t b = idx / HW;
   const int p = (int)(idx - b * HW);
   const T *at = attn + b * KK * HW + p;
-  T *gl = glogits + b * KK * HW + p;
+  A *gl = glogits + b * KK * HW + p;
   A a[KK], ga[KK];
   A dot = 0;
 #pragma unroll
   for (int t = 0; t < KK; ++t) {
     a[t] = Num<T>::ld(at + (int64_t)t * HW);
-    ga[t] = Num<T>::ld(gl + (int64_t)t * HW);
+    ga[t] = gl[(int64_t)t * HW];
     dot += a[t] * ga[t];
   }
 #pragma unroll
-  for (int t = 0; t < KK; ++t) gl[(int64_t)t * HW] = Num<T>::from(a[t] * (ga[t] - dot));
+  for (int t = 0; t < KK; ++t) gl[(int64_t)t * HW] = a[t] * (ga[t] - dot);
 }
 
 struct AggGeo {
@@ -610,8 +611,8 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
 
 // (2) d/d a_ij [+ d/d flow when gflow != NULL], then (3) the softmax Jacobian in place
 template <typename T>
-static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *gout, T *glogits, T *gflow, int64_t B,
-                         int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm, hipStream_t stream) {
+static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *gout, typename Num<T>::acc *glogits,
+                         typename Num<T>::acc *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm, hipStream_t stream) {
   using A = typename Num<T>::acc;
   const int threads = 512;
   const int64_t ntiles = ceil_div(H * W, threads);
@@ -643,8 +644,8 @@ static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *go
 // All three outputs are ACCUMULATED into (the caller zeroes them, or passes partial gradients to add to).
 // workspace (gfla_scatter_workspace_bytes, may be NULL): enables the matrix-core scatter for d/d source (f32).
 template <typename T>
-static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *gout, T *gsrc, T *gflow,
-                         T *glogits, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W,
+static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *gout, T *gsrc,
+                         typename Num<T>::acc *gflow, typename Num<T>::acc *glogits, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W,
                          int k, int sm, gfla_stream_t stream_, void *workspace = nullptr) {
   if (!src || !flow || !attn || !gout) return GFLA_ERR_NULL_POINTER;
   int st = agg_check(B, C, Hs, Ws, H, W, k);
@@ -666,7 +667,7 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
       if (st == GFLA_OK) {
         if (lds_fallback && skip_limit != 0xffffffffu) {
           bool done = false;
-          GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutAttn, src, flow, gout, attn, gsrc, (T *)nullptr, B, C, Hs, Ws, H, W,
+          GFLA_K_SWITCH(k, st = launch_be_bwd_lds<T, K>(kGoutAttn, src, flow, gout, attn, gsrc, (A *)nullptr, B, C, Hs, Ws, H, W,
                                                         stream, &done, 0, 0, (const T *)nullptr, skip_stat, skip_limit));
           if (st != GFLA_OK) return st;
           if (!done) return GFLA_ERR_UNSUPPORTED;
@@ -685,13 +686,17 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
       if (st != GFLA_OK) return st;
       if (!done) return GFLA_ERR_UNSUPPORTED;
     }
-    if (glogits) st = launch_agg_ga<T>(src, flow, attn, gout, glogits, (T *)nullptr, B, C, Hs, Ws, H, W, k, sm, stream);
+    if (glogits) st = launch_agg_ga<T>(src, flow, attn, gout, glogits, (A *)nullptr, B, C, Hs, Ws, H, W, k, sm, stream);
     return st;
   }
-  AggGeo g = agg_geometry(B, C, H, W, 32, 2 * kNumCU * kWavesPerCU);
-  if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  GFLA_K_SWITCH(k, agg_bwd_kernel<T, K><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, g.cpt, g.ncg, g.sp_blocks));
-  return launch_status();
+  if constexpr (sizeof(T) == 2) {
+    return GFLA_ERR_UNSUPPORTED;  // bf16 storage: the planes-in-LDS kernels only
+  } else {
+    AggGeo g = agg_geometry(B, C, H, W, 32, 2 * kNumCU * kWavesPerCU);
+    if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+    GFLA_K_SWITCH(k, agg_bwd_kernel<T, K><<<dim3((unsigned)g.blocks), dim3(kBlock), 0, stream>>>(src, flow, attn, gout, gsrc, gflow, glogits, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, g.cpt, g.ncg, g.sp_blocks));
+    return launch_status();
+  }
 }
 
 // Backward of everything in ExtractorAttn that flows into block_source(source, flow): the gradient of
@@ -699,7 +704,7 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
 // (attn, grad_out; may be NULL), scattered into grad_source / grad_flow in one pass.
 template <typename T>
 static int local_attn_source_bwd(const T *src, const T *flow, const T *gunf, const T *attn, const T *gout,
-                                 T *gsrc, T *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                 T *gsrc, typename Num<T>::acc *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
                                  int64_t W, int k, int layout, gfla_stream_t stream_) {
   using A = typename Num<T>::acc;
   if (!src || !flow || (!gunf && !(attn && gout)) || ((attn == nullptr) != (gout == nullptr))) return GFLA_ERR_NULL_POINTER;
@@ -751,6 +756,15 @@ int gfla_local_attn_aggregate_bwd_ws_f32(const float *s, const float *f, const f
                                          int64_t Ws, int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
   return gfla::aggregate_bwd<float>(s, f, a, go, gs, gf, gl, B, C, Hs, Ws, H, W, k, sm, st, workspace);
 }
+/* bf16 storage: grad_source bf16; grad_flow and grad_logits FLOAT32 (reductions over channels, accumulated across
+ * workgroups) */
+int gfla_local_attn_aggregate_bwd_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *a, const uint16_t *go,
+                                       uint16_t *gs, float *gf, float *gl, int64_t B, int64_t C, int64_t Hs,
+                                       int64_t Ws, int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
+  return gfla::aggregate_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
+                                     reinterpret_cast<const bf16_t *>(a), reinterpret_cast<const bf16_t *>(go),
+                                     reinterpret_cast<bf16_t *>(gs), gf, gl, B, C, Hs, Ws, H, W, k, sm, st);
+}
 int gfla_local_attn_aggregate_bwd_f64(const double *s, const double *f, const double *a, const double *go,
                                       double *gs, double *gf, double *gl, int64_t B, int64_t C,
                                       int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm,
@@ -761,6 +775,14 @@ int gfla_local_attn_source_bwd_f32(const float *s, const float *f, const float *
                                    float *gs, float *gf, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
                                    int64_t W, int k, int layout, gfla_stream_t st) {
   return gfla::local_attn_source_bwd<float>(s, f, gu, a, go, gs, gf, B, C, Hs, Ws, H, W, k, layout, st);
+}
+int gfla_local_attn_source_bwd_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *gu, const uint16_t *a,
+                                    const uint16_t *go, uint16_t *gs, float *gf, int64_t B, int64_t C, int64_t Hs,
+                                    int64_t Ws, int64_t H, int64_t W, int k, int layout, gfla_stream_t st) {
+  return gfla::local_attn_source_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
+                                             reinterpret_cast<const bf16_t *>(gu), reinterpret_cast<const bf16_t *>(a),
+                                             reinterpret_cast<const bf16_t *>(go), reinterpret_cast<bf16_t *>(gs), gf, B, C,
+                                             Hs, Ws, H, W, k, layout, st);
 }
 int gfla_local_attn_source_bwd_f64(const double *s, const double *f, const double *gu, const double *a,
                                    const double *go, double *gs, double *gf, int64_t B, int64_t C, int64_t Hs,

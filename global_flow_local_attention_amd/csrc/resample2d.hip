@@ -249,9 +249,17 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_kernel(const T *__restrict__ i
 // ---- LDS-plane kernels: workgroup <-> (b, group of G channels[, 1/split of the pixels]) ----------
 // MODE 0 forward (source planes staged), 1 d/d input1 (gradient planes accumulated in LDS, flushed
 // once), 2 d/d input2 (source planes staged, three atomics per lane and group).
+// element type of what a mode writes: the warped map / the input1 gradient in the storage type; the (dx, dy, sigma)
+// gradient -- a reduction over channel groups, accumulated with atomics -- in the arithmetic type (float for bf16)
+template <typename T, int MODE>
+struct RsOut {
+  using type = typename std::conditional<MODE == 2, typename Num<T>::acc, T>::type;
+};
+
 template <typename T, int KH, int MODE, bool WIN>
 __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
-                                                            const T *__restrict__ gout, T *__restrict__ outp,
+                                                            const T *__restrict__ gout,
+                                                            typename RsOut<T, MODE>::type *__restrict__ outp,
                                                             int C, int Hi, int Wi, int H, int W, int dil,
                                                             int trunc, int G, int ngroups, int split, int per,
                                                             int margin, const unsigned *__restrict__ skip_stat,
@@ -320,10 +328,10 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
         rs_bwd2_pixel<T, A, KH, A>(t, planes0, win_sz, go, HW, gc, rx, ry, rs);
       else
         rs_bwd2_pixel<T, T, KH, A>(t, in1_0, plane_sz, go, HW, gc, rx, ry, rs);
-      T *o = outp + (int64_t)b * 3 * HW + p;
-      atomic_add(o, (T)rx);
-      atomic_add(o + HW, (T)ry);
-      atomic_add(o + 2 * HW, (T)rs);
+      A *o = outp + (int64_t)b * 3 * HW + p;
+      atomic_add(o, rx);
+      atomic_add(o + HW, ry);
+      atomic_add(o + 2 * HW, rs);
     }
   }
   if constexpr (MODE == 1) {
@@ -392,7 +400,7 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
 }
 
 template <typename T>
-static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T *gin2, int64_t B,
+static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, typename Num<T>::acc *gin2, int64_t B,
                           int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int dil,
                           int trunc, gfla_stream_t stream_, const unsigned *skip_stat = nullptr,
                           unsigned skip_limit = 0) {
@@ -401,9 +409,12 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
   if (!gout) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
-  PlaneGeo pg1 = lds_geometry(Hi, Wi, sizeof(lds_acc_t), B, C, H, W, (k - 1) * dil + 1);  // double scatter planes
+  constexpr bool kBf16 = sizeof(T) == 2;
+  // double scatter planes.  bf16 storage: whole planes, one owner each (the flush is a plain read-modify-write)
+  PlaneGeo pg1 = kBf16 ? plane_geometry(Hi * Wi, sizeof(lds_acc_t), B, C, H * W, false)
+                       : lds_geometry(Hi, Wi, sizeof(lds_acc_t), B, C, H, W, (k - 1) * dil + 1);
   PlaneGeo pg2 = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1);          // gather planes
-  if (tuning(6) != 1 && pg1.G > 0 && pg2.G > 0) {
+  if ((tuning(6) != 1 || kBf16) && pg1.G > 0 && pg2.G > 0) {
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -421,6 +432,9 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
     }
     return st;
   }
+  if constexpr (kBf16) {
+    return GFLA_ERR_UNSUPPORTED;  // bf16 storage: the planes-in-LDS kernels only
+  } else {
   if (gin1) {
     Geo g = geometry(B, C, H, W, 16, 4 * kNumCU * kWavesPerCU);
     if (g.blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -435,6 +449,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, T 
     st = launch_status();
   }
   return st;
+  }
 }
 
 }  // namespace gfla
@@ -489,6 +504,14 @@ int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, 
     if (!g1 && !g2) return GFLA_OK;
   }
   return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st, skip_stat, skip_limit);
+}
+/* bf16 storage: grad_in1 bf16; grad_in2 (B,3,H,W) FLOAT32 (a reduction over the channels) */
+int gfla_resample2d_bwd_bf16(const uint16_t *a, const uint16_t *b, const uint16_t *go, uint16_t *g1, float *g2, int64_t B,
+                             int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int d, int trunc,
+                             gfla_stream_t st) {
+  return gfla::resample2d_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(a), reinterpret_cast<const bf16_t *>(b),
+                                      reinterpret_cast<const bf16_t *>(go), reinterpret_cast<bf16_t *>(g1), g2, B, C, Hi,
+                                      Wi, H, W, k, d, trunc, st);
 }
 int gfla_resample2d_bwd_f64(const double *a, const double *b, const double *go, double *g1, double *g2,
                             int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,

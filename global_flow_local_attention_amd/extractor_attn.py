@@ -95,10 +95,10 @@ class LocalAttnAggregateFunction(Function):
             link.park(attn, grad_out)
             ns = nf = False
         gs = torch.zeros_like(source) if ns else None
-        gf = torch.zeros_like(flow_field) if nf else None
-        gl = torch.zeros_like(attn) if nl else None
+        gf = _lib.reduction_like(flow_field) if nf else None  # float32 accumulators for bf16 storage
+        gl = _lib.reduction_like(attn) if nl else None
         if ns or nf or nl:
-            sfx = _lib.suffix(source, "local_attn_aggregate backward", allow_bf16=False)
+            sfx = _lib.suffix(source, "local_attn_aggregate backward")
             tail = (b, c, hs, ws, h, w, ctx.kernel_size, 1 if ctx.apply_softmax else 0)
             if sfx == "f32" and ns:  # d/d source as a block-sparse product on the matrix cores (csrc/patch_mfma.hip)
                 scratch = _lib.scatter_workspace(source, b, h, w, (ctx.kernel_size + 1) ** 2)
@@ -108,6 +108,10 @@ class LocalAttnAggregateFunction(Function):
             else:
                 _lib.call("gfla_local_attn_aggregate_bwd_" + sfx, source, _lib.ptr(source), _lib.ptr(flow_field),
                           _lib.ptr(attn), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl), *tail)
+        if gf is not None and gf.dtype != flow_field.dtype:
+            gf = gf.to(flow_field.dtype)
+        if gl is not None and gl.dtype != attn.dtype:
+            gl = gl.to(attn.dtype)
         return gs, gf, gl, None, None, None
 
 
@@ -145,7 +149,7 @@ class BlockExtractorUnfoldFunction(Function):
         _, _, h, w = flow_field.size()
         ns, nf = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gs = torch.zeros_like(source) if ns else None
-        gf = torch.zeros_like(flow_field) if nf else None
+        gf = _lib.reduction_like(flow_field) if nf else None
         link = ctx.link
         parked = None
         if link is not None:
@@ -153,13 +157,15 @@ class BlockExtractorUnfoldFunction(Function):
         if ns or nf:
             if parked is not None:  # FC-operand gradient + attention-aggregation gradient in one pass
                 attn, g_small = parked
-                _lib.call("gfla_local_attn_source_bwd_" + _lib.suffix(source, "local_attn_source backward", allow_bf16=False), source,
+                _lib.call("gfla_local_attn_source_bwd_" + _lib.suffix(source, "local_attn_source backward"), source,
                           _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(attn), _lib.ptr(g_small),
                           _lib.ptr(gs), _lib.ptr(gf), b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
             else:
-                _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward", allow_bf16=False),
+                _lib.call("gfla_block_extractor_unfold_bwd_" + _lib.suffix(source, "block_extractor_unfold backward"),
                           source, _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_out), _lib.ptr(gs), _lib.ptr(gf),
                           b, c, hs, ws, h, w, ctx.kernel_size, ctx.layout)
+        if gf is not None and gf.dtype != flow_field.dtype:
+            gf = gf.to(flow_field.dtype)
         return gs, gf, None, None, None
 
 

@@ -46,12 +46,12 @@ class Resample2dFunction(Function):
         input1, input2 = ctx.saved_tensors
         want1, want2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g1 = torch.zeros_like(input1) if want1 else None
-        g2 = torch.zeros_like(input2) if want2 else None
+        g2 = _lib.reduction_like(input2) if want2 else None  # float32 accumulator for bf16 storage
         grad_warped = grad_warped.contiguous()
         if (want1 or want2) and grad_warped.numel() > 0 and input1.numel() > 0:
             _, C, Hi, Wi = input1.shape
             B, _, H, W = input2.shape
-            sfx = _lib.suffix(input1, "resample2d backward", allow_bf16=False)
+            sfx = _lib.suffix(input1, "resample2d backward")
             entry = "gfla_resample2d_bwd_" + sfx
             tail = (B, C, Hi, Wi, H, W, ctx.kernel_size, ctx.dilation, 1 if TRUNC_COMPAT else 0)
             # two independent kernels (scatter into input1 / reduction for (dx, dy, sigma)): one C-ABI
@@ -67,6 +67,8 @@ class Resample2dFunction(Function):
             if want2:
                 _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
                           None, _lib.ptr(g2), *tail)
+        if g2 is not None and g2.dtype != input2.dtype:
+            g2 = g2.to(input2.dtype)
         return g1, g2, None, None
 
 

@@ -205,6 +205,31 @@ GFLA_DECL_AGGREGATE_BWD(f32, float)
 GFLA_DECL_AGGREGATE_BWD(f64, double)
 #undef GFLA_DECL_AGGREGATE_BWD
 
+
+/* bf16 storage for the backward entry points (mixed-precision features): feature-map gradients (grad_source,
+ * grad_in1) are bf16 and accumulated into like their f32 counterparts; every gradient that is a REDUCTION over channels
+ * -- grad_flow (B,2,H,W), grad_logits (B,k*k,H,W), grad_in2 (B,3,H,W) -- is float32 (accumulated across workgroups with
+ * float atomics; 8 mantissa bits would not survive C*k*k terms).  Planes must fit LDS (the attention-layer shapes do);
+ * anything else returns GFLA_ERR_UNSUPPORTED.  Accumulation is f32 / f64-in-LDS exactly as in the f32 entry points. */
+int gfla_block_extractor_bwd_bf16(const uint16_t *source, const uint16_t *flow, const uint16_t *grad_out,
+                                  uint16_t *grad_source, float *grad_flow, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                                  int64_t Hf, int64_t Wf, int kernel_size, gfla_stream_t stream);
+int gfla_block_extractor_unfold_bwd_bf16(const uint16_t *source, const uint16_t *flow, const uint16_t *grad_unfold,
+                                         uint16_t *grad_source, float *grad_flow, int64_t B, int64_t C, int64_t Hs,
+                                         int64_t Ws, int64_t Hf, int64_t Wf, int kernel_size, int layout,
+                                         gfla_stream_t stream);
+int gfla_local_attn_aggregate_bwd_bf16(const uint16_t *source, const uint16_t *flow, const uint16_t *attn,
+                                       const uint16_t *grad_out, uint16_t *grad_source, float *grad_flow,
+                                       float *grad_logits, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                       int64_t W, int kernel_size, int apply_softmax, gfla_stream_t stream);
+int gfla_local_attn_source_bwd_bf16(const uint16_t *source, const uint16_t *flow, const uint16_t *grad_unfold,
+                                    const uint16_t *attn, const uint16_t *grad_out, uint16_t *grad_source,
+                                    float *grad_flow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                    int64_t W, int kernel_size, int layout, gfla_stream_t stream);
+int gfla_resample2d_bwd_bf16(const uint16_t *in1, const uint16_t *in2, const uint16_t *grad_out, uint16_t *grad_in1,
+                             float *grad_in2, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+                             int kernel_size, int dilation, int trunc_compat, gfla_stream_t stream);
+
 /* ---- scatters as block-sparse products on the matrix cores (csrc/patch_mfma.hip) -----------------------------
  * The two backward passes that scatter into a feature plane -- the aggregation's d/d source and resample2d's
  * d/d input1 (resample2d_kernel.cu:98-202; replaces its atomicAdd scatter) -- spread each flow pixel's gradient over

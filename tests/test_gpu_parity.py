@@ -722,3 +722,82 @@ def test_fc_tail_matches_torch_ops(gfla, kernel_variant, dtype, KK, Hc, slope, b
         assert a.shape == b_.shape
         assert_close(a, b_, t * 10, "fc tail gradient")
 
+
+
+# ------------------------------------------------------------------------------ bf16 storage, backward (config 5)
+def _rel(got, want):
+    want = want.double()
+    return (got.double().cpu() - want).abs().max().item() / max(1e-30, want.abs().max().item())
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_bf16_backward_ops(gfla, oracle, k):
+    """bf16 storage for the backward entry points: bf16-rounded inputs through the f32 oracle, 2^-7 of the largest
+    entry (gradients leave as bf16 after f32 / f64-in-LDS accumulation; grad_flow / grad_logits accumulate in float32
+    inside the library and are cast at the end)."""
+    B, C, H, W = 2, 8, 16, 12
+    tol = 2 ** -7
+    s = randn((B, C, H, W), seed=171).bfloat16()
+    f = make_flow("coherent", B, H, W, seed=172).bfloat16()
+    sf, ff = s.float(), f.float()
+    # block_extractor (reference layout)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    out = gfla.BlockExtractor(k)(sd, fd)
+    g = randn(tuple(out.shape), seed=173).bfloat16()
+    out.backward(g.to(DEV))
+    gs, gf = oracle.block_extractor_bwd(sf, ff, g.float(), k)
+    assert sd.grad.dtype == torch.bfloat16 and fd.grad.dtype == torch.bfloat16
+    assert _rel(sd.grad.float(), gs) <= tol and _rel(fd.grad.float(), gf) <= tol
+    # unfold layout
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    unf = gfla.BlockExtractorUnfoldFunction.apply(sd, fd, k)
+    gu = _to_unfold(g.float(), k).bfloat16()
+    unf.backward(gu.to(DEV))
+    assert _rel(sd.grad.float(), gs) <= tol and _rel(fd.grad.float(), gf) <= tol
+    # softmax / aggregate: against autograd of the f32 composition on the oracle's extractor
+    lg = randn((B, k * k, H, W), seed=174).bfloat16()
+    go = randn((B, C, H, W), seed=175).bfloat16()
+    sd, fd, ld = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_(), lg.to(DEV).requires_grad_()
+    res, _ = gfla.LocalAttnAggregateFunction.apply(sd, fd, ld, k, True)
+    res.backward(go.to(DEV))
+    from oracle import cpu_modules
+    sc, fc, lc = sf.clone().requires_grad_(), ff.clone().requires_grad_(), lg.float().clone().requires_grad_()
+    bs = cpu_modules._BlockExtractorCPU.apply(sc, fc, k)
+    want = F.avg_pool2d(F.pixel_shuffle(torch.softmax(lc, 1), k) * bs, k, k)
+    want.backward(go.float())
+    assert sd.grad.dtype == fd.grad.dtype == ld.grad.dtype == torch.bfloat16
+    assert _rel(sd.grad.float(), sc.grad) <= tol, "aggregate grad source"
+    assert _rel(fd.grad.float(), fc.grad) <= tol, "aggregate grad flow"
+    assert _rel(ld.grad.float(), lc.grad) <= tol, "aggregate grad logits"
+    # resample2d
+    i1 = randn((B, C, H, W), seed=176).bfloat16()
+    i1d, fd = i1.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    w = gfla.Resample2d(4, 1, 2)(i1d, fd)
+    gw = randn((B, C, H, W), seed=177).bfloat16()
+    w.backward(gw.to(DEV))
+    i2 = torch.cat((ff, torch.full((B, 1, H, W), 2.0)), 1).contiguous()
+    g1, g2 = oracle.resample2d_bwd(i1.float(), i2, gw.float(), 4, 1)
+    assert i1d.grad.dtype == torch.bfloat16 and fd.grad.dtype == torch.bfloat16
+    assert _rel(i1d.grad.float(), g1) <= tol, "resample grad input1"
+    assert _rel(fd.grad.float(), g2[:, :2]) <= tol, "resample grad flow"
+
+
+def test_bf16_backward_at_bench_shape(gfla, oracle):
+    """The same at one attention-layer shape of the bench (one plane per workgroup, 256 channel groups): sample slice
+    against the f32 oracle."""
+    B, C, H, W, k = 4, 256, 32, 22, 3
+    s = randn((B, C, H, W), seed=181).bfloat16()
+    f = make_flow("smooth", B, H, W, seed=182).bfloat16()
+    lg = randn((B, k * k, H, W), seed=183).bfloat16()
+    go = randn((B, C, H, W), seed=184).bfloat16()
+    sd, fd, ld = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_(), lg.to(DEV).requires_grad_()
+    res, _ = gfla.LocalAttnAggregateFunction.apply(sd, fd, ld, k, True)
+    res.backward(go.to(DEV))
+    from oracle import cpu_modules
+    sc, fc, lc = s.float().requires_grad_(), f.float().requires_grad_(), lg.float().requires_grad_()
+    bs = cpu_modules._BlockExtractorCPU.apply(sc, fc, k)
+    want = F.avg_pool2d(F.pixel_shuffle(torch.softmax(lc, 1), k) * bs, k, k)
+    want.backward(go.float())
+    assert _rel(res.float(), want.detach()) <= 2 ** -7
+    for got, ref, nm in ((sd.grad, sc.grad, "source"), (fd.grad, fc.grad, "flow"), (ld.grad, lc.grad, "logits")):
+        assert _rel(got.float(), ref) <= 2 ** -7, nm
