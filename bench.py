@@ -130,9 +130,86 @@ class HotPath:
         return outs
 
 
+FACE_LAYERS = (  # (name, C, H, W, k): FaceGenerator at 256x256, layers=3, ngf=64 (generator.py:388-505)
+    ("attn3", 256, 32, 32, 3),
+    ("attn2", 128, 64, 64, 5),
+)
+
+
+class FacePath:
+    """BASELINE config 5 (configs[4]): the hot path as FaceTargetNet runs it (generator.py:468-499) -- TWO ExtractorAttn
+    per attention layer (previous frame / reference frame), blended into the decoder features by their masks -- for
+    `frames` sequentially generated frames of each clip (generator.py:402-426), bf16 features.  Storage is bf16 end to
+    end; the FC layers run in arithmetic mode 1 (one f16 term per operand: exact for bf16 values, f32 accumulation)."""
+
+    def __init__(self, B, device, seed, frames=6):
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.B, self.device, self.frames = B, device, frames
+        bf = torch.bfloat16
+        torch.manual_seed(1234)
+        self.attn = [tuple(gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(device) for _ in range(2))
+                     for (_, C, H, W, k) in FACE_LAYERS]
+        self.inputs = []
+        for _ in range(frames):
+            per = []
+            for (_, C, H, W, k) in FACE_LAYERS:
+                feat = lambda: torch.randn(B, C, H, W, device=device, generator=gen).to(bf).requires_grad_()
+                prev, ref, dec = feat(), feat(), feat()
+                flows = [smooth_flow(B, H, W, device, gen).to(bf).requires_grad_() for _ in range(2)]
+                masks = [torch.rand(B, 1, H, W, device=device, generator=gen).to(bf) for _ in range(2)]
+                per.append((prev, ref, dec, flows, masks))
+            self.inputs.append(per)
+        self.upstream = None
+        self.reducer = None
+
+    images_per_step = property(lambda self: self.B * self.frames)
+
+    def params(self):
+        return [p for pair in self.attn for m in pair for p in m.parameters()]
+
+    def leaves(self):
+        return [t for per in self.inputs for (prev, ref, dec, flows, _) in per for t in (prev, ref, dec, *flows)]
+
+    def step(self, resample=None, allreduce=True):
+        outs = []
+        for per in self.inputs:  # frames are generated one after the other
+            for (attn_p, attn_r), (prev, ref, dec, flows, masks) in zip(self.attn, per):
+                out_p = dec * (1 - masks[0]) + attn_p(prev, dec, flows[0]) * masks[0]
+                out_r = dec * (1 - masks[1]) + attn_r(ref, dec, flows[1]) * masks[1]
+                outs.append(out_p + out_r)
+        if self.upstream is None:
+            gen = torch.Generator(device=outs[0].device).manual_seed(4321)
+            self.upstream = [(torch.randn(o.shape, device=o.device, generator=gen) / o[0].numel()).to(o.dtype) for o in outs]
+        for t in self.leaves() + self.params():
+            t.grad = None
+        if allreduce and self.reducer is None:
+            self.reducer = gdist.GradBucketReducer(self.params())
+        torch.autograd.backward(outs, self.upstream)
+        if allreduce:
+            self.reducer.finish()
+        return outs
+
+    def describe(self, args, world):
+        return {
+            "metric": "frames/sec (fwd+bwd) FaceGenerator 256x256 attn_layer=2,3, bf16 features -- feature-warping hot path",
+            "dtype": "bf16 storage; f16 MFMA operands (exact for bf16 values) with f32 accumulation in the FC layers, f32 "
+                     "arithmetic elsewhere",
+            "config": {"workload": "GFLA hot path at FaceGenerator 256x256 shapes (BASELINE configs[4]): per generated "
+                                   "frame, attn_p + attn_r ExtractorAttn at L3 (C256,32x32,k3) and L2 (C128,64x64,k5) "
+                                   "fwd+bwd incl. both FC layers and the mask blend of FaceTargetNet.forward; %d frames "
+                                   "generated sequentially per clip" % self.frames,
+                       "clips_per_gpu": self.B, "frames_per_clip": self.frames,
+                       "batch_per_gpu": self.B * self.frames, "global_batch": self.B * self.frames * world,
+                       "parallelism": "dp%d (clips sharded; ExtractorAttn gradients all-reduced in one flat bucket launched "
+                                      "from autograd hooks)" % world,
+                       "fc_layers": "this library's MFMA kernels, arithmetic mode 1 (one f16 term per operand)"}}
+
+
 # ---- algorithmic bytes per C-ABI call (SURVEY.md section 8d; 4 bytes per fp32 element) -------
-def algorithmic_bytes(name, a, esz=4):
-    base = name.rsplit("_", 1)[0]
+def algorithmic_bytes(name, a, esz=None):
+    base, suffix = name.rsplit("_", 1)
+    if esz is None:  # bf16 entries: 2 bytes per element (their float32 reduction outputs are counted at 2 as well)
+        esz = {"bf16": 2, "f64": 8}.get(suffix, 4)
     if base == "gfla_block_extractor_unfold_fwd":
         base, a = "gfla_block_extractor_fwd", a[:10]
     if base == "gfla_block_extractor_unfold_bwd":
@@ -481,6 +558,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
     (tests/test_dist_cpu.py): a typo must not burn the one multi-GPU hardware run."""
     hp = make_hotpath(args.fc_mode)
     resample = make_resample()
+    face = getattr(args, "workload", "pose") == "face_bf16"
+    images = getattr(hp, "images_per_step", args.batch)
 
     def barrier():
         if world > 1:
@@ -489,7 +568,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             torch.cuda.synchronize()
 
     check = None
-    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline and not face:
         check = oracle_check(hp, resample)  # asserts; before anything is timed
     hp.step(resample)  # priming step: lazy initialisation, never timed
     # (Capturing the whole step -- forward + backward, ~90 launches -- into one hipGraph was measured and dropped: 7.146 ms
@@ -504,11 +583,11 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             for _ in range(args.steps):
                 hp.step(resample)
         rows = kt.summary()
-        if args.fc_impl == "mfma":
+        if args.fc_impl == "mfma" and not face:
             probes = fc_kernel_probes(hp)
 
     variants = {}
-    if on_gpu and args.fc_impl == "mfma" and not args.no_variants:
+    if on_gpu and args.fc_impl == "mfma" and not args.no_variants and not face:
         for mode, label in ((3, "fc_mode3_f16x3_split"), (2, "fc_mode2_f16x2_split")):
             if mode == args.fc_mode:
                 continue
@@ -547,6 +626,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         "kernels": rows,
         "fc_kernels": probes,
     }
+    if face:
+        line.update(hp.describe(args, world))
+        line["value"] = round(images * world * args.steps / elapsed, 2)
+        line["unit"] = "frames/s"
     if probes:
         # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
         # with the longest launch
@@ -567,6 +650,11 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         line["roofline"] = {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["GBps"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"], "avg_us": dom["avg_us"],
                             "alg_MB_per_launch": dom["alg_MB"], "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"])}
+        if "alg_GFLOP" in dom:  # an FC-layer entry: several kernels (packing, MFMA contraction, sampling tails) per call
+            line["roofline"].update({"alg_GFLOP_per_call": dom["alg_GFLOP"], "TFLOPs": dom["TFLOPs"],
+                                     "note": "whole C-ABI call, not one kernel: in arithmetic mode 1 the MFMA contraction "
+                                             "runs at the f16 rate and the call is bound by the HBM traffic of its packing "
+                                             "/ sampling / reduction kernels; bytes = operands + results of the call"})
     if variants:
         line["variants"] = variants
     if check is not None:
@@ -591,7 +679,12 @@ def parse_args(argv=None):
                          "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
     ap.add_argument("--fc-impl", choices=("mfma", "library"), default="mfma",
                     help="FC layers of ExtractorAttn: this library's MFMA kernels (default) or round 1's vendor GEMM/conv path")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
+    ap.add_argument("--workload", choices=("pose", "face_bf16"), default="pose",
+                    help="pose: the headline (BASELINE metric, PoseGenerator 256x176 shapes, f32).  face_bf16: BASELINE "
+                         "configs[4] -- FaceGenerator 256x256 shapes, two ExtractorAttn per layer, 6 sequential frames, "
+                         "bf16 features; --batch is then clips per GPU")
+    ap.add_argument("--frames", type=int, default=6, help="face_bf16: frames generated per clip")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3), default=0,
                     help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
                          "f16 terms per operand with f32 accumulation (labelled experiments)")
     ap.add_argument("--with-losses", action="store_true",
@@ -624,6 +717,8 @@ def main():
         gfla.enable_gemm_tuning(os.path.join(tune_dir, "gfla_tunableop_rank%d.csv" % rank))
 
     def make_hotpath(fc_mode):
+        if args.workload == "face_bf16":
+            return FacePath(args.batch, device, seed=100 + rank, frames=args.frames)
         return HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
                        fc_mode=fc_mode, with_losses=args.with_losses)
 

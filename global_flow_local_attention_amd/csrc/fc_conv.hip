@@ -15,6 +15,8 @@ int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *
   if (Wv <= 0 || Wv > Wp || !fc_conv_fits(Wv, Wp, k, mode)) return GFLA_ERR_UNSUPPORTED;
   if (mode == 0)
     return fc_conv_mode<0>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, k, amax_x, amax_w, stream);
+  if (mode == 1)
+    return fc_conv_mode<1>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, k, amax_x, amax_w, stream);
   if (mode == 2)
     return fc_conv_mode<2>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, k, amax_x, amax_w, stream);
   return fc_conv_mode<3>(X, wk, w_split_stride, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, k, amax_x, amax_w, stream);

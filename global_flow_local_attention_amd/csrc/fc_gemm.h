@@ -23,11 +23,18 @@ constexpr int kFcHidden = 128; // hidden_nc of ExtractorAttn (base_function.py:7
 //      result is f32-grade or better at 2.67x the f32 MFMA rate.
 //   2: two f16 terms, 3 cross products: per-product error 2^-21 -- far below the f32 accumulation
 //      error of a K = 2304..3200 dot product -- at 5.3x the f32 MFMA rate.
+//   1: ONE f16 term per operand (round to 11 significant bits after the power-of-two scaling): exact for operands
+//      that are bf16 values (8 significant bits) -- the arithmetic of the bf16-feature path -- at the full f16 MFMA
+//      rate, 16x the f32 one.
 template <int MODE>
 struct Fc;
 template <>
 struct Fc<0> {
   static constexpr int NS = 1, ESZ = 4, REC = 64, PIECES = 4, PITCH = 80, KB = 2;
+};
+template <>
+struct Fc<1> {
+  static constexpr int NS = 1, ESZ = 2, REC = 32, PIECES = 2, PITCH = 48, KB = 1;
 };
 template <>
 struct Fc<2> {
@@ -40,7 +47,7 @@ struct Fc<3> {
 
 inline int fc_nsplit(int mode) { return mode == 0 ? 1 : mode; }
 inline int fc_esz(int mode) { return mode == 0 ? 4 : 2; }
-inline bool fc_mode_ok(int mode) { return mode == 0 || mode == 2 || mode == 3; }
+inline bool fc_mode_ok(int mode) { return mode >= 0 && mode <= 3; }
 
 // An activation operand: 16-channel records, pixel-linear inside a sample (row pitch = the padded width, so a
 // k x k tap is a constant pixel offset), chunk-major.  Strides in bytes.

@@ -169,6 +169,7 @@ int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, in
   fc_pack_act_kernel<M_><<<grid, 256, 0, stream>>>(src, amax, o, C, H, W, g.Hp, g.Wp, g.pad_t, g.pad_l, g.Sx, nch, \
                                                    d.split_stride)
   if (mode == 0) GFLA_LAUNCH(0);
+  else if (mode == 1) GFLA_LAUNCH(1);
   else if (mode == 2) GFLA_LAUNCH(2);
   else GFLA_LAUNCH(3);
 #undef GFLA_LAUNCH
@@ -206,7 +207,9 @@ int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_
   const dim3 grid((unsigned)ceil_div(S, 256), (unsigned)B);
   const PackedDesc d = fc_desc_packed(out, B, Cz / kFcChunk, S, mode);
   unsigned char *o = static_cast<unsigned char *>(out);
-  if (mode == 2)
+  if (mode == 1)
+    fc_pack_z_kernel<1><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
+  else if (mode == 2)
     fc_pack_z_kernel<2><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
   else
     fc_pack_z_kernel<3><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
@@ -281,6 +284,8 @@ int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_
   const dim3 grid((unsigned)ceil_div(most, 256), 4);
   if (mode == 0)
     fc_pack_w_kernel<0><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
+  else if (mode == 1)
+    fc_pack_w_kernel<1><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
   else if (mode == 2)
     fc_pack_w_kernel<2><<<grid, 256, 0, stream>>>(w0, amax, jobs, C, k);
   else
@@ -297,7 +302,7 @@ int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_
 // as 128-byte coalesced atomics.
 template <int MODE>
 struct WgTile {
-  static constexpr int KC = MODE == 2 ? 64 : 32;      // pixels per staged K step
+  static constexpr int KC = (MODE == 2 || MODE == 1) ? 64 : 32;  // pixels per staged K step
   static constexpr int PX = MODE == 0 ? 64 : 32;      // LDS pitch of an X pixel record
   static constexpr int PY = MODE == 0 ? 512 : 320;    // LDS pitch of a Y pixel (128 channels; 256 B + 64: tr-read banks)
 };
@@ -482,10 +487,12 @@ int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dw
 #define GFLA_WG(M_, K_, NB_) launch_wgrad<M_, K_, NB_>(X, Y, y_lead, dwacc, cpad, B, Mk, Wp, stream)
   if (k == 3) {
     if (mode == 0) GFLA_WG(0, 3, 5);
+    else if (mode == 1) GFLA_WG(1, 3, 5);
     else if (mode == 2) GFLA_WG(2, 3, 5);
     else GFLA_WG(3, 3, 5);
   } else {
     if (mode == 0) GFLA_WG(0, 5, 7);
+    else if (mode == 1) GFLA_WG(1, 5, 7);
     else if (mode == 2) GFLA_WG(2, 5, 7);
     else GFLA_WG(3, 5, 7);
   }

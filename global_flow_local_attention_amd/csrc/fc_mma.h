@@ -19,6 +19,10 @@ struct Frag<0> {
   float4 v;
 };
 template <>
+struct Frag<1> {
+  f16x8 s[1];
+};
+template <>
 struct Frag<2> {
   f16x8 s[2];
 };
@@ -47,6 +51,8 @@ __device__ __forceinline__ f32x16 mma(const Frag<MODE> &a, const Frag<MODE> &b, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.y, b.v.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.z, b.v.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v.w, b.v.w, acc, 0, 0, 0);
+  } else if constexpr (MODE == 1) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[0], acc, 0, 0, 0);
   } else if constexpr (MODE == 2) {  // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[1], b.s[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.s[0], b.s[1], acc, 0, 0, 0);

@@ -361,6 +361,74 @@ class FusedAttnFunction(Function):
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
 
 
+class FusedAttnBf16Function(Function):
+    """ExtractorAttn.forward (softmax=True) for bfloat16 FEATURES (BASELINE config 5: mixed-precision face model).
+    Storage is bf16 -- source, target, flow in; result, attention and the feature-map gradients out -- and nothing is
+    ever widened in HBM except the inputs of the FC layers:
+      * FC layers: gfla_fc_{forward,backward}_f32 in arithmetic mode 1 -- ONE f16 term per operand, which represents a
+        bf16 value exactly, f32 accumulation in the MFMA -- at the full f16 matrix-core rate (16x the f32 one);
+      * softmax / aggregate and their backward: the _bf16 entry points (f32 arithmetic, f64-in-LDS scatter);
+      * reductions over channels (d flow, d logits) and all parameter gradients are float32 inside, cast at the end.
+    The FC parameters may be f32 (autocast-style master weights) or bf16."""
+
+    @staticmethod
+    def forward(ctx, source, target, flow, w0, b0, w1, b1, kernel_size, slope):
+        k = int(kernel_size)
+        _lib.require_gpu(source, target, flow, w0, w1)
+        B, C, H, W = source.shape
+        if tuple(target.shape) != (B, C, H, W) or tuple(flow.shape) != (B, 2, H, W):
+            raise ValueError("ExtractorAttn (bf16): source, target and flow must share B, C and H, W")
+        source, flow = source.contiguous(), flow.contiguous()
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        s32, t32, fl32 = f32(source), f32(target), f32(flow)
+        w0c, w1c, b0c, b1c = f32(w0), f32(w1).reshape(k * k, 128), f32(b0), f32(b1)
+        mode = 1
+        ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=source.device)
+        logits32 = s32.new_empty((B, k * k, H, W))
+        _lib.call("gfla_fc_forward_f32", s32, _lib.ptr(s32), _lib.ptr(t32), _lib.ptr(fl32), _lib.ptr(w0c), _lib.ptr(b0c),
+                  _lib.ptr(w1c), _lib.ptr(b1c), _lib.ptr(ws), _lib.ptr(logits32), B, C, H, W, k, float(slope), mode)
+        logits = logits32.to(torch.bfloat16)
+        out = torch.empty_like(source)
+        attn = torch.empty_like(logits)
+        flow_b = flow if flow.dtype == torch.bfloat16 else flow.to(torch.bfloat16)
+        _lib.call("gfla_local_attn_aggregate_fwd_bf16", source, _lib.ptr(source), _lib.ptr(flow_b), _lib.ptr(logits),
+                  _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
+        ctx.save_for_backward(source, flow_b, fl32, attn, w1c, ws)
+        ctx.dims = (B, C, H, W, k, float(slope), mode)
+        ctx.meta = (w0.shape, w1.shape, b0 is not None, b1 is not None, flow.dtype, target.dtype,
+                    tuple(None if t is None else t.dtype for t in (w0, b0, w1, b1)))
+        ctx.mark_non_differentiable(attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, g_out, _g_attn):
+        source, flow_b, fl32, attn, w1c, ws = ctx.saved_tensors
+        B, C, H, W, k, slope, mode = ctx.dims
+        w0_shape, w1_shape, has_b0, has_b1, flow_dtype, target_dtype, pdt = ctx.meta
+        need = ctx.needs_input_grad
+        dev = source.device
+        g_out = g_out.contiguous().to(torch.bfloat16)
+        new32 = lambda shape, wanted: torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
+        gs = torch.zeros_like(source) if need[0] else None                       # bf16, accumulated into
+        gf32 = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev) if need[2] else None
+        gl32 = torch.zeros((B, k * k, H, W), dtype=torch.float32, device=dev)
+        _lib.call("gfla_local_attn_aggregate_bwd_bf16", source, _lib.ptr(source), _lib.ptr(flow_b), _lib.ptr(attn),
+                  _lib.ptr(g_out), _lib.ptr(gs), _lib.ptr(gf32), _lib.ptr(gl32), B, C, H, W, H, W, k, 1)
+        g_s32, g_t32 = new32((B, C, H, W), need[0]), new32((B, C, H, W), need[1])
+        g_w0 = new32(w0_shape, need[3])
+        g_b0 = new32((128,), need[4] and has_b0)
+        g_w1 = new32(w1_shape, need[5])
+        g_b1 = new32((k * k,), need[6] and has_b1)
+        scratch = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
+        _lib.call("gfla_fc_backward_f32", fl32, _lib.ptr(ws), _lib.ptr(fl32), _lib.ptr(w1c), _lib.ptr(gl32),
+                  _lib.ptr(scratch), _lib.ptr(g_s32), _lib.ptr(g_t32), _lib.ptr(gf32), _lib.ptr(g_w0), _lib.ptr(g_b0),
+                  _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode, 2 if need[2] else 0)  # += grad_flow
+        cast = lambda t, dt: None if t is None else t.to(dt)
+        g_source = None if not need[0] else (gs.float() + g_s32).to(torch.bfloat16)
+        return (g_source, cast(g_t32, target_dtype), cast(gf32, flow_dtype), cast(g_w0, pdt[0]), cast(g_b0, pdt[1]),
+                cast(g_w1, pdt[2]), cast(g_b1, pdt[3]), None, None)
+
+
 def _fused_attention(self, source, target, flow_field):
     """Fused evaluation of ExtractorAttn; returns (attn_param_, result)."""
     k = self.kernel_size
@@ -373,6 +441,14 @@ def _fused_attention(self, source, target, flow_field):
         return _unfused_attention(self, source, target, flow_field)
     source_c = source.contiguous()
     flow_c = flow_field.contiguous()
+    if (source.dtype == torch.bfloat16 and target.dtype == torch.bfloat16 and getattr(self, "fc_impl", "mfma") == "mfma"
+            and _tail_slope(act) is not None and isinstance(last, nn.Softmax) and last.dim == 1
+            and isinstance(conv0, nn.Conv2d) and conv0.out_channels == 128 and conv0.kernel_size == (k, k)
+            and conv0.stride == (k, k) and isinstance(conv1, nn.Conv2d) and conv1.kernel_size == (1, 1)
+            and conv1.out_channels == k * k and fc_mfma.supported(c, source.size(2), source.size(3), k, 1)):
+        result, attn = FusedAttnBf16Function.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
+                                                   conv1.bias, k, _tail_slope(act))
+        return attn, result
     mode = _mfma_mode(self, source_c, target, flow_c, conv0, act, conv1, k)
     if mode is not None:
         # both FC layers on the matrix cores: no block tensor, no library GEMM / convolution (fc_mfma.py)

@@ -14,7 +14,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODES = (0, 2, 3)
+MODES = (0, 1, 2, 3)
 DEFAULT_MODE = 3
 
 

@@ -219,3 +219,43 @@ def test_unsupported_shapes_fall_back(gfla):
     b = m3(s, t, f)
     m3.fc_impl = "mfma"
     assert_close(m3(s, t, f).cpu(), b.cpu(), 2e-5, "fc_impl switch")
+
+
+# ------------------------------------------------------------------------------- bf16 features (BASELINE config 5)
+@pytest.mark.parametrize("k,C,H,W", [(3, 16, 12, 10), (5, 8, 11, 9)])
+def test_extractor_attn_bf16_features(lib, gfla, oracle, k, C, H, W):
+    """bf16 source / target / flow through ExtractorAttn (FusedAttnBf16Function: FC layers in arithmetic mode 1 --
+    one f16 term per operand, exact for bf16 values -- aggregation in the _bf16 kernels) against the CPU oracle of the
+    whole block evaluated in float32 on the bf16-rounded inputs: forward and feature-map gradients within 2^-6 of the largest
+    entry, parameter gradients within 2^-5 (the logits are rounded to bf16 once before the softmax, as in any bf16 pipeline)."""
+    from oracle import cpu_modules
+    B, tol = 2, 2 ** -6
+    torch.manual_seed(3)
+    m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+    with torch.no_grad():   # keep the hidden activations clear of the LeakyReLU kink (module docstring)
+        m.fully_connect_layer[0].bias.copy_(torch.where(torch.arange(128) % 2 == 0, 8.0, -8.0))
+        for p in m.parameters():
+            p.copy_(p.bfloat16().float())       # bf16-representable parameters: mode 1 is then exact
+    ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+    ref.load_state_dict(m.state_dict())
+    s, t = randn((B, C, H, W), seed=61).bfloat16(), randn((B, C, H, W), seed=62).bfloat16()
+    f = make_flow("coherent", B, H, W, seed=63).bfloat16()
+    up = randn((B, C, H, W), seed=64).bfloat16()
+    m = m.to(DEV)
+    a = [x.to(DEV).requires_grad_() for x in (s, t, f)]
+    out = m(*a)
+    assert out.dtype == torch.bfloat16
+    out.backward(up.to(DEV))
+    c = [x.float().requires_grad_() for x in (s, t, f)]
+    want = ref(*c)
+    want.backward(up.float())
+    errs = {"out": rel_err(out.float().cpu(), want.detach())}
+    for name, got, w in zip(("source", "target", "flow"), a, c):
+        assert got.grad.dtype == torch.bfloat16
+        errs[name] = rel_err(got.grad.float().cpu(), w.grad)
+    for (n_, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        errs[n_] = rel_err(p.grad.float().cpu(), q.grad)
+    # parameter gradients are sums over every position of softmax gradients built from the bf16-rounded attention
+    # (heavy cancellation: 2^-9 relative noise per term against a sum much smaller than its terms): 2^-5 there
+    bad = {n_: e for n_, e in errs.items() if e > (2 * tol if n_.startswith("fully_connect") else tol)}
+    assert not bad, errs
