@@ -51,6 +51,7 @@ import global_flow_local_attention_amd as gfla  # noqa: E402
 from global_flow_local_attention_amd import _lib, dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 matrix-core peak (MI355X_MICROARCH.md), arithmetic modes 1-3
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input matrix cores = the f32 vector rate (MI355X_MICROARCH.md)
 
 LAYERS = (  # (name, C, H, W, k) for a 256x176 input, layers=3, ngf=64
@@ -268,6 +269,8 @@ def algorithmic_bytes(name, a, esz=None):
         B, Hc, HW, KK = a[11:15]
         writes = 1 + (a[8] is not None) + (a[9] is not None)
         return esz * ((2 + writes) * B * Hc * HW + B * KK * HW)
+    if base == "gfla_local_attn_aggregate_fwd_ws":  # (s, f, l, o, a, ws, B, C, Hs, Ws, H, W, k, sm)
+        return algorithmic_bytes("gfla_local_attn_aggregate_fwd_" + suffix, a[:5] + a[6:], esz)
     if base == "gfla_local_attn_aggregate_bwd_ws":  # (s, f, a, go, gs, gf, gl, ws, B, C, Hs, Ws, H, W, k, sm)
         return algorithmic_bytes("gfla_local_attn_aggregate_bwd_f32", a[:7] + a[8:], esz)
     if base == "gfla_resample2d_bwd_ws":  # (in1, in2, go, g1, g2, ws, B, C, Hi, Wi, H, W, k, d, trunc)
@@ -651,10 +654,13 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"], "avg_us": dom["avg_us"],
                             "alg_MB_per_launch": dom["alg_MB"], "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"])}
         if "alg_GFLOP" in dom:  # an FC-layer entry: several kernels (packing, MFMA contraction, sampling tails) per call
-            line["roofline"].update({"alg_GFLOP_per_call": dom["alg_GFLOP"], "TFLOPs": dom["TFLOPs"],
-                                     "note": "whole C-ABI call, not one kernel: in arithmetic mode 1 the MFMA contraction "
-                                             "runs at the f16 rate and the call is bound by the HBM traffic of its packing "
-                                             "/ sampling / reduction kernels; bytes = operands + results of the call"})
+            peak = MFMA_F16_PEAK_TFLOPS if face else MFMA_F32_PEAK_TFLOPS
+            line["roofline"] = {"bound": "mfma", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["TFLOPs"],
+                                "peak": peak, "unit": "TFLOP/s", "frac": round(dom["TFLOPs"] / peak, 4),
+                                "avg_us": dom["avg_us"], "alg_GFLOP_per_call": dom["alg_GFLOP"], "traffic": None,
+                                "hbm_GBps_of_call": dom["GBps"],
+                                "note": "whole C-ABI call (packing, MFMA contraction, sampling / reduction kernels), HIP "
+                                        "events around the call; peak = dense matrix-core rate of the operand type"}
     if variants:
         line["variants"] = variants
     if check is not None:

@@ -52,6 +52,9 @@ _SINGLE = {
     "gfla_fc_tr_probe": [_ptr, _int, _ptr, _ptr, _ptr],
     "gfla_fc_kernel_f32": [_int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_scatter_workspace_bytes": [_i64] * 3 + [_int],
+    "gfla_aggregate_fwd_workspace_bytes": [_i64] * 3 + [_int],
+    "gfla_local_attn_aggregate_fwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_resample2d_bwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _int, _ptr],
 }
@@ -132,6 +135,22 @@ def scatter_workspace(ref_tensor, B, H, W, entries):
     """Scratch for the matrix-core scatter paths (csrc/patch_mfma.hip): the patch table of one op invocation."""
     n = lib().gfla_scatter_workspace_bytes(int(B), int(H), int(W), int(entries))
     return torch.empty(max(int(n), 16), dtype=torch.uint8, device=ref_tensor.device)
+
+
+def aggregate_fwd(source, flow, logits, out, attn, k, apply_softmax):
+    """softmax + aggregate forward.  f32 / bf16 storage: the coefficient-table kernels (scratch from the caching
+    allocator, csrc/local_attn_aggregate.hip); f64: the plain entry point."""
+    b, c, hs, ws = source.shape
+    h, w = flow.shape[2], flow.shape[3]
+    sfx = suffix(source, "local_attn_aggregate")
+    tail = (b, c, hs, ws, h, w, int(k), 1 if apply_softmax else 0)
+    if sfx in ("f32", "bf16"):
+        n = lib().gfla_aggregate_fwd_workspace_bytes(int(b), int(h), int(w), int(k))
+        scratch = torch.empty(max(int(n), 16), dtype=torch.uint8, device=source.device)
+        call("gfla_local_attn_aggregate_fwd_ws_" + sfx, source, ptr(source), ptr(flow), ptr(logits), ptr(out), ptr(attn),
+             ptr(scratch), *tail)
+    else:
+        call("gfla_local_attn_aggregate_fwd_" + sfx, source, ptr(source), ptr(flow), ptr(logits), ptr(out), ptr(attn), *tail)
 
 
 def require_gpu(*tensors):

@@ -3,8 +3,9 @@
 
 namespace gfla {
 // per thread: a host thread that drives its own device (DataParallel-style workers, tests) tunes only its own launches
-static thread_local int g_tuning[16] = {0};
-int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
+constexpr int kTuningKeys = 24;
+static thread_local int g_tuning[kTuningKeys] = {0};
+int tuning(int key) { return (key >= 0 && key < kTuningKeys) ? g_tuning[key] : 0; }
 }  // namespace gfla
 
 extern "C" {
@@ -22,7 +23,7 @@ const char *gfla_status_string(int status) {
 }
 
 int gfla_set_tuning(int key, int value) {
-  if (key < 0 || key >= 16) return 0;
+  if (key < 0 || key >= gfla::kTuningKeys) return 0;
   int old = gfla::g_tuning[key];
   gfla::g_tuning[key] = value;
   return old;

@@ -393,6 +393,423 @@ __global__ __launch_bounds__(kLdsThreads) void agg_fwd_lds_kernel(
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Forward through a per-pixel COEFFICIENT TABLE (the default for f32 / bf16 storage when the caller hands over a
+// workspace).  What bounds agg_fwd_lds_kernel is neither HBM nor the LDS pipe but the per-pixel setup every channel
+// group repeats -- softmax over k*k logits, tap geometry, folding the attention into the (K+1)x(K+1) patch
+// coefficients: ~1100 VALU instructions per pixel against ~40 per pixel and channel, C/G times.  So:
+//   1. agg_coef_kernel (once per pixel): softmax (-> attn_out), tap geometry, and the patch coefficients of the
+//      pixel as (K+1) rows x (K+2) words of an EVEN-aligned window of source columns, with the replicate clamp in x
+//      already folded in (coefficients of columns left / right of the map are added to the border column) -- a
+//      dynamically indexed scatter, done in LDS.  Written as one record per pixel -- the coefficients + one packed word (window
+//      start, first row) -- in the tile order of the main kernel; pixels whose taps do not form a dense patch (a flow within rounding of an integer) get
+//      a sentinel and are evaluated tap by tap in the main kernel.
+//   2. agg_fwd_stream_kernel (per sample, 1024 pixels and a range of channels): a lane loads the record of its pixel
+//      ONCE (coalesced dwordx4) and keeps it in registers while the planes of its channels stream through LDS in
+//      double-buffered chunks; a patch row is (K+3)/2 ds_read_b64 from an even word -- 256 B/clk against the 128 B/clk
+//      of ds_read_b32, no per-column clamp -- consumed by v_pk_fma_f32 on the register pair a b64 read lands in.
+// Non-finite source values: the window is one word wider than the patch and that word carries weight 0, so an
+// inf / NaN there reaches this pixel (0 * inf), one column further than in the reference.
+// ----------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kAggNotDense = 0xffffffffu;  // packed word of a pixel whose taps are not a dense patch
+constexpr unsigned kAggSkip = 0xfffffffeu;      // lane without a pixel (tile overhang)
+constexpr int kAggCoefThreads = 256;
+
+template <int K>
+constexpr int agg_coef_slots() { return (K + 1) * (K + 2); }
+// floats per pixel in the table: the coefficients + the packed word, padded to whole 16-byte vectors -- a lane fetches
+// its record with a few dwordx4 loads (the texture addresser spends ~16 cycles per wave load whatever its width: one
+// dword load per coefficient was the bottleneck of the first version of this kernel)
+constexpr int agg_record_floats(int k) { return ((k + 1) * (k + 2) + 1 + 3) & ~3; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int K>
+__global__ __launch_bounds__(kAggCoefThreads) void agg_coef_kernel(
+    const T *__restrict__ flow, const T *__restrict__ logits, T *__restrict__ attn_out, float *__restrict__ table,
+    int Hs, int Ws, int H, int W, int apply_softmax, int tw_log2, int ntile) {
+  constexpr int KK = K * K, NS = agg_coef_slots<K>(), NR = agg_record_floats(K);
+  __shared__ float coef[NS * kAggCoefThreads];  // [slot][thread]: a private, dynamically indexable column per lane
+  const int HW = H * W;
+  const int b = blockIdx.y;
+  // wave <-> tile of the main kernel (same lane -> pixel mapping), record vectors written [tile][vector][lane]
+  const int lane = threadIdx.x & 63, t = blockIdx.x * (kAggCoefThreads / 64) + (threadIdx.x >> 6);
+  if (t >= ntile) return;
+  const int tw = 1 << tw_log2, th = 64 >> tw_log2, tiles_x = (W + tw - 1) >> tw_log2;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int yf = ty * th + (lane >> tw_log2), xf = (tx << tw_log2) + (lane & (tw - 1));
+  if (yf >= H || xf >= W) return;
+  const int p = yf * W + xf;
+  float a[KK];
+  const T *lg = logits + (int64_t)b * KK * HW + p;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) a[t] = Num<T>::ld(lg + (int64_t)t * HW);
+  if (apply_softmax) {  // base_function.py:803
+    float m = a[0];
+#pragma unroll
+    for (int t = 1; t < KK; ++t) m = fmaxf(m, a[t]);
+    float ssum = 0;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      a[t] = exp_t<float>(a[t] - m);
+      ssum += a[t];
+    }
+    const float inv = 1.f / ssum;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) a[t] *= inv;
+  }
+  if (attn_out) {
+    T *ao = attn_out + (int64_t)b * KK * HW + p;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) ao[(int64_t)t * HW] = Num<T>::from(a[t]);
+  }
+  PatchTaps<float, K> tp;
+  tp.init(Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p), Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p), xf, yf,
+          Hs, Ws);
+  f32x4 *rec = reinterpret_cast<f32x4 *>(table) + ((int64_t)b * ntile + t) * (NR / 4) * 64 + lane;
+  if (!tp.dense) {
+    rec[(NS >> 2) * 64][NS & 3] = __uint_as_float(kAggNotDense);
+    return;
+  }
+  // even-aligned window [xa, xa + K + 1] that holds every clamped column of the patch
+  const int xs = clampi(tp.x0, 0, Ws - (K + 1));
+  const int xa = xs & ~1;
+  float *mine = coef + threadIdx.x;
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) mine[s_ * kAggCoefThreads] = 0.f;
+  int slot[K + 1];
+#pragma unroll
+  for (int q = 0; q <= K; ++q) slot[q] = (clampi(tp.x0 + q, 0, Ws - 1) - xa) * kAggCoefThreads;
+#pragma unroll
+  for (int r = 0; r <= K; ++r) {
+    float Pr[K + 1];
+#pragma unroll
+    for (int q = 0; q <= K; ++q) Pr[q] = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      float wrow = 0;  // attention mass of tap column j that lands on patch row r
+      if (r < K) wrow += a[r * K + j] * (1 - tp.ay[r]);
+      if (r > 0) wrow += a[(r - 1) * K + j] * tp.ay[r - 1];
+      Pr[j] += wrow * (1 - tp.ax[j]);
+      Pr[j + 1] += wrow * tp.ax[j];
+    }
+    float *row = mine + r * (K + 2) * kAggCoefThreads;
+#pragma unroll
+    for (int q = 0; q <= K; ++q) row[slot[q]] += Pr[q];  // same lane, program order: no race
+  }
+  const int y0 = clampi(tp.y0, -(K + 1), Hs);  // rows are clamped to [0, Hs) anyway
+  const unsigned packed = ((unsigned)(y0 + 16) << 16) | (unsigned)xa;
+#pragma unroll
+  for (int v = 0; v < NR / 4; ++v) {
+    f32x4 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s_ = 4 * v + e;
+      q[e] = s_ < NS ? mine[s_ * kAggCoefThreads] : (s_ == NS ? __uint_as_float(packed) : 0.f);
+    }
+    rec[v * 64] = q;
+  }
+}
+
+// LDS layout of a plane: rows in INTERLEAVED PAIRS,
+//     word(y, x) = (y / 2) * pitch + (x / 2) * 4 + (y % 2) * 2 + (x % 2),     pitch = 32 (mod 64), >= 2 * Ws
+// A word pair (even x) stays contiguous (one ds_read_b64), rows y and y+1 of a pair never share a bank (they occupy
+// alternate 8-byte slots), and consecutive row pairs are 32 banks apart: a lane group whose addresses span <= 8 word
+// pairs of <= 4 plane rows -- a 16 x 2 or 8 x 4 pixel tile with a coherent flow -- reads without bank conflicts (zero
+// flow: 4 % conflict cycles; the bench's flow, which moves ~1 pixel per pixel, still loses 40 %, down from 60 % for
+// row-major planes read by 64 pixels of one row).
+// A chunk of planes is moved in two halves so that the global loads of the NEXT chunk are in flight while the current
+// one is being read: agg_chunk_load (global -> registers, word pairs) ... agg_chunk_store (registers -> LDS).
+constexpr int kAggPre = 8;  // word pairs per thread and chunk (the launcher sizes the chunk accordingly)
+
+template <typename T>
+__device__ __forceinline__ void agg_chunk_load(const T *__restrict__ g, int n, f32x2 (&pre)[kAggPre]) {
+#pragma unroll
+  for (int j = 0; j < kAggPre; ++j) {
+    // unconditional (index clamped): a load under `if (i < n)` turns into a branch + s_waitcnt per load
+    const int i = min(j * (int)blockDim.x + (int)threadIdx.x, n - 1);
+    if constexpr (sizeof(T) == 4) {
+      pre[j] = reinterpret_cast<const f32x2 *>(g)[i];
+    } else {
+      const unsigned raw = reinterpret_cast<const unsigned *>(g)[i];  // two bf16
+      pre[j] = f32x2{__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
+    }
+  }
+}
+__device__ __forceinline__ void agg_chunk_store(float *lds, int n, const f32x2 (&pre)[kAggPre], int per_plane, int wp,
+                                                unsigned m_pl, unsigned m_wp, int pitch, int plane_sz) {
+#pragma unroll
+  for (int j = 0; j < kAggPre; ++j) {
+    const int i = j * (int)blockDim.x + (int)threadIdx.x;
+    if (i < n) {
+      const int c = (int)__umulhi((unsigned)i, m_pl);
+      const int rem = i - c * per_plane;
+      const int y = (int)__umulhi((unsigned)rem, m_wp);
+      const int xp = rem - y * wp;
+      *reinterpret_cast<f32x2 *>(lds + c * plane_sz + (y >> 1) * pitch + (xp << 2) + ((y & 1) << 1)) = pre[j];
+    }
+  }
+}
+
+// workgroup <-> (sample, tile group = blockDim/64 tiles, channel range [sg*CS, sg*CS+CS)); wave <-> tile; lane <-> pixel.
+// The lane's record is fetched ONCE and stays in registers while the channels of the range stream through LDS in
+// chunks of CH planes, double buffered.
+// <= 12 waves per workgroup: 170 VGPRs per lane (record 43 + two channels x two rows in flight 28 + next chunk 16 + ...)
+constexpr int kAggStreamWaves = 12;
+template <typename T, int K>
+__global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ logits,
+    const float *__restrict__ table, T *__restrict__ out, int C, int Hs, int Ws, int H, int W, int apply_softmax,
+    int CH, int CS, int nsuper, int tgroups, int pitch, int total, int tw_log2, int ntile) {
+  constexpr int KK = K * K, NP = (K + 1) / 2, NS = agg_coef_slots<K>(), NR = agg_record_floats(K);
+  static_assert(K % 2 == 1, "paired reads are laid out for odd K");
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *lds = reinterpret_cast<float *>(gfla_smem);
+  // every XCD gets a contiguous run of the (sample, channel range, tile group) index space: the tile groups that
+  // stage the same planes, and the channel ranges that read the same records, share one L2
+  const int per_xcd = (total + kNumXCD - 1) / kNumXCD;
+  int bid = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+  if (bid >= total) return;
+  const int tg = bid % tgroups;
+  bid /= tgroups;
+  const int sg = bid % nsuper;
+  const int b = bid / nsuper;
+  const int c_begin = sg * CS, c_end = min(C, c_begin + CS);
+  const int plane_sz = ((Hs + 1) >> 1) * pitch;
+  const int buf_sz = CH * plane_sz + 4;  // + the word pair a window may read past the last row
+  const int HW = H * W;
+  const float inv_kk = 1.f / (float)KK;
+  const int tw = 1 << tw_log2, th = 64 >> tw_log2;
+  const int tiles_x = (W + tw - 1) >> tw_log2;
+  const int lane = threadIdx.x & 63;
+  const int t = tg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+
+  // the lane's pixel: packed word + coefficients (w2[r][i] = words (2i, 2i+1) of the aligned row window, w1[r] = word K+1)
+  f32x2 w2[K + 1][NP];
+  float w1[K + 1];
+  unsigned m = kAggSkip;
+  int p = 0;
+  if (t < ntile) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int yf = ty * th + (lane >> tw_log2), xf = (tx << tw_log2) + (lane & (tw - 1));
+    if (yf < H && xf < W) {
+      p = yf * W + xf;
+      const f32x4 *rec = reinterpret_cast<const f32x4 *>(table) + ((int64_t)b * ntile + t) * (NR / 4) * 64 + lane;
+      f32x4 q[NR / 4];
+#pragma unroll
+      for (int v = 0; v < NR / 4; ++v) q[v] = rec[v * 64];  // 1 KB per load instruction, fully coalesced
+#pragma unroll
+      for (int r = 0; r <= K; ++r) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          w2[r][i].x = q[(r * (K + 2) + 2 * i) >> 2][(r * (K + 2) + 2 * i) & 3];
+          w2[r][i].y = q[(r * (K + 2) + 2 * i + 1) >> 2][(r * (K + 2) + 2 * i + 1) & 3];
+        }
+        w1[r] = q[(r * (K + 2) + K + 1) >> 2][(r * (K + 2) + K + 1) & 3];
+      }
+      m = __float_as_uint(q[NS >> 2][NS & 3]);
+    }
+  }
+
+  const int wp = Ws >> 1;              // word pairs per row (Ws is even)
+  const int per_plane = Hs * wp;       // word pairs per plane
+  const unsigned m_pl = 0xffffffffu / (unsigned)per_plane + 1u, m_wp = 0xffffffffu / (unsigned)wp + 1u;
+  const T *s0 = src + ((int64_t)b * C + c_begin) * Hs * Ws;
+  f32x2 pre[kAggPre];
+  int gc = min(CH, c_end - c_begin);
+  agg_chunk_load<T>(s0, gc * per_plane, pre);
+  {  // words no load ever writes must be finite: they meet weight 0
+    const int nrow = CH * ((Hs + 1) >> 1);
+    for (int u = 0; u < 2; ++u) {
+      float *bf = lds + u * buf_sz;
+      if (pitch >= 2 * Ws + 4)
+        for (int i = threadIdx.x; i < nrow * 4; i += blockDim.x) bf[(i >> 2) * pitch + 2 * Ws + (i & 3)] = 0.f;
+      if (threadIdx.x < 4) bf[CH * plane_sz + threadIdx.x] = 0.f;
+    }
+  }
+  agg_chunk_store(lds, gc * per_plane, pre, per_plane, wp, m_pl, m_wp, pitch, plane_sz);
+  __syncthreads();
+
+  int ro[K + 1];
+  if (m < kAggSkip) {
+    const int xa = (int)(m & 0xffffu), y0 = (int)(m >> 16) - 16;
+#pragma unroll
+    for (int r = 0; r <= K; ++r) {
+      const int yc = clampi(y0 + r, 0, Hs - 1);
+      ro[r] = (yc >> 1) * pitch + ((yc & 1) << 1) + (xa << 1);  // word pairs of a row sit 4 words apart
+    }
+  }
+  T *o = out + ((int64_t)b * C + c_begin) * HW + p;
+  int cur = 0;
+  for (int cb = c_begin; cb < c_end; cb += CH) {
+    const int gn = min(CH, c_end - cb - CH);  // planes of the next chunk (<= 0: none)
+    if (gn > 0) agg_chunk_load<T>(s0 + (int64_t)(cb + CH - c_begin) * Hs * Ws, gn * per_plane, pre);
+    gc = min(CH, c_end - cb);
+    const float *pl = lds + cur * buf_sz;
+    if (m < kAggSkip) {
+      // One patch row of one channel: NP + 1 ds_read_b64 (word K+1 as the first half of a 64-bit read: a ds_read_b32 is
+      // banked mod 32 and conflicts on this layout).  The empty asm statements keep the reads apart: merged into
+      // ds_read2_b64 they would run at half the LDS rate (MI355X_MICROARCH.md, LDS table).
+      auto load_row = [&](const float *rp, f32x2(&v)[NP], float &u) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          v[i] = *reinterpret_cast<const f32x2 *>(rp + 4 * i);
+          asm volatile("" ::: "memory");
+        }
+        u = (*reinterpret_cast<const f32x2 *>(rp + 4 * NP)).x;
+        asm volatile("" ::: "memory");
+      };
+      int c = 0;
+      for (; c + 2 <= gc; c += 2) {  // two channels at a time: independent accumulation chains
+        f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+        float s0_ = 0.f, s1_ = 0.f;
+        f32x2 v0[2][NP], v1[2][NP];
+        float u0[2], u1[2];
+        load_row(pl + ro[0], v0[0], u0[0]);
+        load_row(pl + plane_sz + ro[0], v1[0], u1[0]);
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          if (r < K) {  // next row in flight while this one is consumed
+            load_row(pl + ro[r + 1], v0[(r + 1) & 1], u0[(r + 1) & 1]);
+            load_row(pl + plane_sz + ro[r + 1], v1[(r + 1) & 1], u1[(r + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // the next row's reads are issued before this row's arithmetic
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            acc0 = __builtin_elementwise_fma(w2[r][i], v0[r & 1][i], acc0);
+            acc1 = __builtin_elementwise_fma(w2[r][i], v1[r & 1][i], acc1);
+          }
+          s0_ = fmaf(w1[r], u0[r & 1], s0_);
+          s1_ = fmaf(w1[r], u1[r & 1], s1_);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        o[0] = Num<T>::from((acc0.x + acc0.y + s0_) * inv_kk);
+        o[HW] = Num<T>::from((acc1.x + acc1.y + s1_) * inv_kk);
+        o += 2 * (int64_t)HW;
+        pl += 2 * plane_sz;
+      }
+      if (c < gc) {
+        f32x2 acc0 = {0.f, 0.f};
+        float s0_ = 0.f;
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          f32x2 v[NP];
+          float u;
+          load_row(pl + ro[r], v, u);
+#pragma unroll
+          for (int i = 0; i < NP; ++i) acc0 = __builtin_elementwise_fma(w2[r][i], v[i], acc0);
+          s0_ = fmaf(w1[r], u, s0_);
+        }
+        o[0] = Num<T>::from((acc0.x + acc0.y + s0_) * inv_kk);
+        o += HW;
+      }
+    } else if (m == kAggNotDense) {
+      // tap by tap exactly as block_extractor does; rolled loops that re-derive a_ij from the logits
+      const int yf = p / W, xf = p - yf * W;
+      const T *lg = logits + (int64_t)b * KK * HW + p;
+      const float fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
+      const float fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+      float sm_max = 0, sm_inv = 1;
+      if (apply_softmax) {
+        sm_max = Num<T>::ld(lg);
+#pragma unroll 1
+        for (int tt = 1; tt < KK; ++tt) sm_max = fmaxf(sm_max, Num<T>::ld(lg + (int64_t)tt * HW));
+        float ssum = 0;
+#pragma unroll 1
+        for (int tt = 0; tt < KK; ++tt) ssum += exp_t<float>(Num<T>::ld(lg + (int64_t)tt * HW) - sm_max);
+        sm_inv = 1.f / ssum;
+      }
+      for (int c = 0; c < gc; ++c) {
+        float acc = 0;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const float dy = (fy0 + (float)(i - K / 2)) + (float)yf;
+          const float fdy = floorf(dy);
+          const int yTc = clampi((int)fdy, 0, Hs - 1), yBc = clampi((int)(fdy + 1), 0, Hs - 1);
+          const int yT = (yTc >> 1) * pitch + ((yTc & 1) << 1), yB = (yBc >> 1) * pitch + ((yBc & 1) << 1);
+          const float yB_P = dy - fdy, yT_P = 1 - yB_P;
+#pragma unroll 1
+          for (int j = 0; j < K; ++j) {
+            const float dx = (fx0 + (float)(j - K / 2)) + (float)xf;
+            const float fdx = floorf(dx);
+            const int xLc = clampi((int)fdx, 0, Ws - 1), xRc = clampi((int)(fdx + 1), 0, Ws - 1);
+            const int xL = ((xLc >> 1) << 2) + (xLc & 1), xR = ((xRc >> 1) << 2) + (xRc & 1);
+            const float xR_P = dx - fdx, xL_P = 1 - xR_P;
+            float aij = Num<T>::ld(lg + (int64_t)(i * K + j) * HW);
+            if (apply_softmax) aij = exp_t<float>(aij - sm_max) * sm_inv;
+            float v = (xL_P * yT_P) * pl[yT + xL];
+            v += (xR_P * yT_P) * pl[yT + xR];
+            v += (xL_P * yB_P) * pl[yB + xL];
+            v += (xR_P * yB_P) * pl[yB + xR];
+            acc += aij * v;
+          }
+        }
+        *o = Num<T>::from(acc * inv_kk);
+        pl += plane_sz;
+        o += HW;
+      }
+    }
+    cur ^= 1;
+    if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, per_plane, wp, m_pl, m_wp, pitch, plane_sz);
+    __syncthreads();  // the next chunk has landed, and nobody still reads the buffer the one after it will overwrite
+  }
+}
+
+// Launch geometry of agg_fwd_stream_kernel.
+struct AggStreamGeo {
+  int CH, CS, nsuper, tgroups, threads, pitch, tw_log2, ntile;
+  unsigned lds;
+};
+inline AggStreamGeo agg_stream_geometry(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k) {
+  AggStreamGeo g{0, 0, 1, 1, 0, 0, 4, 0, 0};
+  // tile width: the one that wastes the fewest lanes on the overhang (16 on ties); tuning key 16 overrides
+  int twl = 4;
+  double best_eff = -1;
+  for (int cand : {4, 3, 5}) {
+    const int64_t tw = 1 << cand, th = 64 >> cand;
+    const double eff = (double)(H * W) / (double)(ceil_div(W, tw) * tw * ceil_div(H, th) * th);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      twl = cand;
+    }
+  }
+  if (tuning(16) == 8 || tuning(16) == 16 || tuning(16) == 32) twl = tuning(16) == 8 ? 3 : tuning(16) == 16 ? 4 : 5;
+  const int64_t ntile = ceil_div(W, 1 << twl) * ceil_div(H, 64 >> twl);
+  const int64_t tmax = tuning(9) >= 64 && tuning(9) <= kAggStreamWaves * 64 ? tuning(9) / 64 : kAggStreamWaves;  // tiles (waves) per workgroup
+  const int64_t tgroups = ceil_div(ntile, tmax);
+  const int64_t twg = ceil_div(ntile, tgroups);  // balanced
+  const int64_t threads = twg * 64;
+  int pitch = (int)(ceil_div(2 * Ws + 32, 64) * 64 - 32);  // smallest value >= 2 Ws that is 32 mod 64
+  if (tuning(17) >= 2 * Ws && !(tuning(17) & 3)) pitch = tuning(17);  // experiment: pair pitch in words
+  const int64_t per_plane = ceil_div(Hs, 2) * pitch * 4;
+  const int64_t budget = 160 * 1024 - 64;
+  // chunk: as many planes as two buffers fit and kAggPre word pairs per thread cover
+  int64_t CH = std::min<int64_t>((budget / 2 - 16) / per_plane, kAggPre * threads / (Hs * (Ws / 2)));
+  if (CH > C) CH = C;
+  if (tuning(4) > 0 && tuning(4) < CH) CH = tuning(4);
+  if (CH >= 2) CH &= ~1LL;  // channel pairs
+  if (CH < 1) return g;
+  // channel ranges: more of them = more workgroups, fewer chunks each (the first chunk of a workgroup is not overlapped)
+  int64_t best_ns = 1;
+  double best_cost = -1;
+  for (int64_t ns = 1; ns * CH <= C || ns == 1; ns *= 2) {
+    const int64_t CS = ceil_div(ceil_div(C, ns), CH) * CH;
+    const int64_t nsr = ceil_div(C, CS);
+    const int64_t wgs = B * tgroups * nsr;
+    const double rounds = (double)ceil_div(wgs, kNumCU);
+    const double cost = rounds * (1.3 + (double)(CS / CH));
+    if (best_cost < 0 || cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best_ns = ns;
+    }
+  }
+  if (tuning(5) > 0) best_ns = tuning(5);
+  const int64_t CS = ceil_div(ceil_div(C, best_ns), CH) * CH;
+  g = AggStreamGeo{(int)CH, (int)CS, (int)ceil_div(C, CS), (int)tgroups, (int)threads, pitch, twl, (int)ntile,
+                   (unsigned)(2 * (CH * per_plane + 16))};
+  return g;
+}
+
 // d/d a_ij (the attention gradient before the softmax Jacobian):
 //     ga[b,ij,p] = (1/K^2) * sum_c grad_out[b,c,p] * block_source_ij[b,c,p]
 // workgroup <-> (b, channel super-group, tile of blockDim pixels); lane <-> ONE pixel, K*K register
@@ -587,12 +1004,40 @@ static int agg_check(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, in
 template <typename T>
 static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T *attn_out, int64_t B,
                          int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm,
-                         gfla_stream_t stream_) {
+                         gfla_stream_t stream_, void *workspace = nullptr) {
   if (!src || !flow || !logits || !out) return GFLA_ERR_NULL_POINTER;
   int st = agg_check(B, C, Hs, Ws, H, W, k);
   if (st != GFLA_OK) return st;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
+  if constexpr (std::is_same<A, float>::value) {
+    // coefficient-table path: needs the caller's workspace (gfla_aggregate_fwd_workspace_bytes)
+    // k = 3 has 16 patch words per output instead of 36: there the per-group setup of agg_fwd_lds_kernel costs less than
+    // the extra pass (23 us against 20 + 5 at the bench shape); tuning key 8 = 2 forces the table path, 1 disables it
+    if (workspace && tuning(3) != 1 && tuning(8) != 1 && (k >= 5 || tuning(8) == 2) && (k & 1) && Ws >= k + 1 && !(Ws & 1) && Ws < 32768 && Hs < 32000 &&
+        B * C * Hs * Ws < (1LL << 31)) {
+      AggStreamGeo pg = agg_stream_geometry(B, C, Hs, Ws, H, W, k);
+      const int64_t total = B * pg.nsuper * pg.tgroups;
+      const int64_t padded = ceil_div(total, kNumXCD) * kNumXCD;
+      if (pg.CH > 0 && padded <= 0x7fffffffLL && B <= 65535) {
+        float *table = static_cast<float *>(workspace);
+        const dim3 cgrid((unsigned)ceil_div(pg.ntile, kAggCoefThreads / 64), (unsigned)B);
+#define GFLA_AGG_TAB(KV)                                                                                                  \
+  agg_coef_kernel<T, KV><<<cgrid, dim3(kAggCoefThreads), 0, stream>>>(flow, logits, attn_out, table, (int)Hs, (int)Ws,        \
+                                                                      (int)H, (int)W, sm, pg.tw_log2, pg.ntile);           \
+  launch_lds(agg_fwd_stream_kernel<T, KV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, logits,    \
+             (const float *)table, out, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, pg.CH, pg.CS, pg.nsuper, pg.tgroups, \
+             pg.pitch, (int)total, pg.tw_log2, pg.ntile)
+        switch (k) {
+          case 1: GFLA_AGG_TAB(1); break;
+          case 3: GFLA_AGG_TAB(3); break;
+          default: GFLA_AGG_TAB(5); break;
+        }
+#undef GFLA_AGG_TAB
+        return launch_status();
+      }
+    }
+  }
   if (tuning(3) != 1) {
     PlaneGeo pg = plane_geometry(Hs * Ws, sizeof(A), B, C, H * W, true, kAggChunk);
     if (pg.G > 0) {
@@ -745,6 +1190,25 @@ int gfla_local_attn_aggregate_fwd_bf16(const uint16_t *s, const uint16_t *f, con
   return gfla::aggregate_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
                                      reinterpret_cast<const bf16_t *>(l), reinterpret_cast<bf16_t *>(o),
                                      reinterpret_cast<bf16_t *>(a), B, C, Hs, Ws, H, W, k, sm, st);
+}
+/* scratch for the coefficient-table forward: (k+1)(k+2) floats + one packed word per flow pixel */
+int64_t gfla_aggregate_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int k) {
+  if (B <= 0 || H <= 0 || W <= 0 || k < 1 || k > 5) return 0;
+  int64_t tiles = 0;  // records are stored per 64-pixel tile (8x8, 16x4 or 32x2, the launcher's choice), overhang included
+  for (int l = 3; l <= 5; ++l) tiles = std::max<int64_t>(tiles, gfla::ceil_div(W, 1 << l) * gfla::ceil_div(H, 64 >> l));
+  return B * tiles * 64 * (int64_t)gfla::agg_record_floats(k) * 4;
+}
+int gfla_local_attn_aggregate_fwd_ws_f32(const float *s, const float *f, const float *l, float *o, float *a,
+                                         void *workspace, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
+                                         int64_t W, int k, int sm, gfla_stream_t st) {
+  return gfla::aggregate_fwd<float>(s, f, l, o, a, B, C, Hs, Ws, H, W, k, sm, st, workspace);
+}
+int gfla_local_attn_aggregate_fwd_ws_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *l, uint16_t *o,
+                                          uint16_t *a, void *workspace, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                                          int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
+  return gfla::aggregate_fwd<bf16_t>(reinterpret_cast<const bf16_t *>(s), reinterpret_cast<const bf16_t *>(f),
+                                     reinterpret_cast<const bf16_t *>(l), reinterpret_cast<bf16_t *>(o),
+                                     reinterpret_cast<bf16_t *>(a), B, C, Hs, Ws, H, W, k, sm, st, workspace);
 }
 int gfla_local_attn_aggregate_bwd_f32(const float *s, const float *f, const float *a, const float *go,
                                       float *gs, float *gf, float *gl, int64_t B, int64_t C, int64_t Hs,

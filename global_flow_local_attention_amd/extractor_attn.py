@@ -72,9 +72,7 @@ class LocalAttnAggregateFunction(Function):
             raise TypeError("local_attn_aggregate: mixed dtypes")
         out = source.new_empty((b, c, h, w))
         attn = torch.empty_like(logits)
-        _lib.call("gfla_local_attn_aggregate_fwd_" + _lib.suffix(source, "local_attn_aggregate"), source,
-                  _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(logits), _lib.ptr(out), _lib.ptr(attn),
-                  b, c, hs, ws, h, w, k, 1 if apply_softmax else 0)
+        _lib.aggregate_fwd(source, flow_field, logits, out, attn, k, apply_softmax)
         ctx.save_for_backward(source, flow_field, attn)
         ctx.kernel_size = k
         ctx.apply_softmax = bool(apply_softmax)
@@ -319,8 +317,7 @@ class FusedAttnFunction(Function):
                   float(slope), mode)
         out = source.new_empty((B, C, H, W))
         attn = torch.empty_like(logits)
-        _lib.call("gfla_local_attn_aggregate_fwd_f32", source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(logits),
-                  _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
+        _lib.aggregate_fwd(source, flow, logits, out, attn, k, True)
         ctx.save_for_backward(source, flow, attn, w1c, ws)
         ctx.dims = (B, C, H, W, k, float(slope), mode)
         ctx.w_shapes = (w0.shape, w1.shape, b0 is not None, b1 is not None)
@@ -391,8 +388,7 @@ class FusedAttnBf16Function(Function):
         out = torch.empty_like(source)
         attn = torch.empty_like(logits)
         flow_b = flow if flow.dtype == torch.bfloat16 else flow.to(torch.bfloat16)
-        _lib.call("gfla_local_attn_aggregate_fwd_bf16", source, _lib.ptr(source), _lib.ptr(flow_b), _lib.ptr(logits),
-                  _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
+        _lib.aggregate_fwd(source, flow_b, logits, out, attn, k, True)
         ctx.save_for_backward(source, flow_b, fl32, attn, w1c, ws)
         ctx.dims = (B, C, H, W, k, float(slope), mode)
         ctx.meta = (w0.shape, w1.shape, b0 is not None, b1 is not None, flow.dtype, target.dtype,

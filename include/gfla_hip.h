@@ -195,6 +195,22 @@ GFLA_DECL_AGGREGATE_FWD(f64, double)
 GFLA_DECL_AGGREGATE_FWD(bf16, uint16_t)
 #undef GFLA_DECL_AGGREGATE_FWD
 
+/* Forward with scratch (f32 / bf16 storage): softmax, tap geometry and the (k+1)x(k+1) patch coefficients of every
+ * flow pixel are computed ONCE (a table of (k+1)(k+2) floats + one word per pixel in `workspace`,
+ * gfla_aggregate_fwd_workspace_bytes(B, H, W, k) bytes, 16-byte aligned) instead of once per channel group, and the
+ * aggregation reads patch rows from LDS with paired 64-bit reads.  workspace == NULL, even k or Ws < k + 1: the
+ * plain entry point's kernels.  Same results up to f32 summation order (the coefficient of a patch word is summed
+ * over its taps before it meets the source value).                                                            */
+int64_t gfla_aggregate_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int kernel_size);
+int gfla_local_attn_aggregate_fwd_ws_f32(const float *source, const float *flow, const float *logits, float *out,
+                                         float *attn_out, void *workspace, int64_t B, int64_t C, int64_t Hs,
+                                         int64_t Ws, int64_t H, int64_t W, int kernel_size, int apply_softmax,
+                                         gfla_stream_t stream);
+int gfla_local_attn_aggregate_fwd_ws_bf16(const uint16_t *source, const uint16_t *flow, const uint16_t *logits,
+                                          uint16_t *out, uint16_t *attn_out, void *workspace, int64_t B, int64_t C,
+                                          int64_t Hs, int64_t Ws, int64_t H, int64_t W, int kernel_size,
+                                          int apply_softmax, gfla_stream_t stream);
+
 #define GFLA_DECL_AGGREGATE_BWD(SFX, T)                                                            \
   int gfla_local_attn_aggregate_bwd_##SFX(const T *source, const T *flow, const T *attn,           \
                                           const T *grad_out, T *grad_source, T *grad_flow,         \

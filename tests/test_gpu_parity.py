@@ -801,3 +801,49 @@ def test_bf16_backward_at_bench_shape(gfla, oracle):
     assert _rel(res.float(), want.detach()) <= 2 ** -7
     for got, ref, nm in ((sd.grad, sc.grad, "source"), (fd.grad, fc.grad, "flow"), (ld.grad, lc.grad, "logits")):
         assert _rel(got.float(), ref) <= 2 ** -7, nm
+
+
+# ------------------------------------------------------- aggregate forward: coefficient-table / streaming kernels
+@pytest.mark.parametrize("shape", [(2, 9, 12, 10), (1, 37, 33, 22), (3, 4, 6, 6), (2, 70, 64, 44), (1, 5, 9, 4), (2, 6, 7, 13)])
+@pytest.mark.parametrize("kind", ["zero", "smooth", "wild", "integer", "near_integer"])
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_aggregate_forward_table_path(gfla, oracle, kernel_variant, shape, kind, k):
+    """gfla_local_attn_aggregate_fwd_ws_f32 with the table path forced for every odd k (tuning key 8 = 2; the default
+    takes it from k = 5) against the float64 oracle chain: ragged tile overhangs, a map as narrow as one patch (4 / 6
+    columns), an odd width (falls back to the plain kernels), several channel chunks and ranges (C = 70), flows far
+    outside the map (the x clamp is folded into the coefficients), and flows within rounding of an integer, where the
+    taps of a pixel stop forming a dense patch and the kernel evaluates it tap by tap."""
+    if kernel_variant == "global":
+        pytest.skip("table path is part of the default dispatch only")
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = shape
+    s = randn((B, C, H, W), seed=71)
+    if kind == "near_integer":
+        f = make_flow("integer", B, H, W, seed=72)
+        f = f + torch.where(randn((B, 2, H, W), seed=73) > 0, 1.0, -1.0) * 2.0 ** -22   # one or two ulps off an integer
+    else:
+        f = make_flow(kind, B, H, W, seed=72)
+    lg = randn((B, k * k, H, W), seed=74) * 2
+    a = torch.softmax(lg.double(), 1)
+    ref = F.avg_pool2d(F.pixel_shuffle(a, k) * oracle.block_extractor_gather(s.double(), f.double(), k), k, k)
+    sd, fd, ld = s.to(DEV), f.to(DEV), lg.to(DEV)
+    out, attn = torch.empty_like(sd), torch.empty_like(ld)
+    gfla.set_tuning(8, 2)
+    try:
+        _lib.aggregate_fwd(sd, fd, ld, out, attn, k, True)
+    finally:
+        gfla.set_tuning(8, 0)
+    assert_close(attn.cpu(), a.float(), F32_FWD * 2, "attn")
+    assert_close(out.cpu(), ref.float(), F32_FWD * 4, "out")
+    if W % 2 == 0 and W >= k + 1:   # bf16 storage through the same kernels
+        sb, fb, lb = (t.bfloat16() for t in (s, f, lg))
+        ab = torch.softmax(lb.double(), 1)
+        refb = F.avg_pool2d(F.pixel_shuffle(ab, k) * oracle.block_extractor_gather(sb.double(), fb.double(), k), k, k)
+        ob, atb = torch.empty_like(sb, device=DEV), torch.empty_like(lb, device=DEV)
+        gfla.set_tuning(8, 2)
+        try:
+            _lib.aggregate_fwd(sb.to(DEV), fb.to(DEV), lb.to(DEV), ob, atb, k, True)
+        finally:
+            gfla.set_tuning(8, 0)
+        err = max_abs(ob.float().cpu(), refb.float()) / max(1e-30, refb.abs().max().item())
+        assert err <= 2 ** -7, err
