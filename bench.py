@@ -38,6 +38,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) that additionally c
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -357,13 +358,25 @@ def pmc_traffic(entry, dims, ptrs=""):
 
 
 def pmc_traffic_kernel(kernel_label):
-    """HBM bytes per launch of one kernel from the committed PMC profile, matched by the kernel's template name."""
+    """HBM bytes per launch of one FC kernel from the committed PMC profile (profiles/pmc_traffic.json), matched by the
+    kernel template and the layer's kernel size; when several launches match (source / target half, forward / data
+    gradient of the convolution kernel) the LARGEST is reported, i.e. an upper bound for the probed launch."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     table = json.load(open(path))
     name = kernel_label.split("<")[0]
-    rows = [r for key, rs in table.items() if key.startswith(name) for r in rs]
+    m = re.search(r"k (\d+)>", kernel_label)
+    k = m.group(1) if m else None
+    rows = []
+    for key, rs in table.items():
+        if not key.startswith(name + "<"):
+            continue
+        args = [x.strip() for x in key[len(name) + 1:].rstrip(">").split(",")]
+        # fc_conv_kernel<MODE, KS, NMB>, fc_wgrad_f32_kernel<KS>, fc_wgrad_kernel<MODE, KS, NB>
+        ks = args[0] if len(args) == 1 else args[1]
+        if k is None or ks == k:
+            rows += rs
     if not rows:
         return None
     return max(r["traffic_bytes"] for r in rows)

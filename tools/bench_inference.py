@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
-"""BASELINE config 3: ExtractorAttn forward only (eval, torch.no_grad), B=32, 256x256 image shapes
-(L3 (256, 32x32) k=3, L2 (128, 64x64) k=5), fused evaluation vs the reference's op-by-op composition on the
-same gfx950 ops, eager and captured in a hipGraph.  usage: python tools/bench_inference.py [--batch 32]"""
+"""BASELINE config 3 (configs[2]): ExtractorAttn forward only (eval, torch.no_grad) at the attention-layer shapes of a
+256x256 image (L3 (256, 32x32) k=3, L2 (128, 64x64) k=5), global batch 32.
+
+    python tools/bench_inference.py [--batch 32] [--iters 10]                       # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/bench_inference.py --gpus N                                           # batch sharded over N ranks
+
+Legs, each timed on its own (HIP events on the launch stream, MAX over ranks):
+  * fused forward: FC layers on this library's MFMA kernels (exact f32) + coefficient-table aggregation, eager and
+    captured in a hipGraph; next to the reference's op-by-op composition on the same gfx950 ops;
+  * N > 1: all_gather_tiles of the generated feature tiles (the north star's "RCCL all-gather of generated tiles over
+    xGMI"), timed separately from the compute and reported as bytes gathered per second.
+GFLA_DIST_BACKEND=gloo GFLA_DEVICE=0 lets two ranks share one GPU to exercise the control flow."""
 import argparse, json, os, sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import global_flow_local_attention_amd as gfla  # noqa: E402
+from global_flow_local_attention_amd import dist as gdist  # noqa: E402
 
 
 def timed(fn, iters):
@@ -23,39 +34,74 @@ def timed(fn, iters):
     return a.elapsed_time(b) * 1e3 / iters
 
 
+def max_over_ranks(us, world, device):
+    if world == 1:
+        return us
+    t = torch.tensor([us], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return t.item()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (sharded over the ranks)")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
-    gfla.enable_gemm_tuning("/tmp/gfla_tunableop_inference.csv")
-    B = a.batch
-    total = {}
+    local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    rank, world, _ = gdist.init_from_env(os.environ.get("GFLA_DIST_BACKEND"), device=local)
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dev = torch.device("cuda", local)
+    lo, hi = gdist.shard_range(a.batch, rank, world)
+    B = hi - lo
+    total, rows = {}, []
     for name, C, H, W, k in (("L3", 256, 32, 32, 3), ("L2", 128, 64, 64, 5)):
-        torch.manual_seed(0)
-        m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).cuda().eval()
-        g = torch.Generator(device="cuda").manual_seed(1)
-        src = torch.randn(B, C, H, W, device="cuda", generator=g)
-        tgt = torch.randn(B, C, H, W, device="cuda", generator=g)
+        torch.manual_seed(0)  # same parameters on every rank
+        m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(dev).eval()
+        g = torch.Generator(device=dev).manual_seed(1 + rank)
+        src = torch.randn(B, C, H, W, device=dev, generator=g)
+        tgt = torch.randn(B, C, H, W, device=dev, generator=g)
         flow = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(
-            torch.randn(B, 2, H, W, device="cuda", generator=g) * 12, (3, 3, 3, 3), mode="replicate"), 7, 1).contiguous()
-        row = {"layer": name, "B": B, "C": C, "HxW": "%dx%d" % (H, W), "k": k}
+            torch.randn(B, 2, H, W, device=dev, generator=g) * 12, (3, 3, 3, 3), mode="replicate"), 7, 1).contiguous()
+        row = {"layer": name, "B_global": a.batch, "B_rank": B, "C": C, "HxW": "%dx%d" % (H, W), "k": k}
         with torch.no_grad():
             m.fused = True
-            m(src, tgt, flow)  # tuning / lazy init
-            row["fused_us"] = round(timed(lambda: m(src, tgt, flow), a.iters), 1)
+            out = m(src, tgt, flow)
+            row["fused_us"] = round(max_over_ranks(timed(lambda: m(src, tgt, flow), a.iters), world, dev), 1)
             graphed = gfla.graphed_inference(m, (src, tgt, flow))
-            row["fused_hipgraph_us"] = round(timed(lambda: graphed(src, tgt, flow), a.iters), 1)
-            m.fused = False
-            row["op_by_op_us"] = round(timed(lambda: m(src, tgt, flow), max(2, a.iters // 3)), 1)
-            m.fused = True
-        row["speedup_vs_op_by_op"] = round(row["op_by_op_us"] / row["fused_us"], 2)
-        for key in ("fused_us", "fused_hipgraph_us", "op_by_op_us"):
-            total[key] = total.get(key, 0) + row[key]
-        print(json.dumps(row), flush=True)
-    print(json.dumps({"both layers": {k: round(v, 1) for k, v in total.items()},
-                      "images_per_s_fused": round(B / (total["fused_us"] * 1e-6), 1),
-                      "images_per_s_op_by_op": round(B / (total["op_by_op_us"] * 1e-6), 1)}), flush=True)
+            row["fused_hipgraph_us"] = round(max_over_ranks(timed(lambda: graphed(src, tgt, flow), a.iters), world, dev), 1)
+            if world == 1:
+                m.fused = False
+                row["op_by_op_us"] = round(timed(lambda: m(src, tgt, flow), max(2, a.iters // 3)), 1)
+                m.fused = True
+                row["speedup_vs_op_by_op"] = round(row["op_by_op_us"] / row["fused_us"], 2)
+            else:
+                gathered = gdist.all_gather_tiles(out)
+                assert gathered.shape[0] == a.batch
+                us = max_over_ranks(timed(lambda: gdist.all_gather_tiles(out), a.iters), world, dev)
+                nbytes = gathered.numel() * gathered.element_size()
+                row["all_gather_tiles_us"] = round(us, 1)
+                row["all_gather_GBps_received_per_rank"] = round(nbytes * (world - 1) / world / us / 1e3, 1)
+        for key in ("fused_us", "fused_hipgraph_us", "op_by_op_us", "all_gather_tiles_us"):
+            if key in row:
+                total[key] = total.get(key, 0) + row[key]
+        rows.append(row)
+        if rank == 0:
+            print(json.dumps(row), flush=True)
+    if rank == 0:
+        summary = {"both layers": {k: round(v, 1) for k, v in total.items()}, "n_gpus": world,
+                   "images_per_s_fused": round(a.batch / (total["fused_us"] * 1e-6), 1),
+                   "images_per_s_fused_hipgraph": round(a.batch / (total["fused_hipgraph_us"] * 1e-6), 1)}
+        if "op_by_op_us" in total:
+            summary["images_per_s_op_by_op"] = round(a.batch / (total["op_by_op_us"] * 1e-6), 1)
+        if "all_gather_tiles_us" in total:
+            summary["images_per_s_incl_gather"] = round(a.batch / ((total["fused_us"] + total["all_gather_tiles_us"]) * 1e-6), 1)
+        print(json.dumps(summary), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,25 @@
+#!/usr/bin/env bash
+# Round-end evidence in one GPU call: HBM traffic counters of the bench step (-> profiles/pmc_traffic.json), MFMA-pipe
+# utilisation of the FC kernels, LDS counters of the aggregation forward before / after, kernel trace of the default
+# bench (steady-state per-step table), then the default bench itself (its roofline.traffic reads the fresh json).
+# usage: gpurun --timeout 2400 -- 'bash tools/gpu_final.sh <tag>'
+set -uo pipefail
+TAG="${1:-final}"
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants"
+for C in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_$C -o pmc -- $BENCH > $OUT/pmc_$C.log 2>&1); echo "$C rc=$?"
+done
+F=$(find /tmp/fin_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+grep -E "fc_conv|fc_wgrad|agg_|be_bwd|rs_lds|patch_" $OUT/pmc_traffic.txt | cut -c1-160 | head -40
+bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants > $OUT/mfma.log 2>&1; grep -E "fc_conv|fc_wgrad" $OUT/mfma/pmc_set1.txt 2>/dev/null | cut -c1-250 | head -12
+# round 1's kernel (agg_fwd_lds_kernel, tuning key 8 = 1) and the table path (agg_coef + agg_fwd_stream) in one run
+bash tools/gpu_pmc_lds.sh $TAG/agg_lds agg_ -- python $PWD/tools/bench_agg_fwd.py --flows smooth --iters 3 > /dev/null 2>&1
+cat $OUT/agg_lds/pmc_summary.txt | cut -c1-330
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_trace -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants > $OUT/rocprof_bench.log 2>&1); echo "trace rc=$?"
+cp /tmp/fin_trace/bench_kernel_stats.csv $OUT/ 2>/dev/null
+python tools/trace_steps.py /tmp/fin_trace/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -48 $OUT/steady_state_steps.txt
+( time timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
