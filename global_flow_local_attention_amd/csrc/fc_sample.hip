@@ -188,20 +188,49 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
   float s0 = 0.f, s1 = 0.f;
   int pend_t = -1, pend_b = -1;                // Z-layout indices of the pending column (-1: none)
   float pt0 = 0.f, pt1 = 0.f, pb0 = 0.f, pb1 = 0.f;  // its sums: (top, bottom) x (channel lane, lane + 64)
-  for (int it = 0; it < kSmpPix / 4; ++it) {
-    const int pp = wave * (kSmpPix / 4) + it, p = p0 + pp;
-    if (p >= HW) break;
+  // The walk is a chain of dependent global accesses per position (flow -> corner addresses -> the four corners of the
+  // convolved map); it is software-pipelined: the flows of the wave's 16 positions are fetched up front (lane i holds
+  // position i's), and the corner values of position it+1 are in flight while position it is processed.
+  constexpr int kWalk = kSmpPix / 4;
+  const int pw0 = p0 + wave * kWalk;
+  const int nwalk = max(0, min(kWalk, HW - pw0));
+  float fx_l = 0.f, fy_l = 0.f;
+  if ((lane & (kWalk - 1)) < nwalk) {
+    fx_l = flow[(b * 2 + 0) * HW + pw0 + (lane & (kWalk - 1))];
+    fy_l = flow[(b * 2 + 1) * HW + pw0 + (lane & (kWalk - 1))];
+  }
+  Corner cn;
+  float gn[8];
+  auto issue = [&](int it) {
+    const int p = pw0 + it;
+    const int y = p / W, x = p - y * W;
+    const float fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fx_l), it));
+    const float fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fy_l), it));
+    cn = corners<KS>(fx, fy, x, y, H, W, wps, wpz);
+    if (gflow) {
+      const float *g00 = gsb + (int64_t)cn.i00 * kFcHidden + lane, *g01 = gsb + (int64_t)cn.i01 * kFcHidden + lane;
+      const float *g10 = gsb + (int64_t)cn.i10 * kFcHidden + lane, *g11 = gsb + (int64_t)cn.i11 * kFcHidden + lane;
+      gn[0] = g00[0], gn[1] = g01[0], gn[2] = g10[0], gn[3] = g11[0];
+      gn[4] = g00[64], gn[5] = g01[64], gn[6] = g10[64], gn[7] = g11[64];
+    }
+  };
+  if (nwalk > 0) issue(0);
+  for (int it = 0; it < nwalk; ++it) {
+    const int pp = wave * kWalk + it, p = p0 + pp;
+    const Corner c = cn;
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = gn[i];
+    if (it + 1 < nwalk) issue(it + 1);
     const float d0 = tile[pp * kSmpPitch + lane], d1 = tile[pp * kSmpPitch + lane + 64];
     s0 += d0;
     s1 += d1;
-    const int y = p / W, x = p - y * W;
     if (ztb) {
+      const int y = p / W, x = p - y * W;
       float *zp = ztb + (int64_t)(lead_t + y * wpt + x) * kFcHidden + lane;
       zp[0] = d0;
       zp[64] = d1;
     }
-    const float fx = flow[(b * 2 + 0) * HW + p], fy = flow[(b * 2 + 1) * HW + p];
-    const Corner c = corners<KS>(fx, fy, x, y, H, W, wps, wpz);
     if (zsb) {
       const float wa = c.xl * c.yt, wb = c.xr * c.yt, wc = c.xl * c.yb, wd = c.xr * c.yb;
       float lt0 = wa * d0, lt1 = wa * d1, lb0 = wc * d0, lb1 = wc * d1;  // this position's left column
@@ -219,13 +248,9 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       pt0 = wb * d0, pt1 = wb * d1, pb0 = wd * d0, pb1 = wd * d1;
     }
     if (gflow) {
-      const float *g00 = gsb + (int64_t)c.i00 * kFcHidden + lane, *g01 = gsb + (int64_t)c.i01 * kFcHidden + lane;
-      const float *g10 = gsb + (int64_t)c.i10 * kFcHidden + lane, *g11 = gsb + (int64_t)c.i11 * kFcHidden + lane;
-      const float a00 = g00[0], a01 = g01[0], a10 = g10[0], a11 = g11[0];
-      const float e00 = g00[64], e01 = g01[64], e10 = g10[64], e11 = g11[64];
       // block_extractor_kernel.cu:160-161 with the convolved map in place of the source plane
-      float gx = d0 * (c.yt * (a01 - a00) + c.yb * (a11 - a10)) + d1 * (c.yt * (e01 - e00) + c.yb * (e11 - e10));
-      float gy = d0 * (c.xl * (a10 - a00) + c.xr * (a11 - a01)) + d1 * (c.xl * (e10 - e00) + c.xr * (e11 - e01));
+      float gx = d0 * (c.yt * (g[1] - g[0]) + c.yb * (g[3] - g[2])) + d1 * (c.yt * (g[5] - g[4]) + c.yb * (g[7] - g[6]));
+      float gy = d0 * (c.xl * (g[2] - g[0]) + c.xr * (g[3] - g[1])) + d1 * (c.xl * (g[6] - g[4]) + c.xr * (g[7] - g[5]));
       gx = wave_sum_f(gx);
       gy = wave_sum_f(gy);
       if (lane == 0) {  // this workgroup is the only writer of its pixels
@@ -394,12 +419,28 @@ __global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ 
   const int y0 = y == 0 ? 0 : y + pad_t, y1 = y == H - 1 ? Hp - 1 : y + pad_t;
   const float *src = dxpad + b * dx_bs + c0 + c;
   if (c0 + c < C) {
-    for (int x = xq; x < W; x += 4) {
-      const int x0 = x == 0 ? 0 : x + pad_l, x1 = x == W - 1 ? Wp - 1 : x + pad_l;
-      float acc = 0.f;
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) acc += src[(int64_t)(yy * Wp + xx) * C];
-      tile[c * (W + 1) + x] = acc;
+    constexpr int XU = 8;  // positions per thread and batch: their centre loads are issued together (one round trip)
+    for (int xb = xq; xb < W; xb += 4 * XU) {
+      float acc[XU];
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int x = min(xb + 4 * i, W - 1);
+        acc[i] = src[(int64_t)((y + pad_t) * Wp + x + pad_l) * C];
+      }
+#pragma unroll
+      for (int i = 0; i < XU; ++i) {
+        const int x = xb + 4 * i;
+        if (x >= W) break;
+        if (y == 0 || y == H - 1 || x == 0 || x == W - 1) {  // border: the padded positions that clamp onto (y, x)
+          const int x0 = x == 0 ? 0 : x + pad_l, x1 = x == W - 1 ? Wp - 1 : x + pad_l;
+          float extra = 0.f;
+          for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx)
+              if (yy != y + pad_t || xx != x + pad_l) extra += src[(int64_t)(yy * Wp + xx) * C];
+          acc[i] += extra;
+        }
+        tile[c * (W + 1) + x] = acc[i];
+      }
     }
   }
   __syncthreads();
