@@ -536,18 +536,29 @@ __device__ __forceinline__ void agg_chunk_load(const T *__restrict__ g, int n, f
     }
   }
 }
-__device__ __forceinline__ void agg_chunk_store(float *lds, int n, const f32x2 (&pre)[kAggPre], int per_plane, int wp,
-                                                unsigned m_pl, unsigned m_wp, int pitch, int plane_sz) {
+// LDS word offsets of the thread's kAggPre word pairs inside a chunk buffer (the same for every chunk: computed once,
+// two 16-bit offsets per register; the chunk buffer has < 2^16 words... in units of 2 words)
+__device__ __forceinline__ void agg_chunk_offsets(int n_max, int per_plane, int wp, int pitch, int plane_sz,
+                                                  unsigned (&off)[kAggPre / 2]) {
+  const unsigned m_pl = 0xffffffffu / (unsigned)per_plane + 1u, m_wp = 0xffffffffu / (unsigned)wp + 1u;  // n * d < 2^32
+#pragma unroll
+  for (int j = 0; j < kAggPre; ++j) {
+    const int i = min(j * (int)blockDim.x + (int)threadIdx.x, n_max - 1);
+    const int c = (int)__umulhi((unsigned)i, m_pl);
+    const int rem = i - c * per_plane;
+    const int y = (int)__umulhi((unsigned)rem, m_wp);
+    const int xp = rem - y * wp;
+    const unsigned o = (unsigned)(c * plane_sz + (y >> 1) * pitch + (xp << 2) + ((y & 1) << 1)) >> 1;  // even word -> /2
+    if (j & 1) off[j >> 1] |= o << 16; else off[j >> 1] = o;
+  }
+}
+__device__ __forceinline__ void agg_chunk_store(float *lds, int n, const f32x2 (&pre)[kAggPre],
+                                                const unsigned (&off)[kAggPre / 2]) {
 #pragma unroll
   for (int j = 0; j < kAggPre; ++j) {
     const int i = j * (int)blockDim.x + (int)threadIdx.x;
-    if (i < n) {
-      const int c = (int)__umulhi((unsigned)i, m_pl);
-      const int rem = i - c * per_plane;
-      const int y = (int)__umulhi((unsigned)rem, m_wp);
-      const int xp = rem - y * wp;
-      *reinterpret_cast<f32x2 *>(lds + c * plane_sz + (y >> 1) * pitch + (xp << 2) + ((y & 1) << 1)) = pre[j];
-    }
+    const unsigned o = (j & 1) ? off[j >> 1] >> 16 : off[j >> 1] & 0xffffu;
+    if (i < n) *reinterpret_cast<f32x2 *>(lds + 2 * o) = pre[j];
   }
 }
 
@@ -613,9 +624,10 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
 
   const int wp = Ws >> 1;              // word pairs per row (Ws is even)
   const int per_plane = Hs * wp;       // word pairs per plane
-  const unsigned m_pl = 0xffffffffu / (unsigned)per_plane + 1u, m_wp = 0xffffffffu / (unsigned)wp + 1u;
   const T *s0 = src + ((int64_t)b * C + c_begin) * Hs * Ws;
   f32x2 pre[kAggPre];
+  unsigned off[kAggPre / 2];
+  agg_chunk_offsets(CH * per_plane, per_plane, wp, pitch, plane_sz, off);
   int gc = min(CH, c_end - c_begin);
   agg_chunk_load<T>(s0, gc * per_plane, pre);
   {  // words no load ever writes must be finite: they meet weight 0
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
       if (threadIdx.x < 4) bf[CH * plane_sz + threadIdx.x] = 0.f;
     }
   }
-  agg_chunk_store(lds, gc * per_plane, pre, per_plane, wp, m_pl, m_wp, pitch, plane_sz);
+  agg_chunk_store(lds, gc * per_plane, pre, off);
   __syncthreads();
 
   int ro[K + 1];
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
   T *o = out + ((int64_t)b * C + c_begin) * HW + p;
   int cur = 0;
   for (int cb = c_begin; cb < c_end; cb += CH) {
-    const int gn = min(CH, c_end - cb - CH);  // planes of the next chunk (<= 0: none)
+    const int gn = min(CH, c_end - cb - CH);  // planes of the next chunk (<= 0: none): in flight during this one
     if (gn > 0) agg_chunk_load<T>(s0 + (int64_t)(cb + CH - c_begin) * Hs * Ws, gn * per_plane, pre);
     gc = min(CH, c_end - cb);
     const float *pl = lds + cur * buf_sz;
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
       }
     }
     cur ^= 1;
-    if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, per_plane, wp, m_pl, m_wp, pitch, plane_sz);
+    if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, off);
     __syncthreads();  // the next chunk has landed, and nobody still reads the buffer the one after it will overwrite
   }
 }
