@@ -145,78 +145,135 @@ struct AggTaps {
   }
 };
 
-// grid (ntiles, B), 256 threads = 32 pixels x 8 entry slots.  The attention weights and the per-pixel tap geometry of
-// the tile go through LDS (loaded / computed once, then read by the 8 threads that share a pixel).
+// grid (ceil(ntiles / 8), B), 256 threads: thread = flow pixel, a half wave = one 32-pixel tile of the scatter kernel.
+// Everything of a pixel stays in registers: the (K+1)^2 patch coefficients (attention x bilinear weights / k^2,
+// block_extractor_kernel.cu:158-161 folded), then the clamp fold -- entries that clamp onto the same border position
+// are summed into one carrier entry (pm_fold) -- as two separable passes of statically indexed, predicated sums
+// (columns, then rows).  (Round 2's first version walked five nested runtime loops over LDS per entry: 54 us.)
 template <int K>
 __global__ __launch_bounds__(256) void agg_patch_table_kernel(const float *__restrict__ flow,
                                                              const float *__restrict__ attn,
                                                              PatchEntry *__restrict__ table,
                                                              int2 *__restrict__ tile_rows,
-                                                             unsigned *__restrict__ stat, int H, int W, int Hs, int Ws) {
+                                                             unsigned *__restrict__ stat, int H, int W, int Hs, int Ws,
+                                                             int ntiles) {
   constexpr int P = K + 1, E = P * P, KK = K * K;
-  __shared__ float s_a[KK][kPmTile + 1];        // attention / k^2
-  __shared__ float s_ax[K][kPmTile], s_ay[K][kPmTile];  // fractional parts of the taps
-  __shared__ int s_x0[kPmTile], s_y0[kPmTile];  // patch anchor; y0 = INT_MIN: not a dense patch / no pixel
-  const int tile = blockIdx.x, ntiles = gridDim.x;
+  static_assert(E % 2 == 0, "entries are written two at a time");
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   const int64_t b = blockIdx.y;
   const int HW = H * W;
-  const int p0 = tile * kPmTile;
+  const int tile = blockIdx.x * 8 + (threadIdx.x >> 5), pl = threadIdx.x & 31;
+  if (tile >= ntiles) return;  // whole half waves leave together
+  const int p = tile * kPmTile + pl;
   const float inv_kk = 1.f / (float)KK;
-  for (int i = threadIdx.x; i < KK * kPmTile; i += 256) {
-    const int ij = i >> 5, pl = i & 31;
-    s_a[ij][pl] = p0 + pl < HW ? attn[(b * KK + ij) * (int64_t)HW + p0 + pl] * inv_kk : 0.f;
-  }
-  if (threadIdx.x < kPmTile) {
-    const int pl = threadIdx.x, p = p0 + pl;
-    int y0 = (int)0x80000000, x0 = 0;
-    if (p < HW) {
-      const int yf = p / W, xf = p - yf * W;
-      AggTaps<K> tp;
-      tp.init(flow[(b * 2 + 0) * HW + p], flow[(b * 2 + 1) * HW + p], xf, yf);
-      if (tp.dense) {
-        y0 = pm_safe_int((float)tp.y0);
-        x0 = pm_safe_int((float)tp.x0);
-      }
-#pragma unroll
-      for (int t = 0; t < K; ++t) {
-        s_ax[t][pl] = tp.ax(t);
-        s_ay[t][pl] = tp.ay(t);
-      }
-    }
-    s_x0[pl] = x0;
-    s_y0[pl] = y0;
-  }
-  __syncthreads();
-  const int pl = threadIdx.x >> 3, sub = threadIdx.x & (kPmSub - 1);
-  PatchEntry *out = table + ((b * ntiles + tile) * kPmTile + pl) * (int64_t)E;
   int lo = 0x7fffffff, hi = -1;
-  const int y0 = s_y0[pl], x0 = s_x0[pl];
-  if (y0 != (int)0x80000000) {
+  i32x4 *out = reinterpret_cast<i32x4 *>(table + ((b * ntiles + tile) * kPmTile + pl) * (int64_t)E);
+  bool dense = false;
+  AggTaps<K> tp;
+  if (p < HW) {
+    const int yf = p / W, xf = p - yf * W;
+    tp.init(flow[(b * 2 + 0) * HW + p], flow[(b * 2 + 1) * HW + p], xf, yf);
+    dense = tp.dense;
+  }
+  if (dense) {
+    const int y0 = pm_safe_int((float)tp.y0), x0 = pm_safe_int((float)tp.x0);
     lo = clampi(y0, 0, Hs - 1);
     hi = clampi(y0 + K, 0, Hs - 1);
-    for (int e = sub; e < E; e += kPmSub) {
-      const int r = e / P, s = e - r * P;
-      const Fold f = pm_fold(r, s, y0, x0, P, Hs, Ws);
-      float v = 0.f;
-      if (f.canonical) {
-        for (int rr = f.r_lo; rr <= f.r_hi; ++rr)
-          for (int ss = f.s_lo; ss <= f.s_hi; ++ss) {
-            // patch entry (rr, ss) = taps (i, j) in {rr-1, rr} x {ss-1, ss}: block_extractor_kernel.cu:158-161 folded
-            for (int i = max(rr - 1, 0); i <= min(rr, K - 1); ++i) {
-              const float a_y = s_ay[i][pl], wy = rr == i ? 1.f - a_y : a_y;
-              for (int j = max(ss - 1, 0); j <= min(ss, K - 1); ++j) {
-                const float a_x = s_ax[j][pl], wx = ss == j ? 1.f - a_x : a_x;
-                v += s_a[i * K + j][pl] * wx * wy;
-              }
-            }
-          }
-      }
-      out[e] = f.canonical ? PatchEntry{(f.ty << 16) | f.tx, v} : PatchEntry{-1, 0.f};
+    float a[KK];
+    const float *at = attn + b * (int64_t)KK * HW + p;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) a[t] = at[(int64_t)t * HW] * inv_kk;
+    float ax[K], ay[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      ax[t] = tp.ax(t);
+      ay[t] = tp.ay(t);
     }
+    float v[P][P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) v[r][q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float wrow = 0.f;  // attention mass of tap column j that lands on patch row r
+        if (r < K) wrow += a[r * K + j] * (1.f - ay[r]);
+        if (r > 0) wrow += a[(r - 1) * K + j] * ay[r - 1];
+        v[r][j] += wrow * (1.f - ax[j]);
+        v[r][j + 1] += wrow * ax[j];
+      }
+    }
+    // pm_fold, one axis at a time: [lo_, hi_] = the entries summed into entry i, can_ = i carries that sum
+    int clo[P], chi[P], rlo[P], rhi[P], tx[P], ty[P];
+    bool ccan[P], rcan[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int xx = x0 + i, yy = y0 + i;
+      clo[i] = chi[i] = rlo[i] = rhi[i] = i;
+      ccan[i] = rcan[i] = true;
+      if (xx <= 0) {
+        clo[i] = 0;
+        ccan[i] = xx == 0 || i == P - 1;
+      } else if (xx >= Ws - 1) {
+        chi[i] = P - 1;
+        ccan[i] = xx == Ws - 1 || i == 0;
+      }
+      if (yy <= 0) {
+        rlo[i] = 0;
+        rcan[i] = yy == 0 || i == P - 1;
+      } else if (yy >= Hs - 1) {
+        rhi[i] = P - 1;
+        rcan[i] = yy == Hs - 1 || i == 0;
+      }
+      tx[i] = clampi(xx, 0, Ws - 1);
+      ty[i] = clampi(yy, 0, Hs - 1);
+    }
+    float cf[P][P];
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q2 = 0; q2 < P; ++q2) acc += (q2 >= clo[q] && q2 <= chi[q]) ? v[r][q2] : 0.f;
+        cf[r][q] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+#pragma unroll
+      for (int q = 0; q < P; q += 2) {
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int r2 = 0; r2 < P; ++r2) {
+          const bool in = r2 >= rlo[r] && r2 <= rhi[r];
+          acc0 += in ? cf[r2][q] : 0.f;
+          acc1 += in ? cf[r2][q + 1] : 0.f;
+        }
+        const bool c0 = rcan[r] && ccan[q], c1 = rcan[r] && ccan[q + 1];
+        i32x4 e;
+        e.x = c0 ? (ty[r] << 16) | tx[q] : -1;
+        e.y = c0 ? __float_as_int(acc0) : 0;
+        e.z = c1 ? (ty[r] << 16) | tx[q + 1] : -1;
+        e.w = c1 ? __float_as_int(acc1) : 0;
+        out[(r * P + q) >> 1] = e;
+      }
   } else {
-    for (int e = sub; e < E; e += kPmSub) out[e] = PatchEntry{-1, 0.f};
+    const i32x4 none = {-1, 0, -1, 0};
+#pragma unroll
+    for (int e = 0; e < E / 2; ++e) out[e] = none;
   }
-  pm_store_tile_rows(lo, hi, tile_rows + b * ntiles + tile, stat);
+  // (lo, hi) of the rows the tile reaches: reduction over the 32 lanes of the half wave
+#pragma unroll
+  for (int msk = 16; msk >= 1; msk >>= 1) {
+    lo = min(lo, __shfl_xor(lo, msk));
+    hi = max(hi, __shfl_xor(hi, msk));
+  }
+  if (pl == 0) {
+    tile_rows[b * ntiles + tile] = make_int2(lo, hi);
+    // dispatch statistic: source rows reached, summed over the tiles (how far the flow spreads the tiles' patches);
+    // spread over kPmStatSlots counters -- thousands of atomics on ONE address serialise (~12 ns each)
+    if (hi >= lo) atomicAdd(stat + (tile + (int)b * ntiles) % kPmStatSlots, (unsigned)(hi - lo + 1));
+  }
 }
 
 // Pixels that are not a dense patch: the reference's tap-by-tap scatter with global atomics (rare: a tap within
@@ -562,11 +619,11 @@ int agg_source_bwd_mfma(const float *flow, const float *attn, const float *gout,
   unsigned *stat = reinterpret_cast<unsigned *>(ws + L.table_bytes + L.rows_bytes);
   const unsigned limit = pm_limit(B, L.ntiles, (int)W, k + 1, adaptive != 0);
   if (hipMemsetAsync(stat, 0, kPmStatSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  const dim3 tg((unsigned)L.ntiles, (unsigned)B);
+  const dim3 tg((unsigned)ceil_div(L.ntiles, 8), (unsigned)B);
   if (k == 3)
-    agg_patch_table_kernel<3><<<tg, 256, 0, stream>>>(flow, attn, table, rows, stat, (int)H, (int)W, (int)Hs, (int)Ws);
+    agg_patch_table_kernel<3><<<tg, 256, 0, stream>>>(flow, attn, table, rows, stat, (int)H, (int)W, (int)Hs, (int)Ws, (int)L.ntiles);
   else
-    agg_patch_table_kernel<5><<<tg, 256, 0, stream>>>(flow, attn, table, rows, stat, (int)H, (int)W, (int)Hs, (int)Ws);
+    agg_patch_table_kernel<5><<<tg, 256, 0, stream>>>(flow, attn, table, rows, stat, (int)H, (int)W, (int)Hs, (int)Ws, (int)L.ntiles);
   int st = launch_status();
   if (st != GFLA_OK) return st;
   st = pm_scatter(gout, gsrc, table, rows, B, C, H, W, Hs, Ws, entries, k + 1, accumulate, stat, limit, stream);
