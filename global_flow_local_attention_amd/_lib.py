@@ -53,6 +53,7 @@ _SINGLE = {
     "gfla_fc_kernel_f32": [_int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_scatter_workspace_bytes": [_i64] * 3 + [_int],
     "gfla_aggregate_fwd_workspace_bytes": [_i64] * 3 + [_int],
+    "gfla_aggregate_fwd_geometry": [_i64] * 6 + [_int, _ptr],
     "gfla_local_attn_aggregate_fwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],

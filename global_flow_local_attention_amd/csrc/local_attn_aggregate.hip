@@ -1210,6 +1210,20 @@ int64_t gfla_aggregate_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int 
   for (int l = 3; l <= 5; ++l) tiles = std::max<int64_t>(tiles, gfla::ceil_div(W, 1 << l) * gfla::ceil_div(H, 64 >> l));
   return B * tiles * 64 * (int64_t)gfla::agg_record_floats(k) * 4;
 }
+/* launch geometry of the table path (host logic only, for the CPU tests):
+ * out[0..8] = channels per chunk, channels per range, ranges, tile groups, threads, LDS row-pair pitch (words), tile
+ * width, tiles per sample, dynamic LDS bytes; returns GFLA_ERR_UNSUPPORTED where the plain kernels are used */
+int gfla_aggregate_fwd_geometry(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int64_t *out) {
+  if (!out) return GFLA_ERR_NULL_POINTER;
+  if (B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || k < 1 || k > 5) return GFLA_ERR_BAD_SHAPE;
+  if (!(k & 1) || Ws < k + 1 || (Ws & 1) || Ws >= 32768 || Hs >= 32000 || B * C * Hs * Ws >= (1LL << 31) || B > 65535)
+    return GFLA_ERR_UNSUPPORTED;
+  const gfla::AggStreamGeo g = gfla::agg_stream_geometry(B, C, Hs, Ws, H, W, k);
+  if (g.CH <= 0) return GFLA_ERR_UNSUPPORTED;
+  const int64_t v[9] = {g.CH, g.CS, g.nsuper, g.tgroups, g.threads, g.pitch, 1 << g.tw_log2, g.ntile, g.lds};
+  for (int i = 0; i < 9; ++i) out[i] = v[i];
+  return GFLA_OK;
+}
 int gfla_local_attn_aggregate_fwd_ws_f32(const float *s, const float *f, const float *l, float *o, float *a,
                                          void *workspace, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H,
                                          int64_t W, int k, int sm, gfla_stream_t st) {

@@ -202,6 +202,10 @@ GFLA_DECL_AGGREGATE_FWD(bf16, uint16_t)
  * plain entry point's kernels.  Same results up to f32 summation order (the coefficient of a patch word is summed
  * over its taps before it meets the source value).                                                            */
 int64_t gfla_aggregate_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int kernel_size);
+/* host-side launch geometry of that path (no GPU needed; tests): out[9] = channels per chunk, channels per range,
+ * ranges, tile groups, threads, LDS row-pair pitch in words, tile width, tiles per sample, dynamic LDS bytes */
+int gfla_aggregate_fwd_geometry(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int kernel_size,
+                                int64_t *out);
 int gfla_local_attn_aggregate_fwd_ws_f32(const float *source, const float *flow, const float *logits, float *out,
                                          float *attn_out, void *workspace, int64_t B, int64_t C, int64_t Hs,
                                          int64_t Ws, int64_t H, int64_t W, int kernel_size, int apply_softmax,

@@ -95,3 +95,38 @@ print('ok')
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_aggregate_forward_table_path_geometry_invariants():
+    """Host-side launch logic of the coefficient-table aggregation forward (csrc/local_attn_aggregate.hip), swept over
+    shapes without a GPU: whatever it picks has to fit the hardware (160 KB of LDS, 12 waves per workgroup), cover every
+    channel and tile, keep the staging within its per-thread budget of word pairs, and keep the LDS pitch on the
+    conflict-free residue; the scratch the size query promises has to hold a record for every tile slot."""
+    from global_flow_local_attention_amd import _lib
+    L = _lib.lib()
+    out = (ctypes.c_int64 * 9)()
+    seen = 0
+    for B in (1, 2, 8, 32, 256):
+        for C in (1, 3, 16, 64, 128, 256, 512):
+            for (H, W) in ((8, 8), (32, 22), (64, 44), (64, 64), (32, 32), (128, 88), (256, 176), (7, 6), (9, 130)):
+                for k in (1, 3, 5):
+                    rc = L.gfla_aggregate_fwd_geometry(B, C, H, W, H, W, k, ctypes.cast(out, ctypes.c_void_p))
+                    if W < k + 1 or W % 2:
+                        assert rc == -3
+                        continue
+                    if rc == -3:      # plane too large for two LDS buffers: the plain kernels take it
+                        assert H * W * 4 * 2 > 60 * 1024
+                        continue
+                    assert rc == 0, (B, C, H, W, k, rc)
+                    CH, CS, ns, tg, threads, pitch, tw, ntile, lds = list(out)
+                    seen += 1
+                    assert 1 <= CH <= C and CS % CH == 0 and ns * CS >= C and (ns - 1) * CS < C
+                    assert threads % 64 == 0 and 64 <= threads <= 12 * 64
+                    assert tw in (8, 16, 32) and ntile == -(-W // tw) * -(-H // (64 // tw))
+                    assert tg * (threads // 64) >= ntile                    # every tile has a wave
+                    assert pitch >= 2 * W and pitch % 64 == 32
+                    per_plane = -(-H // 2) * pitch * 4
+                    assert lds == 2 * (CH * per_plane + 16) and lds <= 160 * 1024
+                    assert CH * H * (W // 2) <= 8 * threads                 # word pairs per thread and chunk
+                    assert L.gfla_aggregate_fwd_workspace_bytes(B, H, W, k) >= B * ntile * 64 * (((k + 1) * (k + 2) + 4) // 4 * 4) * 4
+    assert seen > 300
