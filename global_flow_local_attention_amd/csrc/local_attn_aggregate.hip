@@ -956,6 +956,219 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
   }
 }
 
+// d/d a_ij and d/d flow with the machinery of agg_fwd_stream_kernel (same workgroup <-> (sample, tile group, channel
+// range) decomposition, same double-buffered interleaved planes, same paired reads): per channel the lane accumulates
+// g_c * v_c over its (K+1) x (K+2)-word aligned WINDOW (48 packed-FMA accumulators for K = 5) instead of reading the
+// (K+1)^2 patch with clamped per-column ds_read_b32; the window sums are mapped back to patch sums once per pixel at
+// the end (an 8-way select per patch entry: the x clamp and the window's parity), then mixed into d/d a_ij and
+// d/d flow exactly as agg_ga_lds_kernel does.  One atomic per (ij, channel range) publishes the sums.
+template <typename T, int K>
+__global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
+    const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout, float *__restrict__ glogits,
+    const T *__restrict__ attn, float *__restrict__ gflow, int C, int Hs, int Ws, int H, int W, int CH, int CS,
+    int nsuper, int tgroups, int pitch, int total, int tw_log2, int ntile) {
+  constexpr int KK = K * K, NP = (K + 1) / 2, NW = 2 * NP + 2;  // NW = words of the row window (K + 3)
+  static_assert(K % 2 == 1, "paired reads are laid out for odd K");
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *lds = reinterpret_cast<float *>(gfla_smem);
+  const int per_xcd = (total + kNumXCD - 1) / kNumXCD;
+  int bid = (blockIdx.x % kNumXCD) * per_xcd + blockIdx.x / kNumXCD;
+  if (bid >= total) return;
+  const int tg = bid % tgroups;
+  bid /= tgroups;
+  const int sg = bid % nsuper;
+  const int b = bid / nsuper;
+  const int c_begin = sg * CS, c_end = min(C, c_begin + CS);
+  const int plane_sz = ((Hs + 1) >> 1) * pitch;
+  const int buf_sz = CH * plane_sz + 4;
+  const int HW = H * W;
+  const float inv_kk = 1.f / (float)KK;
+  const int tw = 1 << tw_log2, th = 64 >> tw_log2;
+  const int tiles_x = (W + tw - 1) >> tw_log2;
+  const int lane = threadIdx.x & 63;
+  const int t = tg * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  bool active = false;
+  int p = 0, yf = 0, xf = 0;
+  if (t < ntile) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    yf = ty * th + (lane >> tw_log2);
+    xf = (tx << tw_log2) + (lane & (tw - 1));
+    active = yf < H && xf < W;
+    if (active) p = yf * W + xf;
+  }
+  const float fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
+  const float fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+  PatchTaps<float, K> tp;
+  tp.init(fx0, fy0, xf, yf, Hs, Ws);
+  const bool dense = active && tp.dense;
+  // even-aligned window [xa, xa + K + 2] that holds every clamped column of the patch (as agg_coef_kernel)
+  const int xa = clampi(tp.x0, 0, Ws - (K + 1)) & ~1;
+  int ro[K + 1];
+#pragma unroll
+  for (int r = 0; r <= K; ++r) {
+    const int yc = clampi(tp.y0 + r, 0, Hs - 1);
+    ro[r] = (yc >> 1) * pitch + ((yc & 1) << 1) + (xa << 1);
+  }
+  f32x2 Pw[K + 1][NP + 1];  // window sums: words (2i, 2i+1) of patch row r
+#pragma unroll
+  for (int r = 0; r <= K; ++r)
+#pragma unroll
+    for (int i = 0; i <= NP; ++i) Pw[r][i] = f32x2{0.f, 0.f};
+  float *gl = glogits ? glogits + (int64_t)b * KK * HW + p : nullptr;
+  const T *at = attn ? attn + (int64_t)b * KK * HW + p : nullptr;
+  float gx_acc = 0.f, gy_acc = 0.f;
+
+  const int wp = Ws >> 1, per_plane = Hs * wp;
+  const T *s0 = src + ((int64_t)b * C + c_begin) * Hs * Ws;
+  f32x2 pre[kAggPre];
+  unsigned off[kAggPre / 2];
+  agg_chunk_offsets(CH * per_plane, per_plane, wp, pitch, plane_sz, off);
+  int gc = min(CH, c_end - c_begin);
+  agg_chunk_load<T>(s0, gc * per_plane, pre);
+  {  // words no load ever writes must be finite: they meet weight 0 / are never selected
+    const int nrow = CH * ((Hs + 1) >> 1);
+    for (int u = 0; u < 2; ++u) {
+      float *bf = lds + u * buf_sz;
+      if (pitch >= 2 * Ws + 4)
+        for (int i = threadIdx.x; i < nrow * 4; i += blockDim.x) bf[(i >> 2) * pitch + 2 * Ws + (i & 3)] = 0.f;
+      if (threadIdx.x < 4) bf[CH * plane_sz + threadIdx.x] = 0.f;
+    }
+  }
+  agg_chunk_store(lds, gc * per_plane, pre, off);
+  __syncthreads();
+
+  const T *go_p = gout + ((int64_t)b * C + c_begin) * HW + p;
+  int cur = 0;
+  for (int cb = c_begin; cb < c_end; cb += CH) {
+    const int gn = min(CH, c_end - cb - CH);
+    if (gn > 0) agg_chunk_load<T>(s0 + (int64_t)(cb + CH - c_begin) * Hs * Ws, gn * per_plane, pre);
+    gc = min(CH, c_end - cb);
+    const float *pl = lds + cur * buf_sz;
+    if (dense) {
+      auto load_row = [&](const float *rp, f32x2(&v)[NP + 1]) {
+#pragma unroll
+        for (int i = 0; i <= NP; ++i) {
+          v[i] = *reinterpret_cast<const f32x2 *>(rp + 4 * i);
+          asm volatile("" ::: "memory");
+        }
+      };
+      int c = 0;
+      for (; c + 2 <= gc; c += 2) {
+        const float g0 = Num<T>::ld(go_p) * inv_kk, g1 = Num<T>::ld(go_p + HW) * inv_kk;
+        const f32x2 gg0 = {g0, g0}, gg1 = {g1, g1};
+        f32x2 v0[2][NP + 1], v1[2][NP + 1];
+        load_row(pl + ro[0], v0[0]);
+        load_row(pl + plane_sz + ro[0], v1[0]);
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          if (r < K) {
+            load_row(pl + ro[r + 1], v0[(r + 1) & 1]);
+            load_row(pl + plane_sz + ro[r + 1], v1[(r + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i <= NP; ++i) {
+            Pw[r][i] = __builtin_elementwise_fma(gg0, v0[r & 1][i], Pw[r][i]);
+            Pw[r][i] = __builtin_elementwise_fma(gg1, v1[r & 1][i], Pw[r][i]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        go_p += 2 * (int64_t)HW;
+        pl += 2 * plane_sz;
+      }
+      if (c < gc) {
+        const float g0 = Num<T>::ld(go_p) * inv_kk;
+        const f32x2 gg0 = {g0, g0};
+#pragma unroll
+        for (int r = 0; r <= K; ++r) {
+          f32x2 v[NP + 1];
+          load_row(pl + ro[r], v);
+#pragma unroll
+          for (int i = 0; i <= NP; ++i) Pw[r][i] = __builtin_elementwise_fma(gg0, v[i], Pw[r][i]);
+        }
+        go_p += HW;
+      }
+    } else if (active) {
+      // rare (a tap within rounding of an integer): tap by tap, published directly
+      for (int c = 0; c < gc; ++c) {
+        const float go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
+        const float *plc = pl + (size_t)c * plane_sz;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+          const float dy = (fy0 + (float)(i - K / 2)) + (float)yf;
+          const float fdy = floorf(dy);
+          const int yTc = clampi((int)fdy, 0, Hs - 1), yBc = clampi((int)(fdy + 1), 0, Hs - 1);
+          const int yT = (yTc >> 1) * pitch + ((yTc & 1) << 1), yB = (yBc >> 1) * pitch + ((yBc & 1) << 1);
+          const float yB_P = dy - fdy, yT_P = 1 - yB_P;
+#pragma unroll 1
+          for (int j = 0; j < K; ++j) {
+            const float dx = (fx0 + (float)(j - K / 2)) + (float)xf;
+            const float fdx = floorf(dx);
+            const int xLc = clampi((int)fdx, 0, Ws - 1), xRc = clampi((int)(fdx + 1), 0, Ws - 1);
+            const int xL = ((xLc >> 1) << 2) + (xLc & 1), xR = ((xRc >> 1) << 2) + (xRc & 1);
+            const float xR_P = dx - fdx, xL_P = 1 - xR_P;
+            const float vTL = plc[yT + xL], vTR = plc[yT + xR], vBL = plc[yB + xL], vBR = plc[yB + xR];
+            float bs = (xL_P * yT_P) * vTL;
+            bs += (xR_P * yT_P) * vTR;
+            bs += (xL_P * yB_P) * vBL;
+            bs += (xR_P * yB_P) * vBR;
+            if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, go * bs);
+            if (gflow) {
+              const float gv = Num<T>::ld(at + (int64_t)(i * K + j) * HW) * go;
+              gy_acc += gv * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
+              gx_acc += gv * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
+            }
+          }
+        }
+      }
+      go_p += (int64_t)gc * HW;
+    }
+    cur ^= 1;
+    if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, off);
+    __syncthreads();
+  }
+
+  if (dense) {
+    // window sums -> patch sums: P[r][q] = Pw[r][clamp(x0 + q) - xa]  (the slot is in [0, K + 2]; select chain on
+    // statically indexed registers)
+    int slot[K + 1];
+#pragma unroll
+    for (int q = 0; q <= K; ++q) slot[q] = clampi(tp.x0 + q, 0, Ws - 1) - xa;
+    float P[K + 1][K + 1];
+#pragma unroll
+    for (int r = 0; r <= K; ++r)
+#pragma unroll
+      for (int q = 0; q <= K; ++q) {
+        float v = Pw[r][0].x;
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v = slot[q] == w ? ((w & 1) ? Pw[r][w >> 1].y : Pw[r][w >> 1].x) : v;
+        P[r][q] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float yT_P = 1 - tp.ay[i], yB_P = tp.ay[i];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float xL_P = 1 - tp.ax[j], xR_P = tp.ax[j];
+        float ga = (xL_P * yT_P) * P[i][j];  // block_extractor_kernel.cu:78-84
+        ga += (xR_P * yT_P) * P[i][j + 1];
+        ga += (xL_P * yB_P) * P[i + 1][j];
+        ga += (xR_P * yB_P) * P[i + 1][j + 1];
+        if (gl) atomic_add(gl + (int64_t)(i * K + j) * HW, ga);
+        if (gflow) {
+          const float a_ij = Num<T>::ld(at + (int64_t)(i * K + j) * HW);
+          gy_acc += a_ij * (-xL_P * P[i][j] - xR_P * P[i][j + 1] + xL_P * P[i + 1][j] + xR_P * P[i + 1][j + 1]);
+          gx_acc += a_ij * (-yT_P * P[i][j] - yB_P * P[i + 1][j] + yT_P * P[i][j + 1] + yB_P * P[i + 1][j + 1]);
+        }
+      }
+    }
+  }
+  if (active && gflow) {
+    atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, gx_acc);
+    atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, gy_acc);
+  }
+}
+
 // In place: glogits holds ga (d/d a_ij); turn it into d/d logit_ij = a_ij * (ga_ij - sum_mn a_mn ga_mn).
 template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void agg_softmax_bwd_kernel(const T *__restrict__ attn,
@@ -1071,6 +1284,35 @@ template <typename T>
 static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *gout, typename Num<T>::acc *glogits,
                          typename Num<T>::acc *gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int k, int sm, hipStream_t stream) {
   using A = typename Num<T>::acc;
+  if constexpr (std::is_same<A, float>::value) {
+    // streaming kernel (interleaved planes, paired reads); tuning key 8 = 1: round 1's kernel
+    if (tuning(3) != 1 && tuning(8) != 1 && (k >= 5 || tuning(8) == 2) && (k & 1) && Ws >= k + 1 && !(Ws & 1) && Ws < 32768 && Hs < 32000 &&
+        B * C * Hs * Ws < (1LL << 31)) {
+      const AggStreamGeo pg = agg_stream_geometry(B, C, Hs, Ws, H, W, k);
+      const int64_t total = B * pg.nsuper * pg.tgroups;
+      const int64_t padded = ceil_div(total, kNumXCD) * kNumXCD;
+      if (pg.CH > 0 && padded <= 0x7fffffffLL) {
+#define GFLA_AGG_GA(KV)                                                                                                  \
+  launch_lds(agg_ga_stream_kernel<T, KV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, gout,     \
+             (float *)glogits, gflow ? attn : (const T *)nullptr, (float *)gflow, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, \
+             pg.CH, pg.CS, pg.nsuper, pg.tgroups, pg.pitch, (int)total, pg.tw_log2, pg.ntile)
+        switch (k) {
+          case 1: GFLA_AGG_GA(1); break;
+          case 3: GFLA_AGG_GA(3); break;
+          default: GFLA_AGG_GA(5); break;
+        }
+#undef GFLA_AGG_GA
+        int st = launch_status();
+        if (st == GFLA_OK && sm && glogits) {
+          const int64_t n = B * H * W;
+          GFLA_K_SWITCH(k, agg_softmax_bwd_kernel<T, K><<<dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, stream>>>(
+                               attn, glogits, n, (int)(H * W)));
+          st = launch_status();
+        }
+        return st;
+      }
+    }
+  }
   const int threads = 512;
   const int64_t ntiles = ceil_div(H * W, threads);
   int64_t G = kLdsBudget / (Hs * Ws * (int64_t)sizeof(A));

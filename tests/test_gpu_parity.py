@@ -847,3 +847,40 @@ def test_aggregate_forward_table_path(gfla, oracle, kernel_variant, shape, kind,
             gfla.set_tuning(8, 0)
         err = max_abs(ob.float().cpu(), refb.float()) / max(1e-30, refb.abs().max().item())
         assert err <= 2 ** -7, err
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 12, 10), (1, 37, 33, 22), (3, 4, 6, 6), (2, 70, 64, 44), (2, 6, 7, 13)])
+@pytest.mark.parametrize("kind", ["zero", "smooth", "wild", "near_integer"])
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_aggregate_backward_stream_path(gfla, oracle, kernel_variant, shape, kind, k):
+    """d/d logits and d/d flow of the aggregation through agg_ga_stream_kernel, forced for every odd k (tuning key 8 = 2;
+    default from k = 5), against autograd through the float64 oracle chain: the window sums have to map back onto the
+    patch for clamped columns (wild flows, maps one patch wide), tile overhangs, several chunks and channel ranges, and
+    pixels that are not a dense patch."""
+    if kernel_variant == "global":
+        pytest.skip("stream path is part of the default dispatch only")
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = shape
+    s = randn((B, C, H, W), seed=81)
+    if kind == "near_integer":
+        f = make_flow("integer", B, H, W, seed=82)
+        f = f + torch.where(randn((B, 2, H, W), seed=83) > 0, 1.0, -1.0) * 2.0 ** -22
+    else:
+        f = make_flow(kind, B, H, W, seed=82)
+    lg = randn((B, k * k, H, W), seed=84) * 2
+    go = randn((B, C, H, W), seed=85)
+    s64, f64, l64 = s.double(), f.double().requires_grad_(), lg.double().requires_grad_()
+    a = torch.softmax(l64, 1)
+    ref = F.avg_pool2d(F.pixel_shuffle(a, k) * oracle.block_extractor_gather(s64, f64, k), k, k)
+    ref.backward(go.double())
+    sd, fd, ad, god = s.to(DEV), f.to(DEV), a.detach().float().to(DEV).contiguous(), go.to(DEV)
+    gl, gf = torch.zeros_like(ad), torch.zeros_like(fd)
+    gfla.set_tuning(8, 2)
+    try:
+        _lib.call("gfla_local_attn_aggregate_bwd_f32", sd, _lib.ptr(sd), _lib.ptr(fd), _lib.ptr(ad), _lib.ptr(god), None,
+                  _lib.ptr(gf), _lib.ptr(gl), B, C, H, W, H, W, k, 1)
+    finally:
+        gfla.set_tuning(8, 0)
+    assert_close(gl.cpu(), l64.grad.float(), F32_GRAD, "grad_logits")
+    if kind != "near_integer":   # at (near-)integer flows the bilinear kink makes autograd's one-sided choice arbitrary
+        assert_close(gf.cpu(), f64.grad.float(), F32_GRAD * 4, "grad_flow")
