@@ -1,13 +1,15 @@
 #!/usr/bin/env bash
 # Round-end evidence in one GPU call: HBM traffic counters of the bench step (-> profiles/pmc_traffic.json), MFMA-pipe
 # utilisation of the FC kernels, LDS counters of the aggregation forward before / after, kernel trace of the default
-# bench (steady-state per-step table), then the default bench itself (its roofline.traffic reads the fresh json).
+# bench (steady-state per-step table); the default bench itself runs first (its roofline.traffic reads the committed json).
 # usage: gpurun --timeout 2400 -- 'bash tools/gpu_final.sh <tag>'
 set -uo pipefail
 TAG="${1:-final}"
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the default bench FIRST: after rocprofv3 --pmc passes in the same job the f32-MFMA kernels run ~10 % slower for a while
+( time timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
 BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants"
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_$C -o pmc -- $BENCH > $OUT/pmc_$C.log 2>&1); echo "$C rc=$?"
@@ -22,4 +24,3 @@ cat $OUT/agg_lds/pmc_summary.txt | cut -c1-330
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_trace -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants > $OUT/rocprof_bench.log 2>&1); echo "trace rc=$?"
 cp /tmp/fin_trace/bench_kernel_stats.csv $OUT/ 2>/dev/null
 python tools/trace_steps.py /tmp/fin_trace/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -48 $OUT/steady_state_steps.txt
-( time timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
