@@ -18,6 +18,7 @@
 #include "gfla_common.h"
 #include "be_bwd_lds.h"
 #include "patch_mfma.h"
+#include "rs_taps.h"
 
 namespace gfla {
 
@@ -962,7 +963,10 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
 // (K+1)^2 patch with clamped per-column ds_read_b32; the window sums are mapped back to patch sums once per pixel at
 // the end (an 8-way select per patch entry: the x clamp and the window's parity), then mixed into d/d a_ij and
 // d/d flow exactly as agg_ga_lds_kernel does.  One atomic per (ij, channel range) publishes the sums.
-template <typename T, int K>
+// EPI = 1: the same accumulation for resample2d's d/d input2 (kernel_size 4, dilation 1: a K = 3 patch around
+// floor(p + flow) - 1): `flow` is input2 (dx, dy, sigma), `gflow` its (B, 3, H, W) gradient, the epilogue is
+// rs_bwd2_finish on the row / column sums of the patch sums (resample2d_kernel.cu:273-328); glogits / attn unused.
+template <typename T, int K, int EPI = 0>
 __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout, float *__restrict__ glogits,
     const T *__restrict__ attn, float *__restrict__ gflow, int C, int Hs, int Ws, int H, int W, int CH, int CS,
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
   const int plane_sz = ((Hs + 1) >> 1) * pitch;
   const int buf_sz = CH * plane_sz + 4;
   const int HW = H * W;
-  const float inv_kk = 1.f / (float)KK;
+  const float inv_kk = EPI == 1 ? 1.f : 1.f / (float)KK;
   const int tw = 1 << tw_log2, th = 64 >> tw_log2;
   const int tiles_x = (W + tw - 1) >> tw_log2;
   const int lane = threadIdx.x & 63;
@@ -996,17 +1000,31 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
     active = yf < H && xf < W;
     if (active) p = yf * W + xf;
   }
-  const float fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
-  const float fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
+  constexpr int NF = EPI == 1 ? 3 : 2;  // planes of `flow`
+  const float fx0 = Num<T>::ld(flow + (int64_t)(b * NF + 0) * HW + p);
+  const float fy0 = Num<T>::ld(flow + (int64_t)(b * NF + 1) * HW + p);
   PatchTaps<float, K> tp;
-  tp.init(fx0, fy0, xf, yf, Hs, Ws);
-  const bool dense = active && tp.dense;
+  Taps<float, 2> rt;
+  int px0, py0;  // first column / row of the patch
+  bool dense;
+  if constexpr (EPI == 1) {
+    static_assert(EPI == 0 || K == 3, "resample2d's 4 x 4 taps are a K = 3 patch");
+    rt.template init<true>(fx0, fy0, Num<T>::ld(flow + (int64_t)(b * 3 + 2) * HW + p), xf, yf, Hs, Ws, 1, false);
+    px0 = (int)fminf(fmaxf(floorf((float)xf + fx0), -1048576.f), 1048576.f) - 1;
+    py0 = (int)fminf(fmaxf(floorf((float)yf + fy0), -1048576.f), 1048576.f) - 1;
+    dense = active;
+  } else {
+    tp.init(fx0, fy0, xf, yf, Hs, Ws);
+    px0 = tp.x0;
+    py0 = tp.y0;
+    dense = active && tp.dense;
+  }
   // even-aligned window [xa, xa + K + 2] that holds every clamped column of the patch (as agg_coef_kernel)
-  const int xa = clampi(tp.x0, 0, Ws - (K + 1)) & ~1;
+  const int xa = clampi(px0, 0, Ws - (K + 1)) & ~1;
   int ro[K + 1];
 #pragma unroll
   for (int r = 0; r <= K; ++r) {
-    const int yc = clampi(tp.y0 + r, 0, Hs - 1);
+    const int yc = clampi(py0 + r, 0, Hs - 1);
     ro[r] = (yc >> 1) * pitch + ((yc & 1) << 1) + (xa << 1);
   }
   f32x2 Pw[K + 1][NP + 1];  // window sums: words (2i, 2i+1) of patch row r
@@ -1133,7 +1151,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
     // statically indexed registers)
     int slot[K + 1];
 #pragma unroll
-    for (int q = 0; q <= K; ++q) slot[q] = clampi(tp.x0 + q, 0, Ws - 1) - xa;
+    for (int q = 0; q <= K; ++q) slot[q] = clampi(px0 + q, 0, Ws - 1) - xa;
     float P[K + 1][K + 1];
 #pragma unroll
     for (int r = 0; r <= K; ++r)
@@ -1144,6 +1162,23 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
         for (int w = 1; w < NW; ++w) v = slot[q] == w ? ((w & 1) ? Pw[r][w >> 1].y : Pw[r][w >> 1].x) : v;
         P[r][q] = v;
       }
+    if constexpr (EPI == 1) {
+      float Racc[K + 1], Cacc[K + 1];
+#pragma unroll
+      for (int r = 0; r <= K; ++r) Racc[r] = Cacc[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r <= K; ++r)
+#pragma unroll
+        for (int q = 0; q <= K; ++q) {
+          Racc[r] += rt.col_w(q) * P[r][q];
+          Cacc[q] += rt.row_w(r) * P[r][q];
+        }
+      float rx, ry, rs;
+      rs_bwd2_finish<float, 2>(rt, Racc, Cacc, rx, ry, rs);
+      atomic_add(gflow + (int64_t)(b * 3 + 0) * HW + p, rx);
+      atomic_add(gflow + (int64_t)(b * 3 + 1) * HW + p, ry);
+      atomic_add(gflow + (int64_t)(b * 3 + 2) * HW + p, rs);
+    } else {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
       const float yT_P = 1 - tp.ay[i], yB_P = tp.ay[i];
@@ -1162,12 +1197,36 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
         }
       }
     }
+    }
   }
-  if (active && gflow) {
+  if (EPI == 0 && active && gflow) {
     atomic_add(gflow + (int64_t)(b * 2 + 0) * HW + p, gx_acc);
     atomic_add(gflow + (int64_t)(b * 2 + 1) * HW + p, gy_acc);
   }
 }
+
+// resample2d d/d input2 (kernel_size 4, dilation 1) on agg_ga_stream_kernel<T, 3, 1>; gin2 (B, 3, H, W) float32, accumulated
+// into.  GFLA_ERR_UNSUPPORTED where the shape does not fit (the caller falls back to rs_lds_kernel<MODE 2>).
+template <typename T>
+int rs_bwd2_stream(const T *in1, const T *in2, const T *gout, float *gin2, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
+                   int64_t H, int64_t W, hipStream_t stream) {
+  constexpr int k = 3;
+  if (tuning(3) == 1 || tuning(8) == 1 || Wi < k + 1 || (Wi & 1) || Wi >= 32768 || Hi >= 32000 ||
+      B * C * Hi * Wi >= (1LL << 31) || B * C * H * W >= (1LL << 31) || B > 65535)
+    return GFLA_ERR_UNSUPPORTED;
+  const AggStreamGeo pg = agg_stream_geometry(B, C, Hi, Wi, H, W, k);
+  const int64_t total = B * pg.nsuper * pg.tgroups;
+  const int64_t padded = ceil_div(total, kNumXCD) * kNumXCD;
+  if (pg.CH <= 0 || padded > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  launch_lds(agg_ga_stream_kernel<T, 3, 1>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, in1, in2, gout,
+             (float *)nullptr, (const T *)nullptr, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, pg.CH, pg.CS, pg.nsuper,
+             pg.tgroups, pg.pitch, (int)total, pg.tw_log2, pg.ntile);
+  return launch_status();
+}
+template int rs_bwd2_stream<float>(const float *, const float *, const float *, float *, int64_t, int64_t, int64_t, int64_t,
+                                   int64_t, int64_t, hipStream_t);
+template int rs_bwd2_stream<bf16_t>(const bf16_t *, const bf16_t *, const bf16_t *, float *, int64_t, int64_t, int64_t,
+                                    int64_t, int64_t, int64_t, hipStream_t);
 
 // In place: glogits holds ga (d/d a_ij); turn it into d/d logit_ij = a_ij * (ga_ij - sum_mn a_mn ga_mn).
 template <typename T, int K>

@@ -112,11 +112,6 @@ __device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__
                                               const T *__restrict__ g, int64_t gstride, int nch, A &rx, A &ry,
                                               A &rs) {
   constexpr int N = 2 * KH;
-  const A sg = t.sigma;
-  // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (resample2d_kernel.cu:273-292)
-  const A d2 = -sg * sg, d3 = sg * sg * sg;
-  const A inv2 = (d2 == 0) ? (A)(1.0 / kEps) : (A)1 / d2;
-  const A inv3 = (d3 == 0) ? (A)(1.0 / kEps) : (A)1 / d3;
   int ro[N], co[N];
   A wy[N], wx[N];
 #pragma unroll
@@ -150,33 +145,7 @@ __device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__
     plane += plane_sz;
     g += gstride;
   }
-  // fold the row / column weights back in and apply the derivative coefficients (:273-292);
-  // "L"/"T" taps (index < KH) enter d/dx, d/dy with +, "R"/"B" taps with -
-  A S = 0, g1x = 0, g1y = 0, g1s = 0, Wy = 0, Wx = 0, sx1 = 0, sy1 = 0, ssx = 0, ssy = 0;
-#pragma unroll
-  for (int r = 0; r < N; ++r) {
-    const A R = wy[r] * Racc[r], Cq = wx[r] * Cacc[r];
-    const A yd = t.row_d(r), xd = t.col_d(r);
-    const A ay = (r < KH ? yd : -yd) * inv2, ax = (r < KH ? xd : -xd) * inv2;
-    S += R;
-    g1y += ay * R;
-    g1x += ax * Cq;
-    g1s += (yd * yd * inv3) * R + (xd * xd * inv3) * Cq;
-    Wy += wy[r];
-    Wx += wx[r];
-    sy1 += ay * wy[r];
-    sx1 += ax * wx[r];
-    ssy += (yd * yd * inv3) * wy[r];
-    ssx += (xd * xd * inv3) * wx[r];
-  }
-  const A sgx = sx1 * Wy, sgy = sy1 * Wx, sgs = ssy * Wx + ssx * Wy;  // "sumgrad", counted once (:277,318)
-  // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S
-  const A sum = t.sum, sum2 = t.sum * t.sum;
-  const A is = (sum == 0) ? (A)(1.0 / kEps) : (A)1 / sum;
-  const A is2 = (sum2 == 0) ? (A)(1.0 / kEps) : (A)1 / sum2;
-  rx = g1x * is - (sgx * S) * is2;
-  ry = g1y * is - (sgy * S) * is2;
-  rs = g1s * is - (sgs * S) * is2;
+  rs_bwd2_finish<A, KH>(t, Racc, Cacc, rx, ry, rs);
 }
 
 // ---- global-memory kernels: thread <-> (b, channel chunk, pixel) ---------------------------------
@@ -424,6 +393,14 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
       if (st != GFLA_OK) return st;
     }
     if (gin2) {
+      if constexpr (std::is_same<A, float>::value) {
+        // kernel_size 4, dilation 1: the aggregation's streaming d/d logits kernel with resample2d's epilogue
+        // (rs_taps.h); tuning key 22 = 1: rs_lds_kernel<MODE 2>
+        if (k == 4 && dil == 1 && tuning(22) != 1) {
+          st = rs_bwd2_stream<T>(in1, in2, gout, gin2, B, C, Hi, Wi, H, W, stream);
+          if (st != GFLA_ERR_UNSUPPORTED) return st;
+        }
+      }
       const int64_t blocks = B * pg2.ngroups * pg2.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
       GFLA_KH_SWITCH(k / 2, if (pg2.margin < 0) launch_lds(rs_lds_kernel<T, KH, 2, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg2.lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg2.G, pg2.ngroups, pg2.split, pg2.per, pg2.margin, nullptr, 0u);

@@ -86,4 +86,57 @@ struct Taps {
   }
 };
 
+// resample2d d/d input2 (kernel_size 4, dilation 1, f32 / bf16 storage) on the aggregation's streaming machinery
+// (local_attn_aggregate.hip); GFLA_ERR_UNSUPPORTED where the shape does not fit it
+template <typename T>
+int rs_bwd2_stream(const T *in1, const T *in2, const T *gout, float *gin2, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
+                   int64_t H, int64_t W, hipStream_t stream);
+
+// d/d (dx, dy, sigma) of one pixel from the channel sums of its taps (resample2d_kernel.cu:273-328):
+//   Racc[r] = sum_c g_c sum_q w_x[q] v_c[r][q],   Cacc[q] = sum_c g_c sum_r w_y[r] v_c[r][q]
+// (rows / columns in position order, Taps::row_w / col_w).  Shared by rs_lds_kernel<MODE 2> and the streaming kernel.
+template <typename A, int KH>
+__device__ __forceinline__ void rs_bwd2_finish(const Taps<A, KH> &t, const A (&Racc)[2 * KH], const A (&Cacc)[2 * KH],
+                                               A &rx, A &ry, A &rs) {
+  constexpr int N = 2 * KH;
+  const A sg = t.sigma;
+  // 1/(-sigma^2) and 1/sigma^3 with the SAFE_DIV zero rule (resample2d_kernel.cu:273-292)
+  const A d2 = -sg * sg, d3 = sg * sg * sg;
+  const A inv2 = (d2 == 0) ? (A)(1.0 / kEps) : (A)1 / d2;
+  const A inv3 = (d3 == 0) ? (A)(1.0 / kEps) : (A)1 / d3;
+  A wy[N], wx[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    wy[r] = t.row_w(r);
+    wx[r] = t.col_w(r);
+  }
+  // fold the row / column weights back in and apply the derivative coefficients (:273-292);
+  // "L"/"T" taps (index < KH) enter d/dx, d/dy with +, "R"/"B" taps with -
+  A S = 0, g1x = 0, g1y = 0, g1s = 0, Wy = 0, Wx = 0, sx1 = 0, sy1 = 0, ssx = 0, ssy = 0;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    const A R = wy[r] * Racc[r], Cq = wx[r] * Cacc[r];
+    const A yd = t.row_d(r), xd = t.col_d(r);
+    const A ay = (r < KH ? yd : -yd) * inv2, ax = (r < KH ? xd : -xd) * inv2;
+    S += R;
+    g1y += ay * R;
+    g1x += ax * Cq;
+    g1s += (yd * yd * inv3) * R + (xd * xd * inv3) * Cq;
+    Wy += wy[r];
+    Wx += wx[r];
+    sy1 += ay * wy[r];
+    sx1 += ax * wx[r];
+    ssy += (yd * yd * inv3) * wy[r];
+    ssx += (xd * xd * inv3) * wx[r];
+  }
+  const A sgx = sx1 * Wy, sgy = sy1 * Wx, sgs = ssy * Wx + ssx * Wy;  // "sumgrad", counted once (:277,318)
+  // :328  grad1/sum - grad2/sum^2 with grad2 = sumgrad * S
+  const A sum = t.sum, sum2 = t.sum * t.sum;
+  const A is = (sum == 0) ? (A)(1.0 / kEps) : (A)1 / sum;
+  const A is2 = (sum2 == 0) ? (A)(1.0 / kEps) : (A)1 / sum2;
+  rx = g1x * is - (sgx * S) * is2;
+  ry = g1y * is - (sgy * S) * is2;
+  rs = g1s * is - (sgs * S) * is2;
+}
+
 }  // namespace gfla
