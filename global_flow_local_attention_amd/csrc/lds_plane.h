@@ -184,8 +184,13 @@ __device__ __forceinline__ void zero_planes(A *lds, int n) {
 // g[i] += lds[i].  exclusive = this workgroup is the only writer of these planes (plain
 // read-modify-write, coalesced); otherwise device-scope atomics.
 template <typename T>
-__device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t *lds, int n, bool exclusive) {
+__device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t *lds, int n, bool exclusive,
+                                             bool overwrite = false) {
   using A = typename Num<T>::acc;
+  if (exclusive && overwrite) {  // sole writer of planes the caller did not initialise: plain stores
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from((A)lds[i]);
+    return;
+  }
   if (exclusive) {
     if constexpr (sizeof(T) == 4) {
       if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {

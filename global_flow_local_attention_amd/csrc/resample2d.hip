@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void rs_bwd1_kernel(const T *__restrict__ i
   const int64_t HW = (int64_t)H * W;
   const T *i2 = in2 + (int64_t)b * 3 * HW + (int64_t)y * W + x;
   Taps<A, KH> t;
-  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, trunc != 0);
+  t.init(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, (trunc & 1) != 0);
   const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
   const int64_t plane_sz = (int64_t)Hi * Wi;
   rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, gout + ((int64_t)b * C + c0) * HW + (int64_t)y * W + x, HW,
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
     Taps<A, KH> t;
     t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
-                          MODE == 1 && trunc != 0);
+                          MODE == 1 && (trunc & 1) != 0);
     // outermost taps bound the rows this pixel touches; beyond the window it uses global memory
     const bool inside = !WIN || (t.yT[KH - 1] >= lo_off && t.yB[KH - 1] < hi_off);
     if constexpr (MODE == 0) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     __syncthreads();
     for (int c = 0; c < gc; ++c)
       flush_planes<T>(outp + ((int64_t)b * C + c0 + c) * plane_sz + win.lo * Wi, planes + (size_t)c * win_sz, win_sz,
-                      split == 1 && margin < 0);
+                      split == 1 && margin < 0, (trunc & 2) != 0);  // bit 1 of the flag word: overwrite (host-checked)
   }
 }
 
@@ -383,7 +383,14 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
   PlaneGeo pg1 = kBf16 ? plane_geometry(Hi * Wi, sizeof(lds_acc_t), B, C, H * W, false)
                        : lds_geometry(Hi, Wi, sizeof(lds_acc_t), B, C, H, W, (k - 1) * dil + 1);
   PlaneGeo pg2 = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1);          // gather planes
-  if ((tuning(6) != 1 || kBf16) && pg1.G > 0 && pg2.G > 0) {
+  // flag word `trunc`: bit 0 = the reference's int() truncation quirk; bit 1 = grad_in1 arrives UNINITIALISED and is to be
+  // overwritten -- honoured by the kernels where every element has exactly one writer, zero-filled here otherwise
+  const bool lds_path = (tuning(6) != 1 || kBf16) && pg1.G > 0 && pg2.G > 0;
+  if (gin1 && (trunc & 2) && !(lds_path && pg1.split == 1 && pg1.margin < 0) && !skip_stat) {
+    if (hipMemsetAsync(gin1, 0, (size_t)(B * C * Hi * Wi) * sizeof(T), stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+    trunc &= ~2;
+  }
+  if (lds_path) {
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
@@ -469,8 +476,15 @@ int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, 
     // adaptive only where the LDS-atomic kernel exists as the device-side fallback
     const bool lds_fallback = gfla::lds_geometry(Hi, Wi, sizeof(gfla::lds_acc_t), B, C, H, W, (k - 1) * d + 1).G > 0 &&
                               gfla::lds_geometry(Hi, Wi, sizeof(float), B, C, H, W, (k - 1) * d + 1).G > 0;
-    rc = gfla::rs_input1_bwd_mfma(b, go, g1, workspace, B, C, Hi, Wi, H, W, k, trunc, 1, lds_fallback ? 1 : 0, &skip_stat,
-                                  &skip_limit, static_cast<hipStream_t>(st));
+    if (trunc & 2) {  // overwrite requested: both the product and its device-side fallback must be sole writers
+      const gfla::PlaneGeo pg1 = gfla::lds_geometry(Hi, Wi, sizeof(gfla::lds_acc_t), B, C, H, W, (k - 1) * d + 1);
+      if (lds_fallback && !(pg1.split == 1 && pg1.margin < 0)) {
+        if (hipMemsetAsync(g1, 0, (size_t)(B * C * Hi * Wi) * 4, static_cast<hipStream_t>(st)) != hipSuccess) return GFLA_ERR_LAUNCH;
+        trunc &= ~2;
+      }
+    }
+    rc = gfla::rs_input1_bwd_mfma(b, go, g1, workspace, B, C, Hi, Wi, H, W, k, trunc & 1, (trunc & 2) ? 0 : 1,
+                                  lds_fallback ? 1 : 0, &skip_stat, &skip_limit, static_cast<hipStream_t>(st));
     if (rc == GFLA_OK) {
       if (!lds_fallback || skip_limit == 0xffffffffu) g1 = nullptr, skip_stat = nullptr;  // done unconditionally
     } else if (rc != GFLA_ERR_UNSUPPORTED) {

@@ -45,7 +45,9 @@ class Resample2dFunction(Function):
     def backward(ctx, grad_warped):
         input1, input2 = ctx.saved_tensors
         want1, want2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g1 = torch.zeros_like(input1) if want1 else None
+        # d/d input1 is handed over UNINITIALISED (flag bit 1 below): the library overwrites it where every element has one
+        # writer and zero-fills it itself where it has to accumulate with atomics
+        g1 = torch.empty_like(input1) if want1 else None
         g2 = _lib.reduction_like(input2) if want2 else None  # float32 accumulator for bf16 storage
         grad_warped = grad_warped.contiguous()
         if (want1 or want2) and grad_warped.numel() > 0 and input1.numel() > 0:
@@ -54,16 +56,17 @@ class Resample2dFunction(Function):
             sfx = _lib.suffix(input1, "resample2d backward")
             entry = "gfla_resample2d_bwd_" + sfx
             tail = (B, C, Hi, Wi, H, W, ctx.kernel_size, ctx.dilation, 1 if TRUNC_COMPAT else 0)
+            tail1 = tail[:-1] + (tail[-1] | 2,)  # bit 1: overwrite grad_in1
             # two independent kernels (scatter into input1 / reduction for (dx, dy, sigma)): one C-ABI
             # call each keeps them separately visible to profilers
             if want1:
                 if sfx == "f32":  # d/d input1 as a block-sparse product on the matrix cores when the shape allows
                     ws = _lib.scatter_workspace(input1, B, H, W, ctx.kernel_size * ctx.kernel_size)
                     _lib.call("gfla_resample2d_bwd_ws_f32", input1, _lib.ptr(input1), _lib.ptr(input2),
-                              _lib.ptr(grad_warped), _lib.ptr(g1), None, _lib.ptr(ws), *tail)
+                              _lib.ptr(grad_warped), _lib.ptr(g1), None, _lib.ptr(ws), *tail1)
                 else:
                     _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
-                              _lib.ptr(g1), None, *tail)
+                              _lib.ptr(g1), None, *tail1)
             if want2:
                 _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
                           None, _lib.ptr(g2), *tail)

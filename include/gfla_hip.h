@@ -149,8 +149,12 @@ GFLA_DECL_RESHAPE(bf16, uint16_t)
  *           gradInput2, kernel_size, dilation) (resample2d_cuda.cc:16-26 -> .cu:98-202, :204-330)
  *   grad_in1 (B,C,Hi,Wi) is ACCUMULATED into, must arrive zeroed (resample2d.py:32);
  *   grad_in2 (B,3,H,W) must arrive zeroed as well.  Either may be NULL.
- *   trunc_compat != 0 reproduces the reference's `xf - int(xf)` in the input1 gradient
- *   (resample2d_kernel.cu:137-138); 0 uses floor, which is the true gradient of the forward.    */
+ *   trunc_compat is a flag word.  Bit 0 set reproduces the reference's `xf - int(xf)` in the input1 gradient
+ *   (resample2d_kernel.cu:137-138); clear uses floor, which is the true gradient of the forward.  Bit 1 set
+ *   (GFLA_RESAMPLE_OVERWRITE_IN1): grad_in1 may arrive UNINITIALISED and is overwritten -- by plain stores where every
+ *   element has exactly one writer, after an internal zero fill where the kernels have to accumulate with atomics.       */
+#define GFLA_RESAMPLE_TRUNC_COMPAT 1
+#define GFLA_RESAMPLE_OVERWRITE_IN1 2
 #define GFLA_DECL_RESAMPLE_FWD(SFX, T)                                                             \
   int gfla_resample2d_fwd_##SFX(const T *in1, const T *in2, T *out, int64_t B, int64_t C,          \
                                 int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size,     \

@@ -884,3 +884,29 @@ def test_aggregate_backward_stream_path(gfla, oracle, kernel_variant, shape, kin
     assert_close(gl.cpu(), l64.grad.float(), F32_GRAD, "grad_logits")
     if kind != "near_integer":   # at (near-)integer flows the bilinear kink makes autograd's one-sided choice arbitrary
         assert_close(gf.cpu(), f64.grad.float(), F32_GRAD * 4, "grad_flow")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 12, 10, 4, 1), (1, 4, 200, 176, 4, 1), (2, 6, 16, 14, 4, 2), (4, 64, 32, 22, 4, 1),
+                                  (2, 5, 9, 7, 2, 1)])
+def test_resample2d_backward_overwrite_flag(gfla, kernel_variant, case):
+    """GFLA_RESAMPLE_OVERWRITE_IN1 (bit 1 of the flag word): grad_in1 handed over full of NaNs comes back equal to the
+    accumulate-into-zeros result on every path -- planes in LDS with one writer (plain stores), row windows and the
+    global-memory kernels (internal zero fill + atomics), the matrix-core product with its device-side fallback."""
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W, k, d = case
+    i1 = randn((B, C, H, W), seed=91).to(DEV)
+    i2 = torch.cat((make_flow("smooth", B, H, W, seed=92), torch.full((B, 1, H, W), 2.0)), 1).contiguous().to(DEV)
+    go = randn((B, C, H, W), seed=93).to(DEV)
+    ws = _lib.scatter_workspace(i1, B, H, W, k * k)
+    for use_ws in (False, True):
+        want = torch.zeros_like(i1)
+        got = torch.full_like(i1, float("nan"))
+        for buf, flags in ((want, 1), (got, 3)):
+            if use_ws:
+                _lib.call("gfla_resample2d_bwd_ws_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(buf), None,
+                          _lib.ptr(ws), B, C, H, W, H, W, k, d, flags)
+            else:
+                _lib.call("gfla_resample2d_bwd_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(buf), None,
+                          B, C, H, W, H, W, k, d, flags)
+        assert torch.isfinite(got).all()
+        assert_close(got.cpu(), want.cpu(), F32_GRAD, "overwrite vs accumulate (ws=%s)" % use_ws)
