@@ -910,3 +910,45 @@ def test_resample2d_backward_overwrite_flag(gfla, kernel_variant, case):
                           B, C, H, W, H, W, k, d, flags)
         assert torch.isfinite(got).all()
         assert_close(got.cpu(), want.cpu(), F32_GRAD, "overwrite vs accumulate (ws=%s)" % use_ws)
+
+
+def test_streaming_kernels_random_shapes_against_round1_kernels(gfla, kernel_variant):
+    """Forty random shapes (odd and even widths, maps one patch wide, C not a multiple of the chunk, B = 1, flows from
+    zero to far outside the map) through the streaming kernels -- aggregation forward, d/d logits + d/d flow,
+    resample2d d/d input2 -- against round 1's kernels (tuning keys 8 / 22), which the oracle tests pin."""
+    if kernel_variant == "global":
+        pytest.skip("stream kernels are part of the default dispatch only")
+    from global_flow_local_attention_amd import _lib
+    rng = np.random.RandomState(1234)
+    for it in range(40):
+        B, C = int(rng.randint(1, 4)), int(rng.randint(1, 41))
+        H, W = int(rng.randint(2, 40)), int(rng.randint(4, 50))
+        k = int(rng.choice([1, 3, 5]))
+        scale = float(rng.choice([0.0, 0.7, 3.0, 25.0]))
+        g = torch.Generator().manual_seed(1000 + it)
+        src = torch.randn(B, C, H, W, generator=g).to(DEV)
+        flow = (torch.randn(B, 2, H, W, generator=g) * scale).to(DEV)
+        lg = (torch.randn(B, k * k, H, W, generator=g) * 2).to(DEV)
+        go = torch.randn(B, C, H, W, generator=g).to(DEV)
+        res = {}
+        for tag, key8 in (("old", 1), ("new", 2)):
+            gfla.set_tuning(8, key8)
+            gfla.set_tuning(22, 1 if tag == "old" else 0)
+            try:
+                out, attn = torch.empty_like(src), torch.empty_like(lg)
+                _lib.aggregate_fwd(src, flow, lg, out, attn, k, True)
+                gl, gf = torch.zeros_like(attn), torch.zeros_like(flow)
+                _lib.call("gfla_local_attn_aggregate_bwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(go),
+                          None, _lib.ptr(gf), _lib.ptr(gl), B, C, H, W, H, W, k, 1)
+                i2 = torch.cat((flow, torch.full((B, 1, H, W), 1.5, device=DEV)), 1).contiguous()
+                g2 = torch.zeros_like(i2)
+                _lib.call("gfla_resample2d_bwd_f32", src, _lib.ptr(src), _lib.ptr(i2), _lib.ptr(go), None, _lib.ptr(g2),
+                          B, C, H, W, H, W, 4, 1, 0)
+                res[tag] = (out, attn, gl, gf, g2)
+            finally:
+                gfla.set_tuning(8, 0)
+                gfla.set_tuning(22, 0)
+        for name, a, b in zip(("out", "attn", "grad_logits", "grad_flow", "grad_in2"), res["new"], res["old"]):
+            scale_ = max(1e-30, b.abs().max().item())
+            err = (a - b).abs().max().item() / scale_
+            assert err <= 2e-5, (it, (B, C, H, W, k, scale), name, err)
