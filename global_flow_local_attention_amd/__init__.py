@@ -4,7 +4,7 @@ Public surface = the reference's: BlockExtractor, LocalAttnReshape, Resample2d (
 Functions) and ExtractorAttn; `install()` wires them into an unmodified reference checkout.
 All compute is in libgfla_hip.so (csrc/, C ABI in include/gfla_hip.h); there is no CPU path.
 """
-from ._lib import build, exported_symbols, set_tuning  # noqa: F401
+from ._lib import build, exported_symbols, path_count, set_tuning  # noqa: F401
 from .block_extractor import BlockExtractor, BlockExtractorFunction  # noqa: F401
 from .local_attn_reshape import LocalAttnReshape, LocalAttnReshapeFunction  # noqa: F401
 from .resample2d import Resample2d, Resample2dFunction  # noqa: F401

@@ -66,7 +66,7 @@ _FWD_ONLY_BF16 = set()
 
 def exported_symbols():
     """Every symbol include/gfla_hip.h declares."""
-    names = ["gfla_abi_version", "gfla_status_string", "gfla_set_tuning", "gfla_unfold_supported"]
+    names = ["gfla_abi_version", "gfla_status_string", "gfla_set_tuning", "gfla_path_count", "gfla_unfold_supported"]
     for base in _SIGNATURES:
         for sfx in ("f32", "f64", "bf16"):
             if sfx == "bf16" and base in _FWD_ONLY_BF16:
@@ -95,6 +95,8 @@ def lib():
         handle.gfla_status_string.restype = ctypes.c_char_p
         handle.gfla_status_string.argtypes = [_int]
         handle.gfla_set_tuning.argtypes = [_int, _int]
+        handle.gfla_path_count.argtypes = [_int]
+        handle.gfla_path_count.restype = _i64
         handle.gfla_unfold_supported.argtypes = [_i64, _i64, _int, _int]
         for base, args in _SIGNATURES.items():
             for sfx in ("f32", "f64", "bf16"):
@@ -181,4 +183,15 @@ def unfold_supported(Hs, Ws, k, elem_size):
 
 
 def set_tuning(key, value):
+    """Process-global tuning knob (include/gfla_hip.h); returns the old value."""
     return lib().gfla_set_tuning(int(key), int(value))
+
+
+ABI_VERSION = 3
+# dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
+PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0 = 0, 1, 2, 6
+
+
+def path_count(path):
+    """How many times kernel path `path` has been enqueued by this process (any host thread)."""
+    return int(lib().gfla_path_count(int(path)))

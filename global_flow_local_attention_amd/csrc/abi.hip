@@ -1,15 +1,24 @@
 // Library-level entry points of libgfla_hip.so: version, status strings, tuning knobs.
 #include "gfla_common.h"
 
+#include <atomic>
+
 namespace gfla {
-// per thread: a host thread that drives its own device (DataParallel-style workers, tests) tunes only its own launches
+// PROCESS-global: torch runs the backward of a GPU autograd Function on the engine's per-device worker thread and
+// nn.DataParallel runs replicas on worker threads, so a per-thread table would silently drop the caller's choice there.
 constexpr int kTuningKeys = 24;
-static thread_local int g_tuning[kTuningKeys] = {0};
-int tuning(int key) { return (key >= 0 && key < kTuningKeys) ? g_tuning[key] : 0; }
+static std::atomic<int> g_tuning[kTuningKeys];
+int tuning(int key) { return (key >= 0 && key < kTuningKeys) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
+
+// Dispatch trace: how often each kernel path was enqueued (tests assert which path a call took, whatever thread made it).
+static std::atomic<int64_t> g_path[GFLA_PATH_COUNT];
+void note_path(int id) {
+  if (id >= 0 && id < GFLA_PATH_COUNT) g_path[id].fetch_add(1, std::memory_order_relaxed);
+}
 }  // namespace gfla
 
 extern "C" {
-int gfla_abi_version(void) { return 1; }
+int gfla_abi_version(void) { return GFLA_ABI_VERSION; }
 
 const char *gfla_status_string(int status) {
   switch (status) {
@@ -24,8 +33,10 @@ const char *gfla_status_string(int status) {
 
 int gfla_set_tuning(int key, int value) {
   if (key < 0 || key >= gfla::kTuningKeys) return 0;
-  int old = gfla::g_tuning[key];
-  gfla::g_tuning[key] = value;
-  return old;
+  return gfla::g_tuning[key].exchange(value, std::memory_order_relaxed);
+}
+
+int64_t gfla_path_count(int path) {
+  return (path >= 0 && path < GFLA_PATH_COUNT) ? gfla::g_path[path].load(std::memory_order_relaxed) : -1;
 }
 }

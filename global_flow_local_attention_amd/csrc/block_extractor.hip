@@ -384,6 +384,7 @@ static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, t
   if (tuning(2) != 1 || kBf16) {
     bool done = false;
     int st = launch_be_bwd_lds<T, K>(kGoutTensor, src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
+    if (done) note_path(GFLA_PATH_BE_BWD_LDS);
     if (done || st != GFLA_OK) return st;
   }
   if constexpr (kBf16) {
@@ -395,6 +396,7 @@ static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, t
   const int64_t ncg = ceil_div(C, cpt);
   const int64_t blocks = sp_blocks * ncg * B;
   if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  note_path(GFLA_PATH_BE_BWD_GLOBAL);
   hipLaunchKernelGGL((be_bwd_pix_kernel<T, K>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, src,
                      flow, gout, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, cpt,
                      (int)ncg, (int)sp_blocks);

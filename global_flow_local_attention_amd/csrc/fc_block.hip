@@ -99,6 +99,7 @@ static int fc_forward(const float *source, const float *target, const float *flo
   if (!source || !target || !flow || !w0 || !w1 || !ws_ || !logits) return GFLA_ERR_NULL_POINTER;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
   if (B == 0) return GFLA_OK;
+  note_path(GFLA_PATH_FC_FWD_MODE0 + mode);
   const FcLayout L = fc_layout(B, C, H, W, k, mode);
   unsigned char *ws = static_cast<unsigned char *>(ws_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
@@ -175,6 +176,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   if (!ws_ || !flow || !w1 || !g_logits || !scratch_) return GFLA_ERR_NULL_POINTER;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
   if (B == 0) return GFLA_OK;
+  note_path(GFLA_PATH_FC_BWD_MODE0 + mode);
   const FcLayout L = fc_layout(B, C, H, W, k, mode);
   unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);

@@ -108,5 +108,6 @@ inline int pick_channels_per_thread(int64_t threads_per_channel_group_unit, int6
 }
 
 int tuning(int key);  // defined in abi.hip
+void note_path(int id);  // dispatch trace (gfla_path_count)
 
 }  // namespace gfla

@@ -557,9 +557,19 @@ static bool pm_auto(bool aggregate, int64_t Ws) {
   return aggregate ? Ws >= 32 : Ws <= 24;
 }
 
+// dynamic LDS of patch_scatter_mfma_kernel: the W / G tiles plus 2 bytes per flow tile; plain <<<>>> launches get 64 KB
+static int64_t pm_lds_bytes(int NB, int64_t ntiles) {
+  return (int64_t)(kPmTile * NB * 32 + kPmChannels * kPmGPitch) * (int64_t)sizeof(float) + ((ntiles + 7) & ~(int64_t)7) * 2;
+}
+
 static bool pm_supported(int64_t B, int64_t C, int64_t H, int64_t W, int64_t Hs, int64_t Ws) {
-  return B > 0 && B <= 65535 && C > 0 && Hs >= 2 && Ws >= 2 && Ws <= kPmMaxNB * 32 && Hs < 32768 && Ws < 32768 &&
-         H * W <= (int64_t)kPmTile * 65535 && ceil_div(C, kPmChannels) <= 65535 && tuning(14) != 1;
+  if (!(B > 0 && B <= 65535 && C > 0 && Hs >= 2 && Ws >= 2 && Ws <= kPmMaxNB * 32 && Hs < 32768 && Ws < 32768 &&
+        H * W <= (int64_t)kPmTile * 65535 && ceil_div(C, kPmChannels) <= 65535 && tuning(14) != 1))
+    return false;
+  // the per-tile row table lives in LDS: a flow field with more tiles than fit the 64 KB launch limit is UNSUPPORTED
+  // here (the callers fall back to the LDS-atomic kernels) instead of failing at launch
+  const PmGeo g = pm_geometry(B, C, (int)Hs, (int)Ws, (int)W, 0);
+  return g.R > 0 && pm_lds_bytes(g.NB, ceil_div(H * W, kPmTile)) <= 64 * 1024;
 }
 
 static int pm_scatter(const float *G, float *dS, const PatchEntry *table, const int2 *tile_rows, int64_t B, int64_t C,
@@ -569,7 +579,8 @@ static int pm_scatter(const float *G, float *dS, const PatchEntry *table, const 
   if (g.R == 0) return GFLA_ERR_UNSUPPORTED;
   const int ntiles = (int)ceil_div(H * W, kPmTile);
   const dim3 grid((unsigned)g.bands, (unsigned)B, (unsigned)ceil_div(C, kPmChannels));
-  const unsigned lds = (unsigned)((kPmTile * g.NB * 32 + kPmChannels * kPmGPitch) * sizeof(float) + ((ntiles + 7) & ~7) * 2);
+  const unsigned lds = (unsigned)pm_lds_bytes(g.NB, ntiles);
+  if (lds > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
 #define GFLA_PM(NB_)                                                                                              \
   case NB_:                                                                                                       \
     patch_scatter_mfma_kernel<NB_><<<grid, 256, lds, stream>>>(G, dS, table, tile_rows, (int)C, (int)(H * W), (int)Hs, \

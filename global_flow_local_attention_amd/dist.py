@@ -130,6 +130,7 @@ class GradBucketReducer(object):
             for p, off in bk["params"]:
                 self._where[p] = (i, off)
         self._handles = []
+        self._next = 0  # first bucket whose all-reduce has not been launched
         if self.enabled:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -137,27 +138,41 @@ class GradBucketReducer(object):
     def _launch(self, bk):
         bk["work"] = dist.all_reduce(bk["flat"], op=dist.ReduceOp.SUM, async_op=True)
 
+    def _launch_ready(self):
+        # strictly in bucket order (as DDP does): RCCL matches collectives by ISSUE order, so a rank whose graph
+        # completed bucket 1 before bucket 0 must still issue 0 first -- bucket i waits for 0..i-1
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
     def _on_grad(self, p):
         i, off = self._where[p]
         bk = self.buckets[i]
+        if p in bk["seen"]:
+            # a second backward before finish() (gradient accumulation, retain_graph): p.grad holds the accumulated
+            # value, which is what has to be reduced -- fine as long as the bucket has not left yet
+            if bk["work"] is not None:
+                raise RuntimeError("GradBucketReducer: a parameter received a second gradient after its bucket's "
+                                   "all-reduce was launched; call finish() after every backward (or build the reducer "
+                                   "after the accumulation steps)")
+            bk["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+            return
         bk["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
         bk["seen"].add(p)
         bk["pending"] -= 1
-        if bk["pending"] == 0:
-            self._launch(bk)
+        self._launch_ready()
 
     def finish(self):
-        """Call after backward: launches what is still pending (parameters that got no gradient count as zero), waits
-        for every bucket, and leaves the reduced gradients in .grad (views into the buckets)."""
+        """Call after backward: launches what is still pending IN BUCKET ORDER (parameters that got no gradient count
+        as zero), waits for every bucket, and leaves the reduced gradients in .grad (views into the buckets)."""
         if not self.enabled:
             return
         world = dist.get_world_size()
-        for bk in self.buckets:
-            if bk["work"] is None:
-                for p, off in bk["params"]:
-                    if p not in bk["seen"]:  # no gradient in this backward: contributes zeros
-                        bk["flat"][off:off + p.numel()].zero_()
-                self._launch(bk)
+        for bk in self.buckets[self._next:]:
+            for p, off in bk["params"]:
+                if p not in bk["seen"]:  # no gradient in this backward: contributes zeros
+                    bk["flat"][off:off + p.numel()].zero_()
+            self._launch(bk)
         for bk in self.buckets:
             bk["work"].wait()
             if self.average:
@@ -165,6 +180,7 @@ class GradBucketReducer(object):
             for p, off in bk["params"]:
                 p.grad = bk["flat"][off:off + p.numel()].view_as(p)
             bk["pending"], bk["work"], bk["seen"] = len(bk["params"]), None, set()
+        self._next = 0
 
     def remove(self):
         for h in self._handles:

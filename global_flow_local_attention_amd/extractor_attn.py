@@ -273,23 +273,49 @@ def _tail_fusable(self, conv0, act, conv1, dtype, k):
     return conv1.in_channels == hc and max(hc * kk + hc, 4 * kk * 64) * esz <= 64 * 1024
 
 
+def _fc_layers_fit(source, target, flow_field, conv0, act, conv1, k):
+    """The module IS the reference's ExtractorAttn layout (base_function.py:799-803) and the three maps line up: what
+    both MFMA evaluations (f32 and bf16 features) require."""
+    return (_tail_slope(act) is not None
+            and source.shape == target.shape and source.shape[2:] == flow_field.shape[2:]
+            and source.size(0) == flow_field.size(0) and flow_field.size(1) == 2
+            and isinstance(conv0, nn.Conv2d) and isinstance(conv1, nn.Conv2d)
+            and conv0.out_channels == 128 and conv0.in_channels == 2 * source.size(1)
+            and conv0.kernel_size == (k, k) and conv0.stride == (k, k) and conv0.padding == (0, 0)
+            and conv0.dilation == (1, 1) and conv0.groups == 1
+            and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.padding == (0, 0)
+            and conv1.dilation == (1, 1) and conv1.groups == 1 and conv1.in_channels == 128
+            and conv1.out_channels == k * k)
+
+
 def _mfma_mode(self, source, target, flow_field, conv0, act, conv1, k):
     """Arithmetic mode of the MFMA path for the FC layers (fc_mfma.py), or None to use the library path."""
-    if getattr(self, "fc_impl", "mfma") != "mfma" or _tail_slope(act) is None:
+    if getattr(self, "fc_impl", "mfma") != "mfma":
         return None
     mode = getattr(self, "fc_mode", None)
     mode = fc_mfma.DEFAULT_MODE if mode is None else int(mode)
     ok = (source.dtype == torch.float32 and target.dtype == torch.float32 and flow_field.dtype == torch.float32
-          and source.shape == target.shape and source.shape[2:] == flow_field.shape[2:]
-          and isinstance(conv0, nn.Conv2d) and isinstance(conv1, nn.Conv2d)
-          and conv0.out_channels == 128 and conv0.in_channels == 2 * source.size(1)
-          and conv0.kernel_size == (k, k) and conv0.stride == (k, k) and conv0.padding == (0, 0)
-          and conv0.dilation == (1, 1) and conv0.groups == 1
-          and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.padding == (0, 0)
-          and conv1.groups == 1 and conv1.in_channels == 128 and conv1.out_channels == k * k)
+          and _fc_layers_fit(source, target, flow_field, conv0, act, conv1, k))
     if not ok or mode not in fc_mfma.MODES:
         return None
     return mode if fc_mfma.supported(source.size(1), source.size(2), source.size(3), k, mode) else None
+
+
+# bf16 features: the aggregation's backward keeps a (double accumulator + f32 source) plane pair per position in LDS
+# (csrc/local_attn_aggregate.hip: Hs*Ws*(sizeof(lds_acc_t)+4) <= kLdsBudget); larger maps have no bf16 backward
+_BF16_BWD_MAX_POSITIONS = (64 * 1024) // 12
+
+
+def _bf16_path_ok(self, source, target, flow_field, conv0, act, conv1, last, k):
+    if not (source.dtype == torch.bfloat16 and target.dtype == torch.bfloat16
+            and flow_field.dtype in (torch.bfloat16, torch.float32)
+            and getattr(self, "fc_impl", "mfma") == "mfma" and isinstance(last, nn.Softmax) and last.dim == 1
+            and _fc_layers_fit(source, target, flow_field, conv0, act, conv1, k)
+            and fc_mfma.supported(source.size(1), source.size(2), source.size(3), k, 1)):
+        return False
+    needs_bwd = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or flow_field.requires_grad
+                                             or conv0.weight.requires_grad or conv1.weight.requires_grad)
+    return not needs_bwd or source.size(2) * source.size(3) <= _BF16_BWD_MAX_POSITIONS
 
 
 class FusedAttnFunction(Function):
@@ -437,14 +463,21 @@ def _fused_attention(self, source, target, flow_field):
         return _unfused_attention(self, source, target, flow_field)
     source_c = source.contiguous()
     flow_c = flow_field.contiguous()
-    if (source.dtype == torch.bfloat16 and target.dtype == torch.bfloat16 and getattr(self, "fc_impl", "mfma") == "mfma"
-            and _tail_slope(act) is not None and isinstance(last, nn.Softmax) and last.dim == 1
-            and isinstance(conv0, nn.Conv2d) and conv0.out_channels == 128 and conv0.kernel_size == (k, k)
-            and conv0.stride == (k, k) and isinstance(conv1, nn.Conv2d) and conv1.kernel_size == (1, 1)
-            and conv1.out_channels == k * k and fc_mfma.supported(c, source.size(2), source.size(3), k, 1)):
-        result, attn = FusedAttnBf16Function.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
-                                                   conv1.bias, k, _tail_slope(act))
-        return attn, result
+    if source.dtype == torch.bfloat16:
+        if _bf16_path_ok(self, source_c, target, flow_c, conv0, act, conv1, last, k):
+            result, attn = FusedAttnBf16Function.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
+                                                       conv1.bias, k, _tail_slope(act))
+            return attn, result
+        # a bf16 map the bf16 kernels do not take (shape mismatch, planes beyond the LDS backward): evaluate the block in
+        # float32 -- every gradient exists there -- and hand the result back in bf16
+        if not getattr(self, "_bf16_warned", False):
+            import warnings
+            warnings.warn("ExtractorAttn: bfloat16 features of shape %s are evaluated in float32 (the bf16 kernels do not "
+                          "take this shape)" % (tuple(source.shape),))
+            self._bf16_warned = True
+        with torch.autocast(device_type="cuda", enabled=False):
+            attn, result = _fused_attention_f32_module(self, source.float(), target.float(), flow_field.float())
+        return attn.to(torch.bfloat16), result.to(torch.bfloat16)
     mode = _mfma_mode(self, source_c, target, flow_c, conv0, act, conv1, k)
     if mode is not None:
         # both FC layers on the matrix cores: no block tensor, no library GEMM / convolution (fc_mfma.py)
@@ -475,6 +508,31 @@ def _fused_attention(self, source, target, flow_field):
         hidden = hidden + _source_half_fc(self, source_c, flow_c, conv0, c, k, link)
         logits = conv1(act(hidden))
     return _aggregate(source_c, flow_c, logits, last, k, link)
+
+
+def _fused_attention_f32_module(self, source, target, flow_field):
+    """_fused_attention on float32 inputs with the module's parameters viewed as float32 (bf16 modules)."""
+    fc = self.fully_connect_layer
+    if fc[0].weight.dtype == torch.float32:
+        return _fused_attention(self, source, target, flow_field)
+    import copy
+    shadow = copy.copy(self)              # shares nothing mutable we touch; parameters are re-derived below
+    shadow._modules = dict(self._modules)
+    layers = []
+    for m in fc:
+        if isinstance(m, nn.Conv2d):
+            m32 = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=m.bias is not None)
+            m32 = m32.to(m.weight.device)
+            del m32.weight                 # differentiable float32 views of the bf16 parameters
+            m32.weight = m.weight.float()
+            if m.bias is not None:
+                del m32.bias
+                m32.bias = m.bias.float()
+            layers.append(m32)
+        else:
+            layers.append(m)
+    shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
+    return _fused_attention(shadow, source, target, flow_field)
 
 
 def _aggregate(source_c, flow_c, logits, last, k, link):

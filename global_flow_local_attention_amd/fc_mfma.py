@@ -5,7 +5,7 @@ logits (B, k*k, H, W) -- what the reference computes as
     fully_connect_layer[:3](cat(extractor(target, 0), extractor(source, flow)))
 -- through gfla_fc_forward_f32 / gfla_fc_backward_f32 (csrc/fc_block.hip): no block tensor, no library GEMM or
 convolution.  `mode` picks the arithmetic of the contraction (include/gfla_hip.h): 0 exact-f32 MFMA, 3 three-term
-f16 split (f32-grade), 2 two-term f16 split.
+f16 split (f32-grade), 2 two-term f16 split.  The default is 0.
 """
 import ctypes
 
@@ -15,7 +15,9 @@ from torch.autograd import Function
 from . import _lib
 
 MODES = (0, 1, 2, 3)
-DEFAULT_MODE = 3
+# exact f32 (v_mfma_f32_32x32x2_f32): the reference computes this layer in fp32 (base_function.py:799-810), so this is
+# what a module without an explicit `fc_mode` gets; 2 / 3 are labelled experiments, 1 belongs to the bf16-feature path
+DEFAULT_MODE = 0
 
 
 def supported(C, H, W, k, mode=DEFAULT_MODE):

@@ -70,6 +70,8 @@ class Resample2dFunction(Function):
             if want2:
                 _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
                           None, _lib.ptr(g2), *tail)
+        elif g1 is not None:
+            g1.zero_()  # nothing was launched (an empty input2 / gradient): d/d input1 is zero, not uninitialised memory
         if g2 is not None and g2.dtype != input2.dtype:
             g2 = g2.to(input2.dtype)
         return g1, g2, None, None

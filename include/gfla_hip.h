@@ -26,8 +26,8 @@
  *   - return 0 on success, a negative gfla_status otherwise (the reference returns 1 always and
  *     swallows launch errors, block_extractor_cuda.cc:11, block_extractor_kernel.cu:215);
  *   - suffix = storage type: _f32, _f64 (the two types the reference dispatches,
- *     AT_DISPATCH_FLOATING_TYPES) and _bf16 (new; forward only, fp32 arithmetic inside).
- *     bf16 buffers are raw uint16_t bit patterns.
+ *     AT_DISPATCH_FLOATING_TYPES) and _bf16 (new; forward AND backward, fp32 arithmetic inside, reductions over
+ *     channels returned in float32).  bf16 buffers are raw uint16_t bit patterns.
  */
 #ifndef GFLA_HIP_H_
 #define GFLA_HIP_H_
@@ -48,6 +48,10 @@ typedef enum gfla_status {
 
 typedef void *gfla_stream_t; /* hipStream_t */
 
+/* Bumped whenever an entry point is added or a signature changes.
+ *   1: round 1 (the three ops + aggregate)   2: round 2 (fc_*, *_ws, bf16 backward, max_cosine, correctness_map)
+ *   3: round 3 (gfla_path_count, process-global tuning, aggregate flags)                                   */
+#define GFLA_ABI_VERSION 3
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
@@ -62,6 +66,23 @@ const char *gfla_status_string(int status);
  *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)
  *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)                                     */
 int gfla_set_tuning(int key, int value);
+
+/* Dispatch trace (tests): number of times a kernel path has been enqueued by this process, from any host thread
+ * (autograd runs backward on its own worker threads).  -1 for an unknown id. */
+enum gfla_path {
+  GFLA_PATH_BE_BWD_LDS = 0,     /* block_extractor backward: planes-in-LDS kernel */
+  GFLA_PATH_BE_BWD_GLOBAL = 1,  /* block_extractor backward: global-atomics kernel (tuning key 2) */
+  GFLA_PATH_FC_FWD_MODE0 = 2,   /* gfla_fc_forward_f32 in arithmetic mode 0 .. 3 = ids 2 .. 5 */
+  GFLA_PATH_FC_FWD_MODE1 = 3,
+  GFLA_PATH_FC_FWD_MODE2 = 4,
+  GFLA_PATH_FC_FWD_MODE3 = 5,
+  GFLA_PATH_FC_BWD_MODE0 = 6,   /* gfla_fc_backward_f32, ids 6 .. 9 */
+  GFLA_PATH_FC_BWD_MODE1 = 7,
+  GFLA_PATH_FC_BWD_MODE2 = 8,
+  GFLA_PATH_FC_BWD_MODE3 = 9,
+  GFLA_PATH_COUNT = 10
+};
+int64_t gfla_path_count(int path);
 
 /* ---- block_extractor ---------------------------------------------------------------------
  * forward : replaces block_extractor_cuda.forward(source, flow_field, output, kernel_size)

@@ -92,6 +92,34 @@ def _reducer_worker(rank, world, port, ret):
             assert torch.allclose(p.grad, (want[0][i] + want[1][i]) / 2, atol=1e-6), (step, i)
         assert torch.equal(unused.grad, torch.zeros(7))
     red.remove()
+    # ranks whose graphs use DIFFERENT parameters (data-dependent branch): buckets complete in different orders on the
+    # two ranks; launches must still be issued in bucket order or the collectives pair up wrongly / hang
+    torch.manual_seed(1)
+    br = torch.nn.ModuleList([torch.nn.Linear(6, 3), torch.nn.Linear(6, 3), torch.nn.Linear(3, 2)])
+    red2 = gd.GradBucketReducer(list(br.parameters()), bucket_mb=60e-6)
+    assert len(red2.buckets) >= 3
+    x = torch.full((2, 6), float(rank + 1))
+    br[2](br[rank](x)).sum().backward()                             # rank r only touches branch r
+    red2.finish()
+    for rr in range(world):
+        ref = torch.nn.ModuleList([torch.nn.Linear(6, 3), torch.nn.Linear(6, 3), torch.nn.Linear(3, 2)])
+        ref.load_state_dict(br.state_dict())
+        ref[2](ref[rr](torch.full((2, 6), float(rr + 1)))).sum().backward()
+        assert torch.allclose(br[rr].weight.grad, ref[rr].weight.grad / 2, atol=1e-6)
+        assert torch.allclose(br[rr].bias.grad, ref[rr].bias.grad / 2, atol=1e-6)
+    # a second backward after a bucket has left must not go unnoticed
+    red2.remove()
+    one = torch.nn.Linear(6, 3)
+    red3 = gd.GradBucketReducer(list(one.parameters()))               # one bucket, complete after the first backward
+    one(x).sum().backward()
+    try:
+        one(x).sum().backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "second gradient" in str(e)
+    assert raised
+    red3.finish()
+    red3.remove()
     dist.barrier()
     dist.destroy_process_group()
     ret[rank] = True

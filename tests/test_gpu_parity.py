@@ -952,3 +952,85 @@ def test_streaming_kernels_random_shapes_against_round1_kernels(gfla, kernel_var
             scale_ = max(1e-30, b.abs().max().item())
             err = (a - b).abs().max().item() / scale_
             assert err <= 2e-5, (it, (B, C, H, W, k, scale), name, err)
+
+
+# ------------------------------------------------------------------------------ dispatch: defaults and tuning
+def test_default_fc_arithmetic_is_exact_f32(gfla, kernel_variant):
+    """A module built through the reference surface, WITHOUT an explicit fc_mode, runs the exact-f32 MFMA kernels
+    (arithmetic mode 0) in forward and backward -- the reference's precision (base_function.py:799-810)."""
+    if kernel_variant == "global":
+        pytest.skip("dispatch test, independent of the gather/scatter variant")
+    from global_flow_local_attention_amd import _lib, fc_mfma
+    assert fc_mfma.DEFAULT_MODE == 0
+    before = [_lib.path_count(i) for i in range(10)]
+    mod = gfla.ExtractorAttn(16, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    assert not hasattr(mod, "fc_mode")
+    s, t = (randn((2, 16, 12, 10), seed=i).to(DEV).requires_grad_() for i in (1, 2))
+    f = make_flow("smooth", 2, 12, 10, seed=3).to(DEV).requires_grad_()
+    mod(s, t, f).sum().backward()
+    torch.cuda.synchronize()
+    after = [_lib.path_count(i) for i in range(10)]
+    delta = [a - b for a, b in zip(after, before)]
+    assert delta[_lib.PATH_FC_FWD_MODE0] == 1 and delta[_lib.PATH_FC_BWD_MODE0] == 1, delta
+    assert sum(delta[_lib.PATH_FC_FWD_MODE0 + 1:_lib.PATH_FC_FWD_MODE0 + 4]) == 0, delta   # no f16-split forward
+    assert sum(delta[_lib.PATH_FC_BWD_MODE0 + 1:_lib.PATH_FC_BWD_MODE0 + 4]) == 0, delta
+    mod.fc_mode = 3                                                                         # explicit opt-in still works
+    mod(s, t, f).sum().backward()
+    assert _lib.path_count(_lib.PATH_FC_FWD_MODE0 + 3) == after[_lib.PATH_FC_FWD_MODE0 + 3] + 1
+
+
+def test_tuning_reaches_the_autograd_backward_thread(gfla, kernel_variant):
+    """Tuning keys are process-global: a key set on the main thread must steer a backward that autograd runs on its
+    own worker thread (a thread_local table silently lost the forced-global backward coverage)."""
+    from global_flow_local_attention_amd import _lib
+    s = randn((2, 5, 9, 8), seed=1).to(DEV).requires_grad_()
+    f = make_flow("coherent", 2, 9, 8, seed=2).to(DEV).requires_grad_()
+    lds0, glob0 = _lib.path_count(_lib.PATH_BE_BWD_LDS), _lib.path_count(_lib.PATH_BE_BWD_GLOBAL)
+    gfla.BlockExtractor(3)(s, f).sum().backward()
+    torch.cuda.synchronize()
+    lds1, glob1 = _lib.path_count(_lib.PATH_BE_BWD_LDS), _lib.path_count(_lib.PATH_BE_BWD_GLOBAL)
+    if kernel_variant == "global":
+        assert (lds1 - lds0, glob1 - glob0) == (0, 1)
+    else:
+        assert (lds1 - lds0, glob1 - glob0) == (1, 0)
+
+
+def test_resample2d_backward_with_empty_flow_returns_zeros(gfla):
+    """An empty input2 skips the native call; d/d input1 must then be zeros, not uninitialised memory."""
+    i1 = randn((2, 3, 6, 5), seed=1).to(DEV).requires_grad_()
+    i2 = torch.zeros(2, 2, 0, 5, device=DEV)
+    out = gfla.Resample2d(4, 1, 2)(i1, i2)
+    assert out.shape == (2, 3, 0, 5)
+    out.sum().backward()
+    assert torch.equal(i1.grad, torch.zeros_like(i1))
+
+
+def test_bf16_features_beyond_the_lds_backward_fall_back_to_f32(gfla, oracle, kernel_variant):
+    """128x128 bf16 maps: the bf16 aggregation backward does not take planes that large; the block must
+    still train -- evaluated in float32, results handed back in bf16 -- instead of raising in backward."""
+    if kernel_variant == "global":
+        pytest.skip("gate test")
+    import warnings
+    from oracle import cpu_modules
+    B, C, H, W, k = 1, 16, 128, 128, 3
+    torch.manual_seed(0)
+    mod = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+    ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+    ref.load_state_dict(mod.state_dict())
+    mod = mod.to(DEV)
+    bf = lambda x: x.to(torch.bfloat16)
+    s, t = bf(randn((B, C, H, W), seed=1)), bf(randn((B, C, H, W), seed=2))
+    f = bf(make_flow("smooth", B, H, W, seed=3))
+    sd, td, fd = (x.to(DEV).requires_grad_() for x in (s, t, f))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = mod(sd, td, fd)
+    assert any("float32" in str(x.message) for x in w)
+    assert out.dtype == torch.bfloat16
+    out.float().sum().backward()
+    sc, tc, fc = (x.float().requires_grad_() for x in (s, t, f))
+    want = ref(sc, tc, fc)
+    want.sum().backward()
+    assert_close(out.float().cpu(), want.detach(), 2 ** -7, "bf16 fallback forward")
+    assert_close(sd.grad.float().cpu(), sc.grad, 2 ** -6, "bf16 fallback grad source")
+    assert_close(fd.grad.float().cpu(), fc.grad, 2 ** -5, "bf16 fallback grad flow")

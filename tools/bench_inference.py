@@ -7,7 +7,8 @@
         tools/bench_inference.py --gpus N                                           # batch sharded over N ranks
 
 Legs, each timed on its own (HIP events on the launch stream, MAX over ranks):
-  * fused forward: FC layers on this library's MFMA kernels (exact f32) + coefficient-table aggregation, eager and
+  * fused forward: FC layers on this library's MFMA kernels (--fc-mode, default 0 = exact f32; every line carries
+    the mode it was measured in) + coefficient-table aggregation, eager and
     captured in a hipGraph; next to the reference's op-by-op composition on the same gfx950 ops;
   * N > 1: all_gather_tiles of the generated feature tiles (the north star's "RCCL all-gather of generated tiles over
     xGMI"), timed separately from the compute and reported as bytes gathered per second.
@@ -47,6 +48,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (sharded over the ranks)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
+                    help="arithmetic of the FC contraction: 0 exact f32 MFMA (the product default, the reference's "
+                         "precision); 3 / 2 = f16-split operands (labelled experiments)")
     a = ap.parse_args()
     local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -60,12 +64,13 @@ def main():
     for name, C, H, W, k in (("L3", 256, 32, 32, 3), ("L2", 128, 64, 64, 5)):
         torch.manual_seed(0)  # same parameters on every rank
         m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(dev).eval()
+        m.fc_mode = a.fc_mode
         g = torch.Generator(device=dev).manual_seed(1 + rank)
         src = torch.randn(B, C, H, W, device=dev, generator=g)
         tgt = torch.randn(B, C, H, W, device=dev, generator=g)
         flow = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(
             torch.randn(B, 2, H, W, device=dev, generator=g) * 12, (3, 3, 3, 3), mode="replicate"), 7, 1).contiguous()
-        row = {"layer": name, "B_global": a.batch, "B_rank": B, "C": C, "HxW": "%dx%d" % (H, W), "k": k}
+        row = {"layer": name, "fc_mode": a.fc_mode, "B_global": a.batch, "B_rank": B, "C": C, "HxW": "%dx%d" % (H, W), "k": k}
         with torch.no_grad():
             m.fused = True
             out = m(src, tgt, flow)
@@ -91,7 +96,9 @@ def main():
         if rank == 0:
             print(json.dumps(row), flush=True)
     if rank == 0:
-        summary = {"both layers": {k: round(v, 1) for k, v in total.items()}, "n_gpus": world,
+        summary = {"fc_mode": a.fc_mode,
+                   "fc_arithmetic": "exact f32 MFMA" if a.fc_mode == 0 else "%d f16 terms per operand, f32 accumulate" % a.fc_mode,
+                   "both layers": {k: round(v, 1) for k, v in total.items()}, "n_gpus": world,
                    "images_per_s_fused": round(a.batch / (total["fused_us"] * 1e-6), 1),
                    "images_per_s_fused_hipgraph": round(a.batch / (total["fused_hipgraph_us"] * 1e-6), 1)}
         if "op_by_op_us" in total:
