@@ -207,6 +207,64 @@ class FacePath:
                        "fc_layers": "this library's MFMA kernels, arithmetic mode 1 (one f16 term per operand)"}}
 
 
+class TrainerPath:
+    """`--workload trainer_step` (BASELINE configs[3] on one rank's shard): one
+    TrainerShell.optimize_parameters step (pose_model.py:186-196) of the in-repo generator-shaped network
+    (warp_generator.WarpGenerator at the production widths: ngf 64 -> ExtractorAttn L3 (C256, 1/8 scale, k3) and L2
+    (C128, 1/4 scale, k5)) on a 256x176 batch: forward, L1 + sampling-correctness (frozen random VGG-shaped pyramid,
+    max-cosine MFMA kernel, Resample2d, fused loss map) + affine-regularisation losses, backward with the bucketed
+    reducer's hooks over ALL parameters, Adam step.  GAN / style terms stubbed, as configs[3] prescribes.  The stock
+    convolutions / InstanceNorms of the network run through torch (MIOpen), like the reference's own."""
+
+    def __init__(self, B, device, seed, fc_mode=0, ngf=64, size=(256, 176)):
+        from global_flow_local_attention_amd.trainer import TrainerShell
+        gen = torch.Generator(device=device).manual_seed(seed)
+        self.B, self.device = B, device
+        torch.manual_seed(1234)  # identical parameters on every rank
+        self.net = gfla.WarpGenerator(3, 18, 3, ngf, flow_scale=8.0).to(device)
+        for m in (self.net.attn3, self.net.attn2):
+            m.fc_mode = fc_mode
+        vgg = gfla.RandomFeaturePyramid(seed=11).to(device)
+        self.shell = TrainerShell(self.net, lr=1e-4, correctness=gfla.PerceptualCorrectness(vgg=vgg),
+                                  regularization=gfla.MultiAffineRegularizationLoss({"2": 5, "3": 3}), attn_layer=(2, 3))
+        H, W = size
+        rnd = lambda c: torch.rand(B, c, H, W, device=device, generator=gen)
+        self.source, self.target = rnd(3) * 2 - 1, rnd(3) * 2 - 1
+        self.source_B, self.target_B = rnd(18), rnd(18)
+        self.size, self.ngf, self.fc_mode = size, ngf, fc_mode
+        self.losses = {}
+
+    images_per_step = property(lambda self: self.B)
+
+    def params(self):
+        return list(self.net.parameters())
+
+    def step(self, resample=None, allreduce=True):
+        self.losses = self.shell.optimize_parameters((self.source, self.source_B, self.target_B), self.target,
+                                                     source=self.source)
+        return self.losses
+
+    def describe(self, args, world):
+        nparam = sum(p.numel() for p in self.params())
+        return {
+            "metric": "images/sec, one generator training step (fwd + losses + bwd + Adam) of a generator-shaped network "
+                      "around the GFLA hot path, 256x176",
+            "dtype": "f32",
+            "config": {"workload": "trainer_step: TrainerShell.optimize_parameters on WarpGenerator(ngf=%d) at %dx%d -- conv "
+                                   "encoders, flow head, ExtractorAttn L3 (C%d,%dx%d,k3) + L2 (C%d,%dx%d,k5) with mask blend, "
+                                   "decoder; losses L1 + PerceptualCorrectness (frozen random VGG-shaped pyramid) + "
+                                   "MultiAffineRegularizationLoss; GAN/style terms stubbed (BASELINE configs[3]); Adam step"
+                                   % (self.ngf, self.size[0], self.size[1], 4 * self.ngf, self.size[0] // 8, self.size[1] // 8,
+                                      2 * self.ngf, self.size[0] // 4, self.size[1] // 4),
+                       "batch_per_gpu": self.B, "global_batch": self.B * world, "parameters": nparam,
+                       "parallelism": "dp%d (batch shards; ALL %d parameters (%.1f MB) all-reduced in %d bucket(s) launched from "
+                                      "autograd hooks, overlapping backward)"
+                                      % (world, nparam, nparam * 4 / 1e6, len(self.shell.reducer.buckets)),
+                       "fc_layers": "this library's MFMA kernels, arithmetic mode %d; the network's stock convolutions / "
+                                    "InstanceNorms run through torch (MIOpen), as the reference's do" % self.fc_mode,
+                       "losses": {k: round(v, 5) for k, v in self.losses.items()}}}
+
+
 # ---- algorithmic bytes per C-ABI call (SURVEY.md section 8d; 4 bytes per fp32 element) -------
 def algorithmic_bytes(name, a, esz=None):
     base, suffix = name.rsplit("_", 1)
@@ -574,7 +632,9 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
     (tests/test_dist_cpu.py): a typo must not burn the one multi-GPU hardware run."""
     hp = make_hotpath(args.fc_mode)
     resample = make_resample()
-    face = getattr(args, "workload", "pose") == "face_bf16"
+    workload = getattr(args, "workload", "pose")
+    face = workload == "face_bf16"
+    custom = workload != "pose"  # face_bf16 / trainer_step: the workload object describes itself
     images = getattr(hp, "images_per_step", args.batch)
 
     def barrier():
@@ -584,7 +644,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             torch.cuda.synchronize()
 
     check = None
-    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline and not face:
+    if rank == 0 and world == 1 and on_gpu and not args.no_cpu_baseline and not custom:
         check = oracle_check(hp, resample)  # asserts; before anything is timed
     hp.step(resample)  # priming step: lazy initialisation, never timed
     # (Capturing the whole step -- forward + backward, ~90 launches -- into one hipGraph was measured and dropped: 7.146 ms
@@ -599,11 +659,11 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             for _ in range(args.steps):
                 hp.step(resample)
         rows = kt.summary()
-        if args.fc_impl == "mfma" and not face:
+        if args.fc_impl == "mfma" and not custom:
             probes = fc_kernel_probes(hp)
 
     variants = {}
-    if on_gpu and args.fc_impl == "mfma" and not args.no_variants and not face:
+    if on_gpu and args.fc_impl == "mfma" and not args.no_variants and not custom:
         for mode, label in ((3, "fc_mode3_f16x3_split"), (2, "fc_mode2_f16x2_split")):
             if mode == args.fc_mode:
                 continue
@@ -642,10 +702,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         "kernels": rows,
         "fc_kernels": probes,
     }
-    if face:
+    if custom:
         line.update(hp.describe(args, world))
         line["value"] = round(images * world * args.steps / elapsed, 2)
-        line["unit"] = "frames/s"
+        line["unit"] = "frames/s" if face else "images/s"
     if probes:
         # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
         # with the longest launch
@@ -679,7 +739,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
     if check is not None:
         line["oracle_check"] = check
     if rank == 0:
-        if world == 1 and on_gpu and not args.no_cpu_baseline:
+        if world == 1 and on_gpu and not args.no_cpu_baseline and not custom:
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(line), flush=True)
     return line
@@ -698,10 +758,11 @@ def parse_args(argv=None):
                          "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")
     ap.add_argument("--fc-impl", choices=("mfma", "library"), default="mfma",
                     help="FC layers of ExtractorAttn: this library's MFMA kernels (default) or round 1's vendor GEMM/conv path")
-    ap.add_argument("--workload", choices=("pose", "face_bf16"), default="pose",
+    ap.add_argument("--workload", choices=("pose", "face_bf16", "trainer_step"), default="pose",
                     help="pose: the headline (BASELINE metric, PoseGenerator 256x176 shapes, f32).  face_bf16: BASELINE "
                          "configs[4] -- FaceGenerator 256x256 shapes, two ExtractorAttn per layer, 6 sequential frames, "
-                         "bf16 features; --batch is then clips per GPU")
+                         "bf16 features; --batch is then clips per GPU.  trainer_step: one TrainerShell.optimize_parameters step "
+                         "of the in-repo generator-shaped network (SURVEY 8f row 4 / BASELINE configs[3] per rank)")
     ap.add_argument("--frames", type=int, default=6, help="face_bf16: frames generated per clip")
     ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3), default=0,
                     help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
@@ -738,6 +799,8 @@ def main():
     def make_hotpath(fc_mode):
         if args.workload == "face_bf16":
             return FacePath(args.batch, device, seed=100 + rank, frames=args.frames)
+        if args.workload == "trainer_step":
+            return TrainerPath(args.batch, device, seed=100 + rank, fc_mode=fc_mode)
         return HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
                        fc_mode=fc_mode, with_losses=args.with_losses)
 

@@ -15,6 +15,7 @@ from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCo
 from .graphs import GraphedCall, graphed_inference  # noqa: F401
 from .install import install  # noqa: F401
 from .trainer import TrainerShell, load_reference_checkpoint  # noqa: F401
+from .warp_generator import RandomFeaturePyramid, WarpGenerator  # noqa: F401
 from .tuning import enable_gemm_tuning, gemm_tuning_results, seed_conv_db  # noqa: F401
 
 __version__ = "0.1.0"

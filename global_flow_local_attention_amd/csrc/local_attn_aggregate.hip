@@ -1436,7 +1436,8 @@ static int aggregate_bwd(const T *src, const T *flow, const T *attn, const T *go
       if (st != GFLA_ERR_UNSUPPORTED) return st;
     }
   }
-  if (tuning(3) != 1 && Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) <= kLdsBudget) {
+  // bf16 storage exists for the planes-in-LDS kernels only: the forced-global test knob (key 3) does not apply to it
+  if ((tuning(3) != 1 || sizeof(T) == 2) && Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(A)) <= kLdsBudget) {
     // (1) grad_source + grad_flow: block_extractor backward of the factored gradient a_ij*g_c/k^2
     if (gsrc || gflow) {
       bool done = false;

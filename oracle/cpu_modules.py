@@ -97,11 +97,21 @@ def max_cosine_cpu(source, target, eps=1e-8):
 class PerceptualCorrectnessCPU(nn.Module):
     """external_function.py:246-279 (calculate_loss) op by op on the host, with the CPU Resample2d."""
 
-    def __init__(self):
+    def __init__(self, vgg=None, layer=('rel1_1', 'relu2_1', 'relu3_1', 'relu4_1')):
         super().__init__()
         self.eps = 1e-8
         self.resample = Resample2dCPU(4, 1, sigma=2)
         self.target_vgg, self.source_vgg = {}, {}
+        self.vgg, self.layer = vgg, list(layer)
+
+    def __call__(self, target, source, flow_list, used_layers, mask=None):
+        """external_function.py:235-243 with an injected feature extractor."""
+        used_layers = sorted(used_layers, reverse=True)
+        self.target_vgg, self.source_vgg = self.vgg(target), self.vgg(source)
+        loss = 0
+        for i in range(len(flow_list)):
+            loss = loss + self.calculate_loss(flow_list[i], self.layer[used_layers[i]], mask)
+        return loss
 
     def calculate_loss(self, flow, layer, mask=None):
         target_vgg, source_vgg = self.target_vgg[layer], self.source_vgg[layer]

@@ -128,3 +128,24 @@ def test_trainer_shell_world2_matches_single_process():
     shell.optimize_parameters((img,), tgt)
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.allclose(flat, ret[0], atol=1e-5)
+
+
+def test_warp_generator_step_on_host_with_oracle_blocks():
+    """The generator-shaped network + trainer shell, every hot-path op the oracle's: shapes, conventions
+    (generator.py:13-36 return triple, coarse-to-fine flow order), all parameters reached, one Adam step taken."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import trainer_util as tu
+    shell, net = tu.build_shell("cpu", ngf=8)
+    batch = tu.make_batch(2, 32, 32)
+    gen, flows, masks = net(batch[0], batch[2], batch[3])
+    assert gen.shape == (2, 3, 32, 32)
+    assert [tuple(f.shape) for f in flows] == [(2, 2, 4, 4), (2, 2, 8, 8)]
+    assert [tuple(m.shape) for m in masks] == [(2, 1, 4, 4), (2, 1, 8, 8)]
+    keys = set(net.state_dict())
+    assert {"attn3.fully_connect_layer.0.weight", "attn2.fully_connect_layer.2.bias"} <= keys
+    losses, grads, before, after = tu.run_step(shell, net, batch, "cpu")
+    assert set(losses) == {"app_gen", "correctness_gen", "regularization"}
+    assert all(v == v and abs(v) < 1e6 for v in losses.values())
+    assert set(grads) == set(before), set(before) - set(grads)           # every parameter got a gradient
+    moved = [n for n in before if not torch.equal(before[n], after[n])]
+    assert len(moved) == len(before)

@@ -1,0 +1,54 @@
+"""Shared by the CPU and GPU trainer tests: one `TrainerShell.optimize_parameters` step of the in-repo generator-shaped
+network (`WarpGenerator`) with the sampling-correctness and affine-regularisation losses -- buildable on the GPU ops or,
+identically parameterised, on the host with the oracle's op-by-op blocks (the checker)."""
+import torch
+
+
+def make_batch(B, H, W, structure_nc=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    tgt = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    src_B = torch.rand(B, structure_nc, H, W, generator=g)
+    tgt_B = torch.rand(B, structure_nc, H, W, generator=g)
+    return src, tgt, src_B, tgt_B
+
+
+def build_shell(device, ngf=16, structure_nc=6, seed=5, flow_scale=6.0, lr=1e-3, state=None, bucket_mb=32.0):
+    """(shell, net).  device 'cpu' -> every hot-path op is the oracle's (cpu_modules); a cuda device -> this library's."""
+    import global_flow_local_attention_amd as gfla
+    from global_flow_local_attention_amd.trainer import TrainerShell
+    on_gpu = torch.device(device).type == "cuda"
+    vgg = gfla.RandomFeaturePyramid(seed=11)
+    torch.manual_seed(seed)
+    if on_gpu:
+        net = gfla.WarpGenerator(3, structure_nc, 3, ngf, flow_scale=flow_scale)
+        correctness = gfla.PerceptualCorrectness(vgg=vgg.to(device))
+        regular = gfla.MultiAffineRegularizationLoss({"2": 5, "3": 3})
+    else:
+        from oracle import cpu_modules
+        net = gfla.WarpGenerator(3, structure_nc, 3, ngf, attn_cls=cpu_modules.ExtractorAttnCPU, flow_scale=flow_scale)
+        correctness = cpu_modules.PerceptualCorrectnessCPU(vgg=vgg)
+
+        class _Regular(object):  # external_function.py:12-27 over the oracle's op-by-op AffineRegularizationLoss
+            def __init__(self):
+                self.m = {"3": cpu_modules.AffineRegularizationLossOpByOp(3), "2": cpu_modules.AffineRegularizationLossOpByOp(5)}
+
+            def __call__(self, flows):
+                return self.m["3"](flows[0]) + self.m["2"](flows[1])
+
+        regular = _Regular()
+    if state is not None:
+        net.load_state_dict(state)
+    net = net.to(device)
+    shell = TrainerShell(net, lr=lr, correctness=correctness, regularization=regular, attn_layer=(2, 3),
+                         bucket_mb=bucket_mb)
+    return shell, net
+
+
+def run_step(shell, net, batch, device):
+    src, tgt, src_B, tgt_B = (t.to(device) for t in batch)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    losses = shell.optimize_parameters((src, src_B, tgt_B), tgt, source=src)
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    after = {n: p.detach().clone() for n, p in net.named_parameters()}
+    return losses, grads, before, after
