@@ -537,7 +537,10 @@ def fc_kernel_probes(hp, iters=10):
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / iters * 1e3
                 tf = flops / (us * 1e-6) / 1e12
-                kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
+                if mode == 4:
+                    kern = "fc_wino_conv_kernel" if which < 4 else "fc_wgrad_f32_kernel"
+                else:
+                    kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
                 rows.append({"kernel": "%s<mode %d, k %d>: %s" % (kern, mode, k, nm), "dims": [B, C, H, W, k],
                              "avg_us": round(us, 1), "alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(tf, 1),
                              "frac_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
@@ -697,7 +700,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                    "parallelism": "dp%d (batch shards; ExtractorAttn gradients all-reduced in one flat bucket launched "
                                   "from autograd hooks, overlapping backward)" % world,
                    "fc_layers": ("this library's MFMA kernels, arithmetic mode %d (%s); no vendor GEMM / convolution in the step"
-                                 % (args.fc_mode, "exact f32" if args.fc_mode == 0 else "f16-split operands, f32 accumulate"))
+                                 % (args.fc_mode, {0: "exact f32, direct convolution", 4: "f32, Winograd-domain convolutions F(2x2,5x5) / "
+                                                   "F(4x4,3x3)"}.get(args.fc_mode, "f16-split operands, f32 accumulate")))
                    if args.fc_impl == "mfma" else "round 1's vendor-library path (torch.mm / F.conv2d)"},
         "kernels": rows,
         "fc_kernels": probes,
@@ -764,7 +768,7 @@ def parse_args(argv=None):
                          "bf16 features; --batch is then clips per GPU.  trainer_step: one TrainerShell.optimize_parameters step "
                          "of the in-repo generator-shaped network (SURVEY 8f row 4 / BASELINE configs[3] per rank)")
     ap.add_argument("--frames", type=int, default=6, help="face_bf16: frames generated per clip")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3), default=0,
+    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4), default=0,
                     help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
                          "f16 terms per operand with f32 accumulation (labelled experiments)")
     ap.add_argument("--with-losses", action="store_true",

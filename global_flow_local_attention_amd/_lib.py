@@ -189,7 +189,7 @@ def set_tuning(key, value):
 
 ABI_VERSION = 3
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
-PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0 = 0, 1, 2, 6
+PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_COUNT = 0, 1, 2, 7, 12
 
 
 def path_count(path):

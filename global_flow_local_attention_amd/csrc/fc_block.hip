@@ -16,12 +16,14 @@ struct FcLayout {
   FcHalf hs, ht;
   int nch_c, cpad, nt_d, KK, dw1_tiles;
   // forward workspace, kept for backward
-  int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, fwd_total;
+  int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, wu_ft, wu_fs, wu_dt, wu_ds, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
   int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, bwd_total;
 };
 
-static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode) {
+static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
+  const bool wino = mode_ == 4;
+  const int mode = fc_base_mode(mode_);
   FcLayout L;
   L.hs = fc_half(H, W, k, true);
   L.ht = fc_half(H, W, k, false);
@@ -41,11 +43,16 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode) {
   L.xt = take(fc_packed_bytes(B, L.nch_c, L.ht.Sx, mode));
   L.gs = take(B * L.hs.Mg * kFcHidden * 4);
   L.hid = take(B * (int64_t)H * W * kFcHidden * 4);
-  L.wd_t = take(fc_wpack_bytes(L.nt_d, nch_h, k, mode));
-  L.wd_s = take(fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  L.wd_t = take(wino ? 0 : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  L.wd_s = take(wino ? 0 : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
   L.gt = take(B * L.ht.Mg * kFcHidden * 4);
-  L.wf_t = take(fc_wpack_bytes(1, L.nch_c, k, mode));
-  L.wf_s = take(fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.wf_t = take(wino ? 0 : fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.wf_s = take(wino ? 0 : fc_wpack_bytes(1, L.nch_c, k, mode));
+  // Winograd mode: U = G w G^T of the forward (C -> 128) and data-gradient (128 -> C) convolutions of both halves
+  L.wu_ft = take(wino ? fc_wino_wpack_bytes(C, kFcHidden) : 0);
+  L.wu_fs = take(wino ? fc_wino_wpack_bytes(C, kFcHidden) : 0);
+  L.wu_dt = take(wino ? fc_wino_wpack_bytes(kFcHidden, C) : 0);
+  L.wu_ds = take(wino ? fc_wino_wpack_bytes(kFcHidden, C) : 0);
   L.fwd_total = o;
 
   o = 0;
@@ -80,8 +87,12 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
   if (B > 65535 || C > 4096 || H > 2048 || W > 2048) return GFLA_ERR_UNSUPPORTED;
   // the smallest input tile of each convolution (64 outputs + the tap halo) has to fit the LDS of a CU
   const FcHalf hs = fc_half((int)H, (int)W, k, true), ht = fc_half((int)H, (int)W, k, false);
-  if (!fc_conv_fits(hs.Wo, hs.Wp, k, mode) || !fc_conv_fits(hs.Wp, hs.Wp, k, mode) ||
-      !fc_conv_fits(ht.Wo, ht.Wp, k, mode) || !fc_conv_fits(ht.Wp, ht.Wp, k, mode))
+  if (mode == 4) {
+    if (!fc_wino_fits(hs.Mv, hs.Wo, hs.Wp, k) || !fc_wino_fits(hs.Md, hs.Wp, hs.Wp, k) ||
+        !fc_wino_fits(ht.Mv, ht.Wo, ht.Wp, k) || !fc_wino_fits(ht.Md, ht.Wp, ht.Wp, k))
+      return GFLA_ERR_UNSUPPORTED;
+  } else if (!fc_conv_fits(hs.Wo, hs.Wp, k, mode) || !fc_conv_fits(hs.Wp, hs.Wp, k, mode) ||
+             !fc_conv_fits(ht.Wo, ht.Wp, k, mode) || !fc_conv_fits(ht.Wp, ht.Wp, k, mode))
     return GFLA_ERR_UNSUPPORTED;
   if ((int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
   return GFLA_OK;
@@ -93,14 +104,24 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
     if (rc_ != GFLA_OK) return rc_; \
   } while (0)
 
+// the four Winograd weight sets of one layer (mode 4)
+static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream) {
+  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), C, 0, 0, k, stream));
+  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_fs), C, C, 0, k, stream));
+  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_dt), C, 0, 1, k, stream));
+  return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ds), C, C, 1, k, stream);
+}
+
 static int fc_forward(const float *source, const float *target, const float *flow, const float *w0, const float *b0,
                       const float *w1, const float *b1, void *ws_, float *logits, int64_t B, int C, int H, int W,
-                      int k, float slope, int mode, hipStream_t stream) {
+                      int k, float slope, int mode_, hipStream_t stream) {
   if (!source || !target || !flow || !w0 || !w1 || !ws_ || !logits) return GFLA_ERR_NULL_POINTER;
-  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode_));
   if (B == 0) return GFLA_OK;
-  note_path(GFLA_PATH_FC_FWD_MODE0 + mode);
-  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  note_path(GFLA_PATH_FC_FWD_MODE0 + mode_);
+  const FcLayout L = fc_layout(B, C, H, W, k, mode_);
+  const bool wino = mode_ == 4;
+  const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const uint32_t *a_src = mode ? amax + kAmaxSrc : nullptr, *a_tgt = mode ? amax + kAmaxTgt : nullptr;
@@ -113,15 +134,23 @@ static int fc_forward(const float *source, const float *target, const float *flo
   }
   GFLA_TRY(fc_pack_act(source, a_src, ws + L.xs, B, C, H, W, L.hs, mode, stream));
   GFLA_TRY(fc_pack_act(target, a_tgt, ws + L.xt, B, C, H, W, L.ht, mode, stream));
-  GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
   float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
-  const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
-  GFLA_TRY(fc_conv(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.Mv,
-                   L.hs.Wo, L.hs.Wp, k, mode, a_src, a_w, stream));
-  GFLA_TRY(fc_conv(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.Mv,
-                   L.ht.Wo, L.ht.Wp, k, mode, a_tgt, a_w, stream));
+  if (wino) {
+    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
+    GFLA_TRY(fc_wino_conv(xs, reinterpret_cast<const float *>(ws + L.wu_fs), gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden,
+                          B, L.nch_c, L.hs.Mv, L.hs.Wo, L.hs.Wp, L.hs.Sx, k, stream));
+    GFLA_TRY(fc_wino_conv(xt, reinterpret_cast<const float *>(ws + L.wu_ft), gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden,
+                          B, L.nch_c, L.ht.Mv, L.ht.Wo, L.ht.Wp, L.ht.Sx, k, stream));
+  } else {
+    GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
+    const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
+    GFLA_TRY(fc_conv(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.Mv,
+                     L.hs.Wo, L.hs.Wp, k, mode, a_src, a_w, stream));
+    GFLA_TRY(fc_conv(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.Mv,
+                     L.ht.Wo, L.ht.Wp, k, mode, a_tgt, a_w, stream));
+  }
   return fc_sample_tail_fwd(gs, gt, flow, b0, w1, b1, reinterpret_cast<float *>(ws + L.hid), logits, B, H, W, k,
                             L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wo, L.ht.Wo, slope, stream);
 }
@@ -129,8 +158,10 @@ static int fc_forward(const float *source, const float *target, const float *flo
 // data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
 // Z-layout gradient map
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
-                            float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode,
+                            float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode_,
                             hipStream_t stream, int acc_x = 0) {
+  const bool wino = mode_ == 4;
+  const int mode = fc_base_mode(mode_);
   const bool want_w = g_w0 != nullptr;
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const int nch_h = kFcHidden / kFcChunk;
@@ -150,9 +181,14 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   }
   if (g_x) {
     float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
-    const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
-    GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
-                     g.Wp, k, mode, a_z, a_w, stream));
+    if (wino) {
+      GFLA_TRY(fc_wino_conv(Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C,
+                            C, B, nch_h, g.Md, g.Wp, g.Wp, g.Sz, k, stream));
+    } else {
+      const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
+      GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
+                       g.Wp, k, mode, a_z, a_w, stream));
+    }
     GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
   }
   if (want_w) {
@@ -171,13 +207,14 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
 
 static int fc_backward(void *ws_, const float *flow, const float *w1, const float *g_logits, void *scratch_,
                        float *g_source, float *g_target, float *g_flow, float *g_w0, float *g_b0, float *g_w1,
-                       float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode, int flags,
+                       float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode_, int flags,
                        hipStream_t stream) {
   if (!ws_ || !flow || !w1 || !g_logits || !scratch_) return GFLA_ERR_NULL_POINTER;
-  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
+  GFLA_TRY(fc_args_ok(B, C, H, W, k, mode_));
   if (B == 0) return GFLA_OK;
-  note_path(GFLA_PATH_FC_BWD_MODE0 + mode);
-  const FcLayout L = fc_layout(B, C, H, W, k, mode);
+  note_path(GFLA_PATH_FC_BWD_MODE0 + mode_);
+  const FcLayout L = fc_layout(B, C, H, W, k, mode_);
+  const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
@@ -205,9 +242,9 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
       return GFLA_ERR_LAUNCH;
   }
   if (need_s)
-    GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode, stream,
+    GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode_, stream,
                               (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0));
-  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode, stream));
+  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream));
   if (g_w0 && mode != 0) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
@@ -274,6 +311,13 @@ int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *w
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (mode == 4) {
+    unsigned char *xq = ws + (is_source ? L.xs : L.xt);
+    GFLA_TRY(fc_pack_act(x, nullptr, xq, B, C, H, W, g, 0, stream));
+    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
+    return fc_wino_conv(fc_desc_packed(xq, B, L.nch_c, g.Sx, 0), reinterpret_cast<const float *>(ws + (is_source ? L.wu_fs : L.wu_ft)),
+                        out, g.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, g.Mv, g.Wo, g.Wp, g.Sx, k, stream);
+  }
   uint32_t *a_x = mode ? amax + (is_source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;
   if (mode) {
     GFLA_TRY(fc_maxabs(x, B * (int64_t)C * H * W, a_x, stream));
@@ -308,11 +352,11 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
   if (hipMemcpyAsync(sc + (is_source ? L.dzs : L.dzt), z, (size_t)(B * g.Sz * kFcHidden * 4), hipMemcpyDeviceToDevice,
                      stream) != hipSuccess)
     return GFLA_ERR_LAUNCH;
-  if (grad_w0 && mode == 0 &&  // the other half of conv0.weight.grad is zero by contract
+  if (grad_w0 && fc_base_mode(mode) == 0 &&  // the other half of conv0.weight.grad is zero by contract
       hipMemsetAsync(grad_w0, 0, (size_t)kFcHidden * 2 * C * k * k * 4, stream) != hipSuccess)
     return GFLA_ERR_LAUNCH;
   GFLA_TRY(fc_half_backward(L, g, is_source != 0, ws, sc, grad_x, grad_w0, B, C, H, W, k, mode, stream));
-  if (grad_w0 && mode != 0) {
+  if (grad_w0 && fc_base_mode(mode) != 0) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
                              a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,
@@ -336,6 +380,19 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
   const bool source = (which & 1) == 0;
   const FcHalf &g = source ? L.hs : L.ht;
   unsigned char *ws = static_cast<unsigned char *>(workspace), *sc = static_cast<unsigned char *>(scratch);
+  if (mode == 4) {
+    const PackedDesc X4 = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, 0);
+    const PackedDesc Z4 = fc_desc_nhwc(reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz, kFcHidden);
+    if (which < 2)
+      return fc_wino_conv(X4, reinterpret_cast<const float *>(ws + (source ? L.wu_fs : L.wu_ft)),
+                          reinterpret_cast<float *>(ws + (source ? L.gs : L.gt)), g.Mg * kFcHidden, kFcHidden, kFcHidden, B,
+                          L.nch_c, g.Mv, g.Wo, g.Wp, g.Sx, k, stream);
+    if (which < 4)
+      return fc_wino_conv(Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
+                          reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, B,
+                          kFcHidden / kFcChunk, g.Md, g.Wp, g.Wp, g.Sz, k, stream);
+    return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
+  }
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const uint32_t *a_x = mode ? amax + (source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;
   const uint32_t *a_z = mode ? amax + (source ? kAmaxZs : kAmaxZt) : nullptr;

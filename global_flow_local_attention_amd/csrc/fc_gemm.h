@@ -45,9 +45,13 @@ struct Fc<3> {
   static constexpr int NS = 3, ESZ = 2, REC = 32, PIECES = 2, PITCH = 48, KB = 1;
 };
 
+//   4: float32 throughout, Winograd domain (fc_wino.hip): F(2x2,5x5) / F(4x4,3x3) on the same 6 points, the 36 point-wise
+//      products as f32 MFMA GEMMs over the channels -- 2.78x / 4x fewer multiplies; operands, packing and every other
+//      kernel are mode 0's.
+inline int fc_base_mode(int mode) { return mode == 4 ? 0 : mode; }  // operand format / non-convolution kernels
 inline int fc_nsplit(int mode) { return mode == 0 ? 1 : mode; }
 inline int fc_esz(int mode) { return mode == 0 ? 4 : 2; }
-inline bool fc_mode_ok(int mode) { return mode >= 0 && mode <= 3; }
+inline bool fc_mode_ok(int mode) { return mode >= 0 && mode <= 4; }
 
 // An activation operand: 16-channel records, pixel-linear inside a sample (row pitch = the padded width, so a
 // k x k tap is a constant pixel offset), chunk-major.  Strides in bytes.
@@ -146,6 +150,13 @@ PackedDesc fc_desc_nhwc(const float *base, int64_t S, int Cz);
 int64_t fc_packed_bytes(int64_t B, int nch, int64_t S, int mode);
 int64_t fc_wpack_bytes(int ntiles, int nch, int k, int mode);
 int fc_tr_probe(const short *image, int n_halves, const int *offsets, short *out, hipStream_t stream);
+
+// fc_wino.hip (arithmetic mode 4)
+int64_t fc_wino_wpack_bytes(int n_in, int n_out);
+int fc_wino_pack_weights(const float *w0, float *U, int C, int c_off, int dgrad, int k, hipStream_t stream);
+bool fc_wino_fits(int M, int Wv, int Wp, int k);
+int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
+                 int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream);
 
 // fc_sample.hip
 int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,

@@ -14,7 +14,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-MODES = (0, 1, 2, 3)
+MODES = (0, 1, 2, 3, 4)
 # exact f32 (v_mfma_f32_32x32x2_f32): the reference computes this layer in fp32 (base_function.py:799-810), so this is
 # what a module without an explicit `fc_mode` gets; 2 / 3 are labelled experiments, 1 belongs to the bf16-feature path
 DEFAULT_MODE = 0

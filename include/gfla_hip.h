@@ -72,15 +72,17 @@ int gfla_set_tuning(int key, int value);
 enum gfla_path {
   GFLA_PATH_BE_BWD_LDS = 0,     /* block_extractor backward: planes-in-LDS kernel */
   GFLA_PATH_BE_BWD_GLOBAL = 1,  /* block_extractor backward: global-atomics kernel (tuning key 2) */
-  GFLA_PATH_FC_FWD_MODE0 = 2,   /* gfla_fc_forward_f32 in arithmetic mode 0 .. 3 = ids 2 .. 5 */
+  GFLA_PATH_FC_FWD_MODE0 = 2,   /* gfla_fc_forward_f32 in arithmetic mode 0 .. 4 = ids 2 .. 6 */
   GFLA_PATH_FC_FWD_MODE1 = 3,
   GFLA_PATH_FC_FWD_MODE2 = 4,
   GFLA_PATH_FC_FWD_MODE3 = 5,
-  GFLA_PATH_FC_BWD_MODE0 = 6,   /* gfla_fc_backward_f32, ids 6 .. 9 */
-  GFLA_PATH_FC_BWD_MODE1 = 7,
-  GFLA_PATH_FC_BWD_MODE2 = 8,
-  GFLA_PATH_FC_BWD_MODE3 = 9,
-  GFLA_PATH_COUNT = 10
+  GFLA_PATH_FC_FWD_MODE4 = 6,
+  GFLA_PATH_FC_BWD_MODE0 = 7,   /* gfla_fc_backward_f32, ids 7 .. 11 */
+  GFLA_PATH_FC_BWD_MODE1 = 8,
+  GFLA_PATH_FC_BWD_MODE2 = 9,
+  GFLA_PATH_FC_BWD_MODE3 = 10,
+  GFLA_PATH_FC_BWD_MODE4 = 11,
+  GFLA_PATH_COUNT = 12
 };
 int64_t gfla_path_count(int path);
 

@@ -34,7 +34,7 @@ BENCH_SHAPES = [  # (name, B, C, H, W, k)
     ("attn3_256x256", 32, 256, 32, 32, 3),
     ("attn2_256x256", 32, 128, 64, 64, 5),
 ]
-FC_PATHS = [("mfma", 0), ("mfma", 3), ("mfma", 2), ("library", 0)]
+FC_PATHS = [("mfma", 0), ("mfma", 4), ("mfma", 3), ("mfma", 2), ("library", 0)]
 
 
 def _ref():

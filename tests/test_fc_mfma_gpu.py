@@ -17,7 +17,7 @@ from util import assert_close, make_flow, max_abs, randn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MODES = (0, 3, 2)
+MODES = (0, 4, 3, 2)
 FWD_TOL, GRAD_TOL = 1e-5, 2e-5
 
 

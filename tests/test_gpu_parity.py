@@ -962,18 +962,18 @@ def test_default_fc_arithmetic_is_exact_f32(gfla, kernel_variant):
         pytest.skip("dispatch test, independent of the gather/scatter variant")
     from global_flow_local_attention_amd import _lib, fc_mfma
     assert fc_mfma.DEFAULT_MODE == 0
-    before = [_lib.path_count(i) for i in range(10)]
+    before = [_lib.path_count(i) for i in range(_lib.PATH_COUNT)]
     mod = gfla.ExtractorAttn(16, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
     assert not hasattr(mod, "fc_mode")
     s, t = (randn((2, 16, 12, 10), seed=i).to(DEV).requires_grad_() for i in (1, 2))
     f = make_flow("smooth", 2, 12, 10, seed=3).to(DEV).requires_grad_()
     mod(s, t, f).sum().backward()
     torch.cuda.synchronize()
-    after = [_lib.path_count(i) for i in range(10)]
+    after = [_lib.path_count(i) for i in range(_lib.PATH_COUNT)]
     delta = [a - b for a, b in zip(after, before)]
     assert delta[_lib.PATH_FC_FWD_MODE0] == 1 and delta[_lib.PATH_FC_BWD_MODE0] == 1, delta
-    assert sum(delta[_lib.PATH_FC_FWD_MODE0 + 1:_lib.PATH_FC_FWD_MODE0 + 4]) == 0, delta   # no f16-split forward
-    assert sum(delta[_lib.PATH_FC_BWD_MODE0 + 1:_lib.PATH_FC_BWD_MODE0 + 4]) == 0, delta
+    assert sum(delta[_lib.PATH_FC_FWD_MODE0 + 1:_lib.PATH_FC_FWD_MODE0 + 5]) == 0, delta   # no other arithmetic
+    assert sum(delta[_lib.PATH_FC_BWD_MODE0 + 1:_lib.PATH_FC_BWD_MODE0 + 5]) == 0, delta
     mod.fc_mode = 3                                                                         # explicit opt-in still works
     mod(s, t, f).sum().backward()
     assert _lib.path_count(_lib.PATH_FC_FWD_MODE0 + 3) == after[_lib.PATH_FC_FWD_MODE0 + 3] + 1
