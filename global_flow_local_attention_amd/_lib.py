@@ -50,6 +50,7 @@ _SINGLE = {
     "gfla_fc_conv_fwd_f32": [_ptr, _ptr, _int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_fc_conv_bwd_f32": [_ptr, _int, _ptr, _ptr, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_fc_tr_probe": [_ptr, _int, _ptr, _ptr, _ptr],
+    "gfla_fc_wino_debug_buffer": [_ptr],
     "gfla_fc_kernel_f32": [_int, _ptr, _ptr] + [_i64] * 4 + [_int, _int, _ptr],
     "gfla_scatter_workspace_bytes": [_i64] * 3 + [_int],
     "gfla_aggregate_fwd_workspace_bytes": [_i64] * 3 + [_int],

@@ -12,17 +12,19 @@
 //
 // One fused kernel per convolution (forward of either half, and the data gradient = the same kernel on the Z-layout
 // gradient map with flipped / transposed weights): no transformed tensor ever exists in HBM.
-//   workgroup = 32 tiles (two 16-row MFMA blocks) x 64 output channels x ALL 36 points; 4 waves, wave w = output
-//   channels 16w..16w+15, 36 x 2 accumulators of 16x16 (288 registers; one wave per SIMD, 512-register budget);
+//   workgroup = 32 tiles (two 16-row MFMA blocks) x 64 output channels x ALL 36 points; 8 waves, wave w = output
+//   channels 16(w&3)..+15 and 18 of the 36 points (three rows of the point grid): 18 x 2 accumulators of 16x16 (144
+//   registers, two waves per SIMD);
 //   per 8-channel step:  A = transformed input V[point][tile][8 ch] from LDS (double buffered: the NEXT step's
-//   transform -- 256 (tile, channel) items, one per thread, B^T d B in registers -- runs on the vector ALUs while
-//   this step's 144 MFMAs run on the matrix cores), B = the wave's slice of U = G w G^T, global -> registers directly
-//   in fragment layout, each register reloaded for the next step right after its last use;
+//   transform -- a thread takes one (tile, channel) item, B^T d in registers, then its wave's three rows of
+//   (B^T d) B -- runs on the vector ALUs while the other wave of the SIMD runs this step's MFMAs: the two waves of a
+//   SIMD take the two halves of a step in opposite order), B = the wave's slice of U = G w G^T, global -> registers
+//   directly in fragment layout, each register reloaded for the next step right after its last use;
 //   raw input pixels of a 16-channel chunk: one contiguous span of the linearised map (tap (i,j) = pixel offset
 //   i*Wp + j, as in fc_conv_impl.h), prefetched into registers one step ahead, LDS pitch 80 / 72 bytes so that the
 //   transform's reads (8 tiles x 8 channels per wave) are spread over all banks;
-//   epilogue: A^T M A per lane in registers (a lane holds all 36 points of its (tile, channel) pairs), stores to the
-//   same (pixel, channel) f32 map fc_conv writes.
+//   epilogue: A^T M A: each wave reduces its three point rows to an m x m partial per (tile, channel) in registers, the
+//   wave pairs swap partials through LDS, stores go to the same (pixel, channel) f32 map fc_conv writes.
 #include "fc_gemm.h"
 
 namespace gfla {
@@ -31,12 +33,14 @@ constexpr int kWnXi = 36;       // 6 x 6 points
 constexpr int kWnTiles = 32;    // tiles per workgroup
 constexpr int kWnN = 64;        // output channels per workgroup
 constexpr int kWnVFloats = kWnXi * kWnTiles * 8;  // one V buffer: [point][tile][8 channels]
-constexpr int kWnPF = 10;       // 16-byte pieces of the raw span a thread holds in registers across a step
+constexpr int kWnThreads = 512;
+constexpr unsigned kWnLdsLimit = 160 * 1024;
+constexpr int kWnPF = 5;        // 16-byte pieces of the raw span a thread holds in registers across half a step
 
 template <int KS>
 struct Wn {
   static constexpr int M = KS == 5 ? 2 : 4;        // output tile edge
-  static constexpr int PITCH = KS == 5 ? 80 : 72;  // LDS bytes per raw pixel (16 channels + pad): tile stride = 8 banks
+  static constexpr int PITCH = 80;                 // LDS bytes per raw pixel (16 channels + one 16-byte pad slot)
 };
 
 // ---- the three transforms (points 0, 1, -1, 2, -1/2, inf) -----------------------------------------------------
@@ -48,6 +52,19 @@ __device__ __forceinline__ void wn_bt(const float (&d)[6], float (&o)[6]) {
   o[3] = -0.5f * d[1] - d[2] + 0.5f * d[3] + d[4];
   o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
   o[5] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
+}
+// rows 3*HALF .. 3*HALF + 2 of B^T d
+template <int HALF>
+__device__ __forceinline__ void wn_bt3(const float (&d)[6], float (&o)[3]) {
+  if constexpr (HALF == 0) {
+    o[0] = d[0] + 1.5f * d[1] - 2.f * d[2] - 1.5f * d[3] + d[4];
+    o[1] = -d[1] - 2.5f * d[2] - 0.5f * d[3] + d[4];
+    o[2] = d[1] + 0.5f * d[2] - 2.5f * d[3] + d[4];
+  } else {
+    o[0] = -0.5f * d[1] - d[2] + 0.5f * d[3] + d[4];
+    o[1] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    o[2] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
+  }
 }
 // A^T (m x 6)
 template <int M>
@@ -164,23 +181,43 @@ static WnGeo wn_geometry(int M, int Wv, int Wp) {
 }
 
 template <int KS>
-static unsigned wn_lds_bytes(const WnGeo &g) {
-  return (unsigned)(2 * kWnVFloats * 4 + ((g.span * Wn<KS>::PITCH + 15) & ~15));
+static unsigned wn_raw_bytes(const WnGeo &g) { return (unsigned)((g.span * Wn<KS>::PITCH + 15) & ~15); }
+
+// double_raw: two raw buffers (the next chunk's pixels land while this chunk is transformed: no extra barrier)
+template <int KS>
+static unsigned wn_lds_bytes(const WnGeo &g, bool double_raw) {
+  constexpr int m = Wn<KS>::M;
+  const unsigned main_loop = (unsigned)(2 * kWnVFloats * 4) + (double_raw ? 2u : 1u) * wn_raw_bytes<KS>(g);
+  const unsigned exchange = (unsigned)(kWnThreads * 4 * m * m * 4);  // epilogue: partial outputs of the wave pairs
+  return main_loop > exchange ? main_loop : exchange;
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+struct Half0 { static constexpr int value = 0; };
+struct Half1 { static constexpr int value = 1; };
+typedef Half1 Yes;
+typedef Half0 No;
 
-template <int KS>
-__global__ __launch_bounds__(256, 1) void fc_wino_conv_kernel(PackedDesc X, const float *__restrict__ U,
-                                                             float *__restrict__ out, int64_t out_bs, int ldo,
-                                                             int n_valid, int Ho, int Wv, int Wp, int nch, WnGeo geo,
-                                                             int ntn, int64_t total_groups, int64_t S) {
-  constexpr int M = Wn<KS>::M, PITCH = Wn<KS>::PITCH;
+// 8 waves.  Wave w: output channels 16*(w & 3) .. +15 of the workgroup's 64, points 18*(w >> 2) .. +17 (three rows of the
+// 6 x 6 point grid), both 16-tile blocks: 18 x 2 accumulators of 16x16 = 144 registers, two waves per SIMD.  Waves w and
+// w + 4 sit on the same SIMD and run the two halves of a step in OPPOSITE order -- one multiplies (matrix cores) while the
+// other transforms the next step's input (vector ALUs, LDS).
+template <int KS, int DBG = 0, bool DB = true>
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc X, const float *__restrict__ U,
+                                                                    float *__restrict__ out, int64_t out_bs, int ldo,
+                                                                    int n_valid, int Ho, int Wv, int Wp, int nch,
+                                                                    WnGeo geo, int ntn, int64_t total_groups, int64_t S,
+                                                                    unsigned long long *stamps) {
+  constexpr int M = Wn<KS>::M, PITCH = Wn<KS>::PITCH, NX = kWnXi / 2;
+  // DBG & 16: per-wave phase timing (s_memtime) summed over the steps -> stamps[workgroup][wave][6]
+  unsigned long long tk0 = 0, t_first = 0, t_second = 0, t_bar = 0, t_pro = 0, t_epi = 0;
+  if constexpr (DBG & 16) tk0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *vbuf = reinterpret_cast<float *>(gfla_smem);      // [2][36][32][8]
-  unsigned char *raw = gfla_smem + 2 * kWnVFloats * 4;     // [span][PITCH]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned char *raw = gfla_smem + 2 * kWnVFloats * 4;     // [1 or 2][span][PITCH]
+  const int raw_bytes = (geo.span * PITCH + 15) & ~15;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nb = wave & 3, xh = wave >> 2;
   // workgroup -> (group of tiles, output-channel tile).  Ids x and x + 8 run on the same XCD: the workgroups that
   // share one group's input pixels (different channel tiles) are neighbours in that XCD's queue (shared L2).
   const int64_t x = blockIdx.x;
@@ -197,80 +234,135 @@ __global__ __launch_bounds__(256, 1) void fc_wino_conv_kernel(PackedDesc X, cons
   const int p0 = M * ty_first * Wp;                         // first pixel of the staged span
   const int64_t avail = S - p0;                             // pixels of this sample behind p0 (the rest reads as zero)
 
-  // transform item of this thread: (tile, channel of the 8-channel step)
-  const int tl = t >> 3, c8 = t & 7;
+  // transform item of this thread: (tile, channel of the 8-channel step), rows 3*xh .. 3*xh + 2 of the point grid
+  const int tl = (t & 255) >> 3, c8 = t & 7;
   int toff;
   {
     const int tau = min(tile0 + tl, ntiles - 1);
     const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
     toff = ((M * ty * Wp + M * tx) - p0) * PITCH + c8 * 4;
   }
-  const int vpos = tl * 8 + (c8 & 3) * 2 + (c8 >> 2);       // float offset inside V[point]
+  // float offset of V[first point][16-tile block][channel pair kq >> 1][tile][kq & 1][k step]: the A fragments of a
+  // half-wave (kq = 0, 1 x 16 tiles, 8 bytes each) are then 256 contiguous bytes -- no bank conflicts on the b64 reads
+  const int vpos = xh * NX * kWnTiles * 8 + (tl >> 4) * 128 + (((c8 & 3) >> 1) * 16 + (tl & 15)) * 4 + (c8 & 1) * 2 + (c8 >> 2);
 
-  const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)p0 * X.pix_stride;
-  const int npieces = geo.span * 4;
+  const unsigned char *xg = X.base + b * X.batch_stride + (int64_t)p0 * X.pix_stride;  // workgroup-uniform
 
-  f32x4v acc[kWnXi][2];
+  f32x4v acc[NX][2];
 #pragma unroll
-  for (int q = 0; q < kWnXi; ++q)
+  for (int q = 0; q < NX; ++q)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) acc[q][mb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  // raw span of one chunk: pieces t, t + 256, ... ; the first kWnPF go through registers (prefetched a step ahead)
+  // raw span of one chunk: 16-byte pieces t, t + 512, ... go global -> registers -> LDS (LDS-DMA was measured and dropped:
+  // with a DMA in flight hipcc turns the counted vmcnt waits of the B-fragment stream into vmcnt(0)).  Addresses = a
+  // uniform base + a 32-bit per-lane offset; pixels behind the end of the sample read its last pixel and are stored as
+  // zeros.  Spans beyond kWnPF pieces per thread are loaded at the commit (large maps only).
+  const int npieces = geo.span * 4;
   u32x4v pf[kWnPF];
-  auto piece_src = [&](int q, int cc) -> const unsigned char * {
+  auto piece_off = [&](int q) -> unsigned {
     const int pix = q >> 2;
-    return xg + (int64_t)cc * X.chunk_stride + (int64_t)min((int64_t)pix, avail - 1) * X.pix_stride + (q & 3) * 16;
+    return (unsigned)min((int64_t)pix, avail - 1) * (unsigned)X.pix_stride + (unsigned)(q & 3) * 16u;
   };
-  auto piece_store = [&](int q, u32x4v v) {
+  auto piece_store = [&](int q, u32x4v v, int cc) {
     const int pix = q >> 2;
     if (pix >= avail) v = u32x4v{0u, 0u, 0u, 0u};
-    uint2 *d = reinterpret_cast<uint2 *>(raw + pix * PITCH + (q & 3) * 16);
+    uint2 *d = reinterpret_cast<uint2 *>(raw + (DB ? (cc & 1) * raw_bytes : 0) + pix * PITCH + (q & 3) * 16);
     d[0] = make_uint2(v[0], v[1]);
     d[1] = make_uint2(v[2], v[3]);
   };
   auto prefetch = [&](int cc) {
+    const unsigned char *base = xg + (int64_t)cc * X.chunk_stride;
 #pragma unroll
-    for (int i = 0; i < kWnPF; ++i) {
-      const int q = min(t + 256 * i, npieces - 1);
-      pf[i] = *reinterpret_cast<const u32x4v *>(piece_src(q, cc));
-    }
+    for (int i = 0; i < kWnPF; ++i) pf[i] = *reinterpret_cast<const u32x4v *>(base + piece_off(min(t + kWnThreads * i, npieces - 1)));
   };
   auto commit = [&](int cc) {
 #pragma unroll
     for (int i = 0; i < kWnPF; ++i) {
-      const int q = t + 256 * i;
-      if (q < npieces) piece_store(q, pf[i]);
+      const int q = t + kWnThreads * i;
+      if (q < npieces) piece_store(q, pf[i], cc);
     }
-    for (int q = t + 256 * kWnPF; q < npieces; q += 256)   // spans beyond the register budget: loaded here
-      piece_store(q, *reinterpret_cast<const u32x4v *>(piece_src(q, cc)));
+    const unsigned char *base = xg + (int64_t)cc * X.chunk_stride;
+    for (int q = t + kWnThreads * kWnPF; q < npieces; q += kWnThreads)
+      piece_store(q, *reinterpret_cast<const u32x4v *>(base + piece_off(q)), cc);
   };
 
-  // this lane's B fragments of the current step: U[ntile][cc][half][point][wave][lane][2]
-  const float2 *ub = reinterpret_cast<const float2 *>(U) + ((int64_t)ntile * nch * 2 * kWnXi * 4 + wave) * 64 + lane;
-  float2 bf[kWnXi];
-  auto load_b = [&](int step, int q) { return ub[((int64_t)step * kWnXi + q) * 4 * 64]; };
+  // this lane's B fragments of the current step: U[ntile][cc][half][point][nb][lane][2]
+  // (the wave's base offset goes through readfirstlane: a scalar base + one per-lane offset register, no per-load
+  // vector address arithmetic in the MFMA stream)
+  const unsigned ub_wave = __builtin_amdgcn_readfirstlane((unsigned)((((unsigned)ntile * nch * 2 * kWnXi + xh * NX) * 4 + nb) * 64));
+  const float2 *ub = reinterpret_cast<const float2 *>(U) + ub_wave;
+  float2 bf[NX];
+  auto load_b = [&](int step, int q) { return (ub + ((unsigned)step * kWnXi + q) * 4 * 64)[lane]; };
 
-  // transform of one step: raw[(tile pixel + i*Wp + j)][channel] -> V[buf][point][tile][channel]
-  auto transform = [&](int step, int buf) {
-    const unsigned char *src = raw + toff + (step & 1) * 32;
-    float *dst = vbuf + buf * kWnVFloats + vpos;
-    float tm[6][6];
+  const int arow = ((lane >> 5) * 16 + (lane & 15)) * 4 + ((lane >> 4) & 1) * 2;  // this lane's A fragment inside V[point][block]
+
+  // ---- the two halves of a step ---------------------------------------------------------------------------------------
+  // f32-input MFMAs execute on the SIMD's f32 ALUs (157 TFLOP/s = the vector rate): vector instructions are NOT hidden
+  // behind them, they add (measured: every ablation of this kernel is additive).  So the instruction streams are kept
+  // lean, and the two waves of a SIMD run the two halves in opposite order so that the LDS / global latencies of one sit
+  // under the arithmetic of the other.
+  // transform of step `step`: raw[(tile pixel + i*Wp + j)][channel] -> V[step & 1][point rows 3*HALF..][tile][channel]
+  // (only the three rows this wave group owns: 18 live values, half the column-pass arithmetic)
+  auto transform = [&](auto half_tag, int step) {
+    constexpr int HALF = decltype(half_tag)::value;
+    const unsigned char *src = raw + (DB ? ((step >> 1) & 1) * raw_bytes : 0) + toff + (step & 1) * 32;
+    float *dst = vbuf + (step & 1) * kWnVFloats + vpos;
+    __builtin_amdgcn_s_setprio(3);  // the short phase goes first whenever both waves of the SIMD can issue
+    float tm[3][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      float d[6], o[6];
+      float d[6], o[3];
 #pragma unroll
       for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float *>(src + (i * Wp + j) * PITCH);
-      wn_bt(d, o);
+      wn_bt3<HALF>(d, o);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) tm[a][j] = o[a];
+      for (int r = 0; r < 3; ++r) tm[r][j] = o[r];
     }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int r = 0; r < 3; ++r) {
       float o[6];
-      wn_bt(tm[a], o);
+      wn_bt(tm[r], o);
 #pragma unroll
-      for (int e = 0; e < 6; ++e) dst[(a * 6 + e) * kWnTiles * 8] = o[e];
+      for (int e = 0; e < 6; ++e) dst[(r * 6 + e) * kWnTiles * 8] = o[e];
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // the wave's 72 MFMAs of step s: 18 points x 2 tile blocks x 2 k steps, taken in 9 pairs of points -- eight MFMAs on
+  // four accumulators, the two MFMAs of an accumulator four issue slots apart (a 16x16x4 f32 MFMA has a 40-cycle
+  // dependent latency against a 32-cycle issue).  A fragments run one pair ahead of their MFMAs; the sched_barriers keep
+  // hipcc from sinking the reads next to their use, where every point would expose a full LDS round trip.
+  auto multiply = [&](int s, int sn) {
+    const float *va = vbuf + (s & 1) * kWnVFloats + xh * NX * kWnTiles * 8 + arow;
+    float2 ra[2][2][2];  // [pair parity][point of the pair][tile block]
+    auto read_pair = [&](int q, int slot) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ra[slot][u][0] = *reinterpret_cast<const float2 *>(va + (q + u) * kWnTiles * 8);
+        ra[slot][u][1] = *reinterpret_cast<const float2 *>(va + (q + u) * kWnTiles * 8 + 16 * 8);
+      }
+    };
+    read_pair(0, 0);
+#pragma unroll
+    for (int q = 0; q < NX; q += 2) {
+      const int slot = (q >> 1) & 1;
+      if (q + 2 < NX) read_pair(q + 2, slot ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float2 b0 = bf[q], b1 = bf[q + 1];
+      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].x, b0.x, acc[q][0], 0, 0, 0);
+      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].x, b0.x, acc[q][1], 0, 0, 0);
+      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].x, b1.x, acc[q + 1][0], 0, 0, 0);
+      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].x, b1.x, acc[q + 1][1], 0, 0, 0);
+      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].y, b0.y, acc[q][0], 0, 0, 0);
+      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].y, b0.y, acc[q][1], 0, 0, 0);
+      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].y, b1.y, acc[q + 1][0], 0, 0, 0);
+      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].y, b1.y, acc[q + 1][1], 0, 0, 0);
+      if constexpr (!(DBG & 4)) {  // the registers are free again: next step's slices, a whole step ahead of their use
+        bf[q] = load_b(sn, q);
+        bf[q + 1] = load_b(sn, q + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -278,71 +370,125 @@ __global__ __launch_bounds__(256, 1) void fc_wino_conv_kernel(PackedDesc X, cons
   prefetch(0);
   commit(0);
 #pragma unroll
-  for (int q = 0; q < kWnXi; ++q) bf[q] = load_b(0, q);
+  for (int q = 0; q < NX; ++q) bf[q] = load_b(0, q);
   __syncthreads();
-  transform(0, 0);
+  if (xh == 0) transform(Half0{}, 0);
+  else transform(Half1{}, 0);
   __syncthreads();
 
-  const int arow = (lane & 15) * 8 + (lane >> 4) * 2;  // float offset of this lane's A fragment inside V[point][block]
+  if constexpr (DBG & 16) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_pro = n - tk0; tk0 = n; }
   for (int s = 0; s < nsteps; ++s) {
     const int cc = s >> 1;
-    const bool stage_next = !(s & 1) && cc + 1 < nch;
-    if (stage_next) prefetch(cc + 1);
-    const float *va = vbuf + (s & 1) * kWnVFloats + arow;
     const int sn = min(s + 1, nsteps - 1);
-#pragma unroll
-    for (int q = 0; q < kWnXi; ++q) {
-      const float2 a0 = *reinterpret_cast<const float2 *>(va + q * kWnTiles * 8);
-      const float2 a1 = *reinterpret_cast<const float2 *>(va + q * kWnTiles * 8 + 16 * 8);
-      const float2 bq = bf[q];
-      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq.x, acc[q][0], 0, 0, 0);
-      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bq.x, acc[q][1], 0, 0, 0);
-      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq.y, acc[q][0], 0, 0, 0);
-      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bq.y, acc[q][1], 0, 0, 0);
-      bf[q] = load_b(sn, q);  // the register is free again: next step's slice, one whole step ahead of its use
+    constexpr bool kS = !(DBG & 8);
+    auto stamp = [&](unsigned long long &slot) {
+      if constexpr (DBG & 16) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long n = __builtin_amdgcn_s_memtime();
+        slot += n - tk0;
+        tk0 = n;
+      }
+    };
+    // raw staging: the next chunk is requested and written inside the even step, around the transform (its registers are
+    // live across the transform only; the loads have its duration to land).  Two raw buffers: no extra barrier.
+    const bool stage_next = !(s & 1) && cc + 1 < nch;
+    constexpr bool kT = !(DBG & 1), kM = !(DBG & 2);
+    // (the transform of the step after the last one reads a stale raw buffer into the unused V buffer: harmless)
+    if (xh == 0) {
+      if constexpr (kM) multiply(s, sn);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(t_first);
+      if constexpr (kS) if (stage_next) prefetch(cc + 1);
+      if constexpr (kT) transform(Half0{}, s + 1);
+      if constexpr (kS && DB) if (stage_next) commit(cc + 1);
+      stamp(t_second);
+    } else {
+      if constexpr (kS) if (stage_next) prefetch(cc + 1);
+      if constexpr (kT) transform(Half1{}, s + 1);
+      if constexpr (kS && DB) if (stage_next) commit(cc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(t_first);
+      if constexpr (kM) multiply(s, sn);
+      stamp(t_second);
     }
-    if (s + 1 < nsteps) transform(s + 1, (s + 1) & 1);
     __syncthreads();
-    if (stage_next) {
-      commit(cc + 1);
-      __syncthreads();
+    if constexpr (kS && !DB) {
+      if (stage_next) {  // single raw buffer: written between two barriers (large maps only)
+        commit(cc + 1);
+        __syncthreads();
+      }
     }
+    stamp(t_bar);
   }
 
-  // epilogue: Y = A^T M A.  C/D layout of the 16x16 MFMA: column (channel) = lane & 15, row (tile) = 4*(lane >> 4) + r
-  const int col = ntile * kWnN + wave * 16 + (lane & 15);
+  // epilogue: Y = A^T M A = sum over the point rows a of A^T[:, a] (x) (A^T M[a, :]).  A wave holds three of the six rows:
+  // it reduces them to an m x m partial per (tile, channel); wave pairs (w, w + 4) swap partials through LDS -- wave w
+  // finishes tile block 0, wave w + 4 block 1.  C/D layout of the 16x16 MFMA: column (channel) = lane & 15,
+  // row (tile) = 4*(lane >> 4) + r.
+  float *xch = reinterpret_cast<float *>(gfla_smem);  // [mb][nb][lane][4 r][m*m], written by the wave that does NOT own mb
+  const int col = ntile * kWnN + nb * 16 + (lane & 15);
   float *ob = out + b * out_bs + col;
+  auto finish = [&](auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;   // this wave's point rows 3*HALF.., and the tile block it finishes
+    float part[2][4][M * M];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float qv[3][M];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float v[6], y[M];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) v[e] = acc[a * 6 + e][mb][r];
+          wn_at<M>(v, y);
+#pragma unroll
+          for (int j = 0; j < M; ++j) qv[a][j] = y[j];
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          float v[6], y[M];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) v[a] = (a >= 3 * HALF && a < 3 * HALF + 3) ? qv[a - 3 * HALF][j] : 0.f;
+          wn_at<M>(v, y);
+#pragma unroll
+          for (int i = 0; i < M; ++i) part[mb][r][i * M + j] = y[i];
+        }
+      }
+    __syncthreads();  // the main loop's LDS is dead
+    {
+      float *dst = xch + (((1 - HALF) * 4 + nb) * 64 + lane) * 4 * M * M;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < M * M; ++e) dst[r * M * M + e] = part[1 - HALF][r][e];
+    }
+    __syncthreads();
+    const float *srcp = xch + ((HALF * 4 + nb) * 64 + lane) * 4 * M * M;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tau = tile0 + mb * 16 + 4 * (lane >> 4) + r;
-      float qv[6][M];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        float v[6], y[M];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) v[e] = acc[a * 6 + e][mb][r];
-        wn_at<M>(v, y);
-#pragma unroll
-        for (int j = 0; j < M; ++j) qv[a][j] = y[j];
-      }
+      const int tau = tile0 + HALF * 16 + 4 * (lane >> 4) + r;
       if (tau >= ntiles || col >= n_valid) continue;
       const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        float v[6], y[M];
+      for (int i = 0; i < M; ++i) {
+        const int yo = M * ty + i;
+        if (yo >= Ho) continue;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) v[a] = qv[a][j];
-        wn_at<M>(v, y);
-        const int xo = M * tx + j;
-        if (xo >= Wv) continue;
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-          const int yo = M * ty + i;
-          if (yo < Ho) ob[(int64_t)(yo * Wv + xo) * ldo] = y[i];
+        for (int j = 0; j < M; ++j) {
+          const int xo = M * tx + j;
+          if (xo < Wv) ob[(int64_t)(yo * Wv + xo) * ldo] = part[HALF][r][i * M + j] + srcp[r * M * M + i * M + j];
         }
       }
+    }
+  };
+  if (xh == 0) finish(Half0{});
+  else finish(Half1{});
+  if constexpr (DBG & 16) {
+    t_epi = __builtin_amdgcn_s_memtime() - tk0;
+    if (stamps && lane == 0) {
+      unsigned long long *o = stamps + ((int64_t)blockIdx.x * 8 + wave) * 6;
+      o[0] = t_pro, o[1] = t_first, o[2] = t_second, o[3] = t_bar, o[4] = t_epi, o[5] = (unsigned long long)xh;
     }
   }
 }
@@ -351,31 +497,60 @@ bool fc_wino_fits(int M, int Wv, int Wp, int k) {
   if (k != 3 && k != 5) return false;
   if (Wv <= 0 || Wv > Wp || M <= 0 || M % Wv) return false;
   const WnGeo g = k == 5 ? wn_geometry<5>(M, Wv, Wp) : wn_geometry<3>(M, Wv, Wp);
-  const unsigned lds = k == 5 ? wn_lds_bytes<5>(g) : wn_lds_bytes<3>(g);
-  return lds <= 160 * 1024;
+  const unsigned lds = k == 5 ? wn_lds_bytes<5>(g, false) : wn_lds_bytes<3>(g, false);
+  return lds <= kWnLdsLimit;
 }
 
 // out[b][r][n] = sum_{chunk, tap, c} X[b][chunk][pix(r) + tap][c] * w[...]  -- the contract of fc_conv (fc_conv_impl.h),
 // with the weights given as the transformed U of fc_wino_pack_weights.  S = pixels per sample X may be read for.
+static unsigned long long *g_wino_stamps = nullptr;  // timing probe buffer (gfla_fc_wino_debug_buffer; tools only)
+
 int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
                  int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream) {
   if (B <= 0) return GFLA_OK;
+  unsigned long long *stamps = g_wino_stamps;
   if (!fc_wino_fits(M, Wv, Wp, k)) return GFLA_ERR_UNSUPPORTED;
   const int ntn = (int)ceil_div(n_valid, kWnN);
+#define GFLA_WINO_LAUNCH(K_, D_, DB_)                                                                                   \
+  {                                                                                                                    \
+    auto kern = fc_wino_conv_kernel<K_, D_, DB_>;                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    kern<<<dim3((unsigned)wgs), kWnThreads, lds, stream>>>(X, U, out, out_bs, ldo, n_valid, M / Wv, Wv, Wp, nch, g, ntn, groups, S, stamps); \
+  }
 #define GFLA_WINO(K_)                                                                                                  \
   {                                                                                                                    \
     const WnGeo g = wn_geometry<K_>(M, Wv, Wp);                                                                        \
-    const unsigned lds = wn_lds_bytes<K_>(g);                                                                          \
+    const bool db = wn_lds_bytes<K_>(g, true) <= kWnLdsLimit && tuning(21) != 1;                                       \
+    const unsigned lds = wn_lds_bytes<K_>(g, db);                                                                      \
     const int64_t groups = B * g.ngroups;                                                                              \
     const int64_t wgs = ceil_div(groups, 8) * 8 * ntn;                                                                 \
     if (wgs > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;                                                               \
-    auto kern = fc_wino_conv_kernel<K_>;                                                                               \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    kern<<<dim3((unsigned)wgs), 256, lds, stream>>>(X, U, out, out_bs, ldo, n_valid, M / Wv, Wv, Wp, nch, g, ntn, groups, S); \
+    if (!db) GFLA_WINO_LAUNCH(K_, 0, false)                                                                            \
+    else switch (K_ == 5 ? tuning(20) : 0) { /* timing ablations of the k = 5 kernel (results are garbage) */         \
+      case 1: GFLA_WINO_LAUNCH(K_, 1, true) break;                                                                     \
+      case 2: GFLA_WINO_LAUNCH(K_, 2, true) break;                                                                     \
+      case 4: GFLA_WINO_LAUNCH(K_, 4, true) break;                                                                     \
+      case 8: GFLA_WINO_LAUNCH(K_, 8, true) break;                                                                     \
+      case 3: GFLA_WINO_LAUNCH(K_, 3, true) break;                                                                     \
+      case 16: GFLA_WINO_LAUNCH(K_, 16, true) break;                                                                   \
+      case 5: GFLA_WINO_LAUNCH(K_, 5, true) break;                                                                     \
+      case 13: GFLA_WINO_LAUNCH(K_, 13, true) break;                                                                   \
+      default: GFLA_WINO_LAUNCH(K_, 0, true) break;                                                                    \
+    }                                                                                                                  \
   }
   if (k == 5) GFLA_WINO(5) else GFLA_WINO(3)
+#undef GFLA_WINO_LAUNCH
 #undef GFLA_WINO
   return launch_status();
 }
 
 }  // namespace gfla
+
+extern "C" {
+/* tools only: device buffer (workgroups x 8 waves x 6 uint64) that the DBG=16 instantiation of the Winograd kernel (tuning
+ * key 20 = 16) fills with per-wave phase times in shader cycles; NULL switches it off */
+int gfla_fc_wino_debug_buffer(void *buffer) {
+  gfla::g_wino_stamps = static_cast<unsigned long long *>(buffer);
+  return GFLA_OK;
+}
+}

@@ -390,6 +390,10 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
                        int kernel_size, int mode, gfla_stream_t stream);
 int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out,
                      gfla_stream_t stream);
+/* tools only: a device buffer (workgroups x 8 waves x 6 uint64) that the timing instantiation of the Winograd
+ * convolution kernel (arithmetic mode 4, tuning key 20 = 16) fills with per-wave phase times in shader cycles;
+ * NULL switches it off.                                                                                          */
+int gfla_fc_wino_debug_buffer(void *buffer);
 
 /* ---- gradient of the replicate padding in front of the target half of ExtractorAttn's first FC layer ---
  * block_target = extractor(target, zero flow) (base_function.py:806) is the replicate-padded unfold of
