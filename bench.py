@@ -538,7 +538,7 @@ def fc_kernel_probes(hp, iters=10):
                 us = e0.elapsed_time(e1) / iters * 1e3
                 tf = flops / (us * 1e-6) / 1e12
                 if mode == 4:
-                    kern = "fc_wino_conv_kernel" if which < 4 else "fc_wgrad_f32_kernel"
+                    kern = "fc_wino_conv_kernel" if which < 4 else "fc_wino_wgrad_kernel"
                 else:
                     kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
                 rows.append({"kernel": "%s<mode %d, k %d>: %s" % (kern, mode, k, nm), "dims": [B, C, H, W, k],

@@ -76,7 +76,13 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
   L.red_tmp = take((int64_t)kFcRedTmpFloats * 4);
   // exact-f32 weight gradient: per-split partial sums (the two halves run one after the other and share it)
   const int64_t sp_s = fc_wgrad_splits(B, L.hs.M, L.cpad), sp_t = fc_wgrad_splits(B, L.ht.M, L.cpad);
-  L.dwp = take(mode == 0 ? (sp_s > sp_t ? sp_s : sp_t) * L.KK * L.cpad * kFcHidden * 4 : 0);
+  int64_t dwp = mode == 0 ? (sp_s > sp_t ? sp_s : sp_t) * L.KK * L.cpad * kFcHidden * 4 : 0;
+  if (wino) {  // Winograd-domain partials: 36 points per (c, n)
+    const int64_t ws_s = fc_wino_wgrad_splits(B, L.hs.Ho, L.hs.Wo, L.cpad, k), ws_t = fc_wino_wgrad_splits(B, L.ht.Ho, L.ht.Wo, L.cpad, k);
+    const int64_t w = (ws_s > ws_t ? ws_s : ws_t) * 36 * L.cpad * kFcHidden * 4;
+    if (w > dwp) dwp = w;
+  }
+  L.dwp = take(dwp);
   L.bwd_total = o;
   return L;
 }
@@ -193,7 +199,12 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
-    if (mode == 0) {
+    if (wino && tuning(19) != 1) {  // (tuning key 19 = 1: the direct weight-gradient kernel under mode 4, for A/B timing)
+      float *part = reinterpret_cast<float *>(sc + L.dwp);
+      GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+      GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
+                                    stream));
+    } else if (mode == 0) {
       float *part = reinterpret_cast<float *>(sc + L.dwp);
       GFLA_TRY(fc_wgrad_f32(X, Z, g.lead, part, L.cpad, B, g.M, g.Wp, k, stream));
       GFLA_TRY(fc_wgrad_reduce(part, fc_wgrad_splits(B, g.M, L.cpad), g_w0, C, source ? C : 0, L.cpad, k, stream));
@@ -391,7 +402,10 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
       return fc_wino_conv(Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
                           reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, B,
                           kFcHidden / kFcChunk, g.Md, g.Wp, g.Wp, g.Sz, k, stream);
-    return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
+    if (tuning(19) == 1)
+      return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
+    return fc_wino_wgrad(X4, reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz * kFcHidden, g.lead,
+                         reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream);
   }
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const uint32_t *a_x = mode ? amax + (source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;

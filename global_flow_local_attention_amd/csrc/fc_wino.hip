@@ -544,6 +544,375 @@ int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs
   return launch_status();
 }
 
+// =====================================================================================================================
+// Weight gradient in the Winograd domain (arithmetic mode 4).
+//
+//   dU[point][c][n] = sum over tiles  V[tile][c][point] * Zh[tile][n][point],   V = B^T d B (the forward's input transform),
+//   Zh = A dY A^T (the m x m output-gradient tile lifted to the 6 x 6 points),   dW[n][c] = G^T dU[.][c][n] G  (k x k),
+// i.e. the adjoint of Y = A^T [U .* V] A: 36 multiplies per (tile, c, n) instead of 100 (k = 5) / 144 (k = 3).
+//
+// Workgroup (8 waves) = one 16-channel chunk of the input x ALL 36 points x the 128 hidden channels (wave w: columns
+// 16w..16w+15: 36 accumulators of 16x16) x a contiguous range of "units" (= up to SEG tiles of ONE tile row of one sample;
+// equal ranges per split, one round of workgroups).  The reduction runs over tiles, four per v_mfma_f32_16x16x4_f32:
+//   A = V[point][tile][c] from LDS, produced 16 tiles at a time by the conv kernel's transform (a thread = one (tile,
+//       channel) item, three of the six point rows; two V buffers), read back as one ds_read_b128 per point and step;
+//   B = Zh: every lane lifts its own (tile, hidden channel) dY values -- 4 (k = 5) or 16 (k = 3) floats straight from the
+//       gradient map in global memory, one k step ahead -- to the 36 points IN REGISTERS (about 32 vector ops per k step);
+//   the two halves of a step (multiply / transform the next 16 tiles) run in opposite order on the two waves of a SIMD.
+// Partial sums per split leave as plain coalesced stores; fc_wino_wgrad_reduce adds the splits, applies G^T . G and writes
+// conv0.weight.grad's layout.
+constexpr int kWwPitch = 72;   // LDS bytes per raw pixel: 16 tiles' stride (8 / 16 pixels) lands on the other half of the banks
+
+template <int KS>
+struct Ww {
+  static constexpr int M = KS == 5 ? 2 : 4;
+  static constexpr int SEG = KS == 5 ? 32 : 16;          // tiles per unit
+  static constexpr int L = M * SEG + 6 - M;              // raw pixels per row of a unit
+  static constexpr int RAW = ((6 * L * kWwPitch + 15) & ~15);
+};
+constexpr int kWwVFloats = kWnXi * 4 * 16 * 4;           // one V buffer: [point][tile & 3][channel][tile >> 2]
+
+struct WwGeo {
+  int TH, TW, nseg;
+};
+
+// A dY A^T for one (tile, channel): dy[i][j] (m x m) -> zh[36]
+template <int M>
+__device__ __forceinline__ void ww_lift(const float (&dy)[M][M], float (&zh)[kWnXi]) {
+  float t[6][M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    if constexpr (M == 2) {
+      const float a = dy[0][j], b = dy[1][j];
+      t[0][j] = a, t[1][j] = a + b, t[2][j] = a - b, t[3][j] = a + 2.f * b, t[4][j] = a - 0.5f * b, t[5][j] = b;
+    } else {
+      const float a = dy[0][j], b = dy[1][j], c = dy[2][j], d = dy[3][j];
+      t[0][j] = a;
+      t[1][j] = a + b + c + d;
+      t[2][j] = a - b + c - d;
+      t[3][j] = a + 2.f * b + 4.f * c + 8.f * d;
+      t[4][j] = a - 0.5f * b + 0.25f * c - 0.125f * d;
+      t[5][j] = d;
+    }
+  }
+#pragma unroll
+  for (int a6 = 0; a6 < 6; ++a6) {
+    if constexpr (M == 2) {
+      const float a = t[a6][0], b = t[a6][1];
+      zh[a6 * 6 + 0] = a, zh[a6 * 6 + 1] = a + b, zh[a6 * 6 + 2] = a - b, zh[a6 * 6 + 3] = a + 2.f * b;
+      zh[a6 * 6 + 4] = a - 0.5f * b, zh[a6 * 6 + 5] = b;
+    } else {
+      const float a = t[a6][0], b = t[a6][1], c = t[a6][2], d = t[a6][3];
+      zh[a6 * 6 + 0] = a;
+      zh[a6 * 6 + 1] = a + b + c + d;
+      zh[a6 * 6 + 2] = a - b + c - d;
+      zh[a6 * 6 + 3] = a + 2.f * b + 4.f * c + 8.f * d;
+      zh[a6 * 6 + 4] = a - 0.5f * b + 0.25f * c - 0.125f * d;
+      zh[a6 * 6 + 5] = d;
+    }
+  }
+}
+
+struct WwUnit {
+  int64_t b;
+  int ty, tx0, ntx;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc X, const float *__restrict__ Z,
+                                                                     int64_t z_bs, int64_t z_lead,
+                                                                     float *__restrict__ part, int cpad, int Wp,
+                                                                     int Wo, WwGeo geo, int64_t total_units, int nsplit,
+                                                                     int64_t SX) {
+  constexpr int M = Ww<KS>::M, SEG = Ww<KS>::SEG, L = Ww<KS>::L, RAW = Ww<KS>::RAW, PITCH = kWwPitch;
+  constexpr int PF = (6 * L * 4 + kWnThreads - 1) / kWnThreads;  // 16-byte pieces of a unit's raw rows per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  float *vbuf = reinterpret_cast<float *>(gfla_smem);            // [2][kWwVFloats]
+  unsigned char *raw = gfla_smem + 2 * kWwVFloats * 4;           // [2][6][L][PITCH]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xh = wave >> 2;
+  const int cc = blockIdx.x, sp = blockIdx.y;
+  const int64_t u0 = total_units * sp / nsplit, u1 = total_units * (sp + 1) / nsplit;
+  const int per_sample = geo.TH * geo.nseg;
+
+  f32x4v acc[kWnXi];
+#pragma unroll
+  for (int q = 0; q < kWnXi; ++q) acc[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto unit_of = [&](int64_t u) {
+    WwUnit un;
+    un.b = u / per_sample;
+    const int r = (int)(u - un.b * per_sample);
+    un.ty = r / geo.nseg;
+    un.tx0 = (r - un.ty * geo.nseg) * SEG;
+    un.ntx = min(SEG, geo.TW - un.tx0);
+    return un;
+  };
+
+  // raw rows of a unit: piece q -> (row = q / (4 L), pixel, part); global -> registers -> LDS (pitch 72: two b64 stores)
+  u32x4v pf[PF];
+  auto piece_addr = [&](const WwUnit &un, int q, int &ldso) -> const unsigned char * {
+    const int row = q / (4 * L), rem = q - row * (4 * L), px = rem >> 2, prt = rem & 3;
+    ldso = (row * L + px) * PITCH + prt * 16;
+    const int64_t pix = (int64_t)(M * un.ty + row) * Wp + M * un.tx0 + px;
+    return X.base + un.b * X.batch_stride + (int64_t)cc * X.chunk_stride + (pix < SX ? pix : SX - 1) * X.pix_stride + prt * 16;
+  };
+  auto prefetch = [&](const WwUnit &un) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      int ldso;
+      pf[i] = *reinterpret_cast<const u32x4v *>(piece_addr(un, min(t + kWnThreads * i, 6 * L * 4 - 1), ldso));
+    }
+  };
+  auto commit = [&](const WwUnit &un, int buf) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int q = t + kWnThreads * i;
+      if (q < 6 * L * 4) {
+        int ldso;
+        (void)piece_addr(un, q, ldso);
+        uint2 *d = reinterpret_cast<uint2 *>(raw + buf * RAW + ldso);
+        d[0] = make_uint2(pf[i][0], pf[i][1]);
+        d[1] = make_uint2(pf[i][2], pf[i][3]);
+      }
+    }
+  };
+
+  // transform item: tile (wave & 3) + 4 * (lane >> 4) of the step's 16, channel lane & 15, point rows 3*xh..
+  const int tq = wave & 3, tks = lane >> 4, tc = lane & 15;
+  const int tl = tq + 4 * tks;
+  const int vpos = (xh * 18 * 4 + tq) * 16 * 4 + tc * 4 + tks;   // float offset of V[first point][tq][c][ks]
+  auto transform = [&](auto half_tag, const WwUnit &un, int h, int rbuf, int vb) {
+    constexpr int HALF = decltype(half_tag)::value;
+    const int tile = min(h * 16 + tl, un.ntx - 1);
+    const unsigned char *src = raw + rbuf * RAW + (M * tile) * PITCH + tc * 4;
+    float *dst = vbuf + vb * kWwVFloats + vpos;
+    __builtin_amdgcn_s_setprio(3);
+    float tm[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float d[6], o[3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float *>(src + (i * L + j) * PITCH);
+      wn_bt3<HALF>(d, o);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) tm[r][j] = o[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float o[6];
+      wn_bt(tm[r], o);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) dst[(r * 6 + e) * 4 * 16 * 4] = o[e];
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // multiply: the step's k steps (4 tiles each); this lane's B operand = Zh of tile 4*ks + (lane >> 4), channel 16*wave + (lane & 15)
+  const int kq = lane >> 4, n = wave * 16 + (lane & 15);
+  auto load_dy = [&](const WwUnit &un, int h, int ks, float (&dy)[M][M]) {
+    const int tile = h * 16 + 4 * ks + kq;
+    const bool live = tile < un.ntx;
+    const int xo0 = M * (un.tx0 + (live ? tile : 0));
+    const float *zp = Z + un.b * z_bs + (z_lead + (int64_t)(M * un.ty) * Wp + xo0) * kFcHidden + n;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const float v = zp[(int64_t)(i * Wp + j) * kFcHidden];
+        // columns Wo .. Wp-1 and the rows behind Ho are zero in the Z layout, but a partial tile of a 4 x 4 tiling can reach
+        // column Wp = the next row's first output: masked
+        dy[i][j] = (live && (M == 2 || xo0 + j < Wo)) ? v : 0.f;
+      }
+  };
+  auto multiply = [&](const WwUnit &un, int h, int vb) {
+    const int nks = min(4, (un.ntx - h * 16 + 3) >> 2);
+    const float *va = vbuf + vb * kWwVFloats + (kq * 16 + (lane & 15)) * 4;
+    float dy[M][M], dyn[M][M];
+    load_dy(un, h, 0, dy);
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) load_dy(un, h, ks + 1, dyn);
+      float zh[kWnXi];
+      ww_lift<M>(dy, zh);
+#pragma unroll
+      for (int q = 0; q < kWnXi; ++q) {
+        const float a = va[q * 4 * 16 * 4 + ks];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, zh[q], acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) dy[i][j] = dyn[i][j];
+    }
+  };
+
+  if (u0 < u1) {
+    // prologue: raw of the first unit, V of its first step
+    WwUnit cur = unit_of(u0);
+    prefetch(cur);
+    commit(cur, 0);
+    __syncthreads();
+    if (xh == 0) transform(Half0{}, cur, 0, 0, 0);
+    else transform(Half1{}, cur, 0, 0, 0);
+    __syncthreads();
+    int vb = 0, rbuf = 0;
+    for (int64_t u = u0; u < u1; ++u) {
+      const int nh = (cur.ntx + 15) >> 4;
+      const bool has_next = u + 1 < u1;
+      const WwUnit nxt = has_next ? unit_of(u + 1) : cur;
+      for (int h = 0; h < nh; ++h) {
+        const bool last_h = h + 1 == nh;
+        // the transform half of this step prepares the unit's next 16 tiles, or (last step of a two-step unit) the next
+        // unit's first 16 -- whose raw rows were written during the unit's first step
+        const bool t_same = !last_h, t_next = last_h && has_next && nh > 1;
+        const bool stage = h == 0 && has_next;   // the next unit's raw rows: requested / written around the transform
+        if (xh == 0) {
+          multiply(cur, h, vb);
+          __builtin_amdgcn_sched_barrier(0);
+          if (stage) prefetch(nxt);
+          if (t_same) transform(Half0{}, cur, h + 1, rbuf, vb ^ 1);
+          else if (t_next) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if (stage) commit(nxt, rbuf ^ 1);
+        } else {
+          if (stage) prefetch(nxt);
+          if (t_same) transform(Half1{}, cur, h + 1, rbuf, vb ^ 1);
+          else if (t_next) transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if (stage) commit(nxt, rbuf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(cur, h, vb);
+        }
+        __syncthreads();
+        if (last_h && has_next && nh == 1) {
+          // a unit of ONE step: the next unit's raw rows were written during this very step, so its first transform runs
+          // here, between two barriers (k = 3 layers and narrow maps: one exposed transform per unit)
+          if (xh == 0) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          else transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          __syncthreads();
+        }
+        vb ^= 1;
+      }
+      cur = nxt;
+      rbuf ^= 1;
+    }
+  }
+
+  // C/D layout of the 16x16 MFMA: column (hidden channel) = lane & 15, row (input channel) = 4*(lane >> 4) + r
+  float *o = part + (((int64_t)sp * kWnXi) * cpad + cc * kFcChunk) * kFcHidden + wave * 16 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < kWnXi; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[((int64_t)q * cpad + 4 * kq + r) * kFcHidden] = acc[q][r];
+}
+
+// conv0.weight.grad[n][c_off + c][i][j] = (G^T (sum_s part[s][.][c][n]) G)[i][j]
+template <int KS>
+__global__ __launch_bounds__(256) void fc_wino_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit,
+                                                                  float *__restrict__ gw, int C, int c_off, int cpad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (c, n), n fastest: coalesced reads
+  if (idx >= (int64_t)cpad * kFcHidden) return;
+  const int n = (int)(idx & (kFcHidden - 1)), c = (int)(idx >> 7);
+  if (c >= C) return;
+  const int64_t per = (int64_t)kWnXi * cpad * kFcHidden;
+  float du[6][6];
+#pragma unroll
+  for (int q = 0; q < kWnXi; ++q) {
+    float s0 = 0.f, s1 = 0.f;
+    const float *p = part + (int64_t)q * cpad * kFcHidden + idx;
+    int s = 0;
+    for (; s + 2 <= nsplit; s += 2) {
+      s0 += p[(int64_t)s * per];
+      s1 += p[(int64_t)(s + 1) * per];
+    }
+    if (s < nsplit) s0 += p[(int64_t)s * per];
+    du[q / 6][q % 6] = s0 + s1;
+  }
+  // G (6 x k): G[a][i] = p_a^i / f_a for a < 5, G[5][k-1] = 1 (wn_g)
+  const float inv_f[5] = {1.f, -1.f / 3.f, 1.f / 3.f, 1.f / 15.f, -16.f / 15.f};
+  const float pt[5] = {0.f, 1.f, -1.f, 2.f, -0.5f};
+  float G[6][KS];
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    float pw = 1.f;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      G[a][i] = pw * inv_f[a];
+      pw *= pt[a];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KS; ++i) G[5][i] = i == KS - 1 ? 1.f : 0.f;
+  float tmp[KS][6];
+#pragma unroll
+  for (int i = 0; i < KS; ++i)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s += G[a][i] * du[a][e];
+      tmp[i][e] = s;
+    }
+  float *g = gw + ((int64_t)n * 2 * C + c_off + c) * KS * KS;
+#pragma unroll
+  for (int i = 0; i < KS; ++i)
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s += tmp[i][e] * G[e][j];
+      g[i * KS + j] = s;
+    }
+}
+
+static WwGeo ww_geometry(int Ho, int Wo, int k) {
+  const int m = k == 5 ? 2 : 4, seg = k == 5 ? 32 : 16;
+  WwGeo g;
+  g.TH = (Ho + m - 1) / m;
+  g.TW = (Wo + m - 1) / m;
+  g.nseg = (g.TW + seg - 1) / seg;
+  return g;
+}
+
+int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k) {
+  const WwGeo g = ww_geometry(Ho, Wo, k);
+  const int64_t units = B * g.TH * g.nseg;
+  // 8 waves per workgroup, two per SIMD: ONE workgroup per CU; one round of 256 workgroups
+  int64_t s = tuning(12) > 0 ? tuning(12) : kNumCU / (cpad / kFcChunk);
+  if (s < 1) s = 1;
+  return (int)(s > units ? units : s);
+}
+
+// part: fc_wino_wgrad_splits(...) * 36 * cpad * 128 floats.  X: packed f32 records; Z: the f32 (B, Sz, 128) Z-layout map.
+int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
+                  int Wo, int Wp, int64_t SX, int k, hipStream_t stream) {
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  if (X.pix_stride != 64) return GFLA_ERR_UNSUPPORTED;
+  if (B <= 0) return GFLA_OK;
+  const WwGeo g = ww_geometry(Ho, Wo, k);
+  const int nsplit = fc_wino_wgrad_splits(B, Ho, Wo, cpad, k);
+  const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)nsplit);
+#define GFLA_WW(K_)                                                                                                    \
+  {                                                                                                                    \
+    const unsigned lds = (unsigned)(2 * kWwVFloats * 4 + 2 * Ww<K_>::RAW);                                             \
+    auto kern = fc_wino_wgrad_kernel<K_>;                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    kern<<<grid, kWnThreads, lds, stream>>>(X, Z, z_bs, z_lead, part, cpad, Wp, Wo, g, B * g.TH * g.nseg, nsplit, SX);   \
+  }
+  if (k == 5) GFLA_WW(5) else GFLA_WW(3)
+#undef GFLA_WW
+  return launch_status();
+}
+
+int fc_wino_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
+                         hipStream_t stream) {
+  const dim3 grid((unsigned)ceil_div((int64_t)cpad * kFcHidden, 256));
+  if (k == 5)
+    fc_wino_wgrad_reduce_kernel<5><<<grid, 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad);
+  else if (k == 3)
+    fc_wino_wgrad_reduce_kernel<3><<<grid, 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad);
+  else
+    return GFLA_ERR_UNSUPPORTED;
+  return launch_status();
+}
+
 }  // namespace gfla
 
 extern "C" {
