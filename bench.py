@@ -216,7 +216,7 @@ class TrainerPath:
     reducer's hooks over ALL parameters, Adam step.  GAN / style terms stubbed, as configs[3] prescribes.  The stock
     convolutions / InstanceNorms of the network run through torch (MIOpen), like the reference's own."""
 
-    def __init__(self, B, device, seed, fc_mode=0, ngf=64, size=(256, 176)):
+    def __init__(self, B, device, seed, fc_mode=4, ngf=64, size=(256, 176)):
         from global_flow_local_attention_amd.trainer import TrainerShell
         gen = torch.Generator(device=device).manual_seed(seed)
         self.B, self.device = B, device
@@ -536,14 +536,25 @@ def fc_kernel_probes(hp, iters=10):
                 e1.record(stream)
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / iters * 1e3
-                tf = flops / (us * 1e-6) / 1e12
+                row = {"dims": [B, C, H, W, k], "avg_us": round(us, 1)}
                 if mode == 4:
+                    # Winograd domain: the kernel EXECUTES 36 multiplies per (tile, c, n) -- F(2x2,5x5): 2x2 outputs per
+                    # tile, F(4x4,3x3): 4x4.  `TFLOPs` / `frac` are these executed MFMA flops against the f32 peak (what the
+                    # hardware does); `effective_TFLOPs` = the reference formulation's flops / time (what the caller gets).
                     kern = "fc_wino_conv_kernel" if which < 4 else "fc_wino_wgrad_kernel"
+                    m = 2 if k == 5 else 4
+                    ext = {0: k - 1, 1: 0, 2: 2 * (k - 1), 3: k - 1, 4: k - 1, 5: 0}[which]
+                    tiles = B * (-(-(H + ext) // m)) * (-(-(W + ext) // m))
+                    done = 2.0 * 36 * tiles * C * 128
+                    row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "effective_GFLOP": round(flops / 1e9, 2),
+                                "effective_TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 else:
                     kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
-                rows.append({"kernel": "%s<mode %d, k %d>: %s" % (kern, mode, k, nm), "dims": [B, C, H, W, k],
-                             "avg_us": round(us, 1), "alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(tf, 1),
-                             "frac_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+                    row.update({"alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
+                row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
+                row["frac_mfma_f32_peak"] = round(row["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+                rows.append(row)
     return rows
 
 
@@ -667,7 +678,11 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
 
     variants = {}
     if on_gpu and args.fc_impl == "mfma" and not args.no_variants and not custom:
-        for mode, label in ((3, "fc_mode3_f16x3_split"), (2, "fc_mode2_f16x2_split")):
+        notes = {0: "float32, DIRECT convolution kernels (a k-ordered fma chain per output): the same step without the "
+                    "Winograd-domain formulation",
+                 4: "float32, Winograd-domain convolutions and weight gradient (the product default)"}
+        for mode, label in ((0, "fc_mode0_f32_direct"), (4, "fc_mode4_f32_winograd"), (3, "fc_mode3_f16x3_split"),
+                            (2, "fc_mode2_f16x2_split")):
             if mode == args.fc_mode:
                 continue
             hv = make_hotpath(mode)
@@ -677,8 +692,9 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             ev = timed_steps(vstep, n, 2, barrier, world, device)
             variants[label] = {"value": round(args.batch * world * n / ev, 2), "unit": "images/s",
                                "ms_per_step": round(ev / n * 1e3, 3),
-                               "note": "labelled experiment, not the headline: FC operands split into %d f16 terms, f32 "
-                                       "accumulation in the MFMA; the parity tests hold it to the same bars as exact f32" % mode}
+                               "note": notes.get(mode, "labelled experiment, not the headline: FC operands split into %d f16 "
+                                                  "terms, f32 accumulation in the MFMA; the parity tests hold it to the same "
+                                                  "bars as the f32 modes" % mode)}
             del hv
 
     line = {
@@ -718,11 +734,16 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                             "achieved": dom["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
+                            **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
                             "traffic": pmc_traffic_kernel(dom["kernel"]),
                             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                               "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
-                            "flops": "reference formulation (2*B*H*W*C*k*k*128 per half and pass); work the kernel adds on "
-                                     "top (extended / padded domains) is not counted",
+                            "flops": ("Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "
+                                      "(2*36*tiles*C*128; tiles = ceil(rows/m)*ceil(cols/m) of the output domain, m = 2 for "
+                                      "F(2x2,5x5), 4 for F(4x4,3x3)) / time; effective_TFLOPs = the reference formulation's "
+                                      "2*B*H*W*C*k*k*128 / time" if args.fc_mode == 4 else
+                                      "reference formulation (2*B*H*W*C*k*k*128 per half and pass); work the kernel adds on "
+                                      "top (extended / padded domains) is not counted"),
                             "timing": "HIP events around 10 back-to-back launches of the kernel alone "
                                       "(gfla_fc_kernel_f32) on the launch stream"}
     elif rows:
@@ -768,9 +789,10 @@ def parse_args(argv=None):
                          "bf16 features; --batch is then clips per GPU.  trainer_step: one TrainerShell.optimize_parameters step "
                          "of the in-repo generator-shaped network (SURVEY 8f row 4 / BASELINE configs[3] per rank)")
     ap.add_argument("--frames", type=int, default=6, help="face_bf16: frames generated per clip")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4), default=0,
-                    help="arithmetic of the MFMA contraction: 0 exact f32 (default, the headline), 3 / 2 = three / two "
-                         "f16 terms per operand with f32 accumulation (labelled experiments)")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4), default=4,
+                    help="arithmetic of the FC contraction: 4 = float32, Winograd-domain convolutions and weight gradient "
+                         "(the product default and the headline); 0 = float32, direct convolution; 3 / 2 = three / two f16 "
+                         "terms per operand with f32 accumulation (labelled experiments)")
     ap.add_argument("--with-losses", action="store_true",
                     help="replace the bare Resample2d sites by the losses that contain them in training (BASELINE "
                          "config 4): PerceptualCorrectness.calculate_loss on synthetic VGG-shaped features + "

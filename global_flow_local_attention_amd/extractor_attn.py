@@ -292,13 +292,11 @@ def _mfma_mode(self, source, target, flow_field, conv0, act, conv1, k):
     """Arithmetic mode of the MFMA path for the FC layers (fc_mfma.py), or None to use the library path."""
     if getattr(self, "fc_impl", "mfma") != "mfma":
         return None
-    mode = getattr(self, "fc_mode", None)
-    mode = fc_mfma.DEFAULT_MODE if mode is None else int(mode)
     ok = (source.dtype == torch.float32 and target.dtype == torch.float32 and flow_field.dtype == torch.float32
           and _fc_layers_fit(source, target, flow_field, conv0, act, conv1, k))
-    if not ok or mode not in fc_mfma.MODES:
+    if not ok:
         return None
-    return mode if fc_mfma.supported(source.size(1), source.size(2), source.size(3), k, mode) else None
+    return fc_mfma.resolve_mode(source.size(1), source.size(2), source.size(3), k, getattr(self, "fc_mode", None))
 
 
 # bf16 features: the aggregation's backward keeps a (double accumulator + f32 source) plane pair per position in LDS

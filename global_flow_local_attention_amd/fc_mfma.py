@@ -4,8 +4,12 @@
 logits (B, k*k, H, W) -- what the reference computes as
     fully_connect_layer[:3](cat(extractor(target, 0), extractor(source, flow)))
 -- through gfla_fc_forward_f32 / gfla_fc_backward_f32 (csrc/fc_block.hip): no block tensor, no library GEMM or
-convolution.  `mode` picks the arithmetic of the contraction (include/gfla_hip.h): 0 exact-f32 MFMA, 3 three-term
-f16 split (f32-grade), 2 two-term f16 split.  The default is 0.
+convolution.  `mode` picks the arithmetic of the contraction (include/gfla_hip.h):
+  4  float32 throughout, Winograd-domain convolutions and weight gradient (csrc/fc_wino.hip: F(2x2,5x5) / F(4x4,3x3),
+     2.78x / 4x fewer multiplies) -- THE DEFAULT; errors against float64 at the bench shapes 1e-6 .. 9e-6, held to the same
+     test bars as mode 0;
+  0  float32, direct convolution: a k-ordered fma chain per output (what mode 4 falls back to for maps its tiles do not fit);
+  3 / 2  operands split into three / two f16 terms, f32 accumulation (labelled experiments);  1  one f16 term (bf16 path).
 """
 import ctypes
 
@@ -15,13 +19,30 @@ from torch.autograd import Function
 from . import _lib
 
 MODES = (0, 1, 2, 3, 4)
-# exact f32 (v_mfma_f32_32x32x2_f32): the reference computes this layer in fp32 (base_function.py:799-810), so this is
-# what a module without an explicit `fc_mode` gets; 2 / 3 are labelled experiments, 1 belongs to the bf16-feature path
-DEFAULT_MODE = 0
+# float32 arithmetic is what the reference computes this layer in (base_function.py:799-810): a module without an explicit
+# `fc_mode` gets the float32 Winograd-domain kernels (4), or the float32 direct kernels (0) where 4 does not take the shape;
+# 2 / 3 are labelled experiments, 1 belongs to the bf16-feature path
+DEFAULT_MODE = 4
+MODE_NAMES = {0: "f32 MFMA, direct convolution", 1: "one f16 term per operand (exact for bf16 values), f32 accumulate",
+              2: "two f16 terms per operand, f32 accumulate", 3: "three f16 terms per operand, f32 accumulate",
+              4: "f32 MFMA, Winograd-domain convolutions F(2x2,5x5) / F(4x4,3x3)"}
 
 
 def supported(C, H, W, k, mode=DEFAULT_MODE):
     return bool(_lib.lib().gfla_fc_supported(int(C), int(H), int(W), int(k), int(mode)))
+
+
+def resolve_mode(C, H, W, k, mode=None):
+    """The arithmetic mode a call will run in: `mode` (DEFAULT_MODE when None) if the kernels take the shape; the float32
+    direct kernels (0) when the float32 Winograd kernels (4) do not; None when nothing does."""
+    mode = DEFAULT_MODE if mode is None else int(mode)
+    if mode not in MODES:
+        return None
+    if supported(C, H, W, k, mode):
+        return mode
+    if mode == 4 and supported(C, H, W, k, 0):
+        return 0
+    return None
 
 
 def workspace_bytes(B, C, H, W, k, mode, which):

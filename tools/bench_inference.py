@@ -19,7 +19,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import global_flow_local_attention_amd as gfla  # noqa: E402
-from global_flow_local_attention_amd import dist as gdist  # noqa: E402
+from global_flow_local_attention_amd import dist as gdist, fc_mfma  # noqa: E402
 
 
 def timed(fn, iters):
@@ -48,9 +48,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (sharded over the ranks)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3), default=0,
-                    help="arithmetic of the FC contraction: 0 exact f32 MFMA (the product default, the reference's "
-                         "precision); 3 / 2 = f16-split operands (labelled experiments)")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 2, 3, 4), default=4,
+                    help="arithmetic of the FC contraction: 4 float32 Winograd-domain (the product default), 0 float32 "
+                         "direct; 3 / 2 = f16-split operands (labelled experiments)")
     a = ap.parse_args()
     local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
@@ -97,7 +97,7 @@ def main():
             print(json.dumps(row), flush=True)
     if rank == 0:
         summary = {"fc_mode": a.fc_mode,
-                   "fc_arithmetic": "exact f32 MFMA" if a.fc_mode == 0 else "%d f16 terms per operand, f32 accumulate" % a.fc_mode,
+                   "fc_arithmetic": fc_mfma.MODE_NAMES[a.fc_mode],
                    "both layers": {k: round(v, 1) for k, v in total.items()}, "n_gpus": world,
                    "images_per_s_fused": round(a.batch / (total["fused_us"] * 1e-6), 1),
                    "images_per_s_fused_hipgraph": round(a.batch / (total["fused_hipgraph_us"] * 1e-6), 1)}
