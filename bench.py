@@ -623,6 +623,70 @@ def cpu_baseline(budget_s=20.0):
                       "kernels with OpenMP + torch CPU convolutions), %.1f s" % (n, b, dt)}
 
 
+def extra_legs(args, device):
+    """The other BASELINE configs, timed by the SAME process right after the headline (rank 0, N = 1): compact results under
+    `legs`, each a few steps bracketed by synchronize.  The headline's contract (metric, value, steps) is untouched."""
+    legs = {}
+
+    def timeit(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    # configs[2]: ExtractorAttn forward only (eval, no_grad) at the attention-layer shapes of a 256x256 image, batch 32
+    from global_flow_local_attention_amd import fc_mfma
+    for mode in (4, 0):
+        mods, ins = [], []
+        gen = torch.Generator(device=device).manual_seed(7)
+        torch.manual_seed(1234)
+        for (_, C, H, W, k) in FACE_LAYERS:
+            m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(device).eval()
+            m.fc_mode = mode
+            mods.append(m)
+            ins.append((torch.randn(32, C, H, W, device=device, generator=gen), torch.randn(32, C, H, W, device=device, generator=gen),
+                        smooth_flow(32, H, W, device, gen)))
+
+        def fwd():
+            with torch.no_grad():
+                for m, a in zip(mods, ins):
+                    m(*a)
+        dt = timeit(fwd, 10, 3)
+        flops = sum(2.0 * 32 * H * W * 128 * (2 * C * k * k + k * k) for (_, C, H, W, k) in FACE_LAYERS)
+        legs["config3_inference_fc_mode%d" % mode] = {
+            "what": "BASELINE configs[2]: ExtractorAttn L3 (C256,32x32,k3) + L2 (C128,64x64,k5) forward only, eval / no_grad, "
+                    "batch 32, %s" % fc_mfma.MODE_NAMES[mode],
+            "ms": round(dt * 1e3, 3), "images_per_s": round(32 / dt, 1),
+            "effective_TFLOPs_of_the_reference_formulation": round(flops / dt / 1e12, 1)}
+        del mods, ins
+    # configs[3] loss side: the warps inside PerceptualCorrectness + the affine regulariser
+    hp = HotPath(args.batch, device, seed=100, vgg_grad=False, fc_impl="mfma", fc_mode=args.fc_mode, with_losses=True)
+    dt = timeit(lambda: hp.step(None, allreduce=False), 5, 2)
+    legs["config4_with_losses"] = {"what": "the headline's two attention layers + PerceptualCorrectness.calculate_loss (max-cosine "
+                                           "MFMA kernel, Resample2d, fused loss map) + MultiAffineRegularizationLoss, fwd+bwd, "
+                                           "batch %d" % args.batch,
+                                   "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(args.batch / dt, 1)}
+    del hp
+    # configs[3] as a whole step of a generator-shaped network (SURVEY 8f row 4)
+    tp = TrainerPath(args.batch, device, seed=100, fc_mode=args.fc_mode)
+    dt = timeit(lambda: tp.step(), 3, 2)
+    legs["config4_trainer_step"] = {"what": tp.describe(args, 1)["config"]["workload"], "ms_per_step": round(dt * 1e3, 3),
+                                    "images_per_s": round(args.batch / dt, 1), "losses": {k: round(v, 5) for k, v in tp.losses.items()}}
+    del tp
+    # configs[4]: face model shapes, bf16 features, 6 sequential frames, 8 clips
+    fp = FacePath(8, device, seed=100, frames=6)
+    dt = timeit(lambda: fp.step(None, allreduce=False), 3, 2)
+    legs["config5_face_bf16"] = {"what": fp.describe(args, 1)["config"]["workload"], "clips": 8, "frames_per_clip": 6,
+                                 "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(48 / dt, 1)}
+    del fp
+    torch.cuda.empty_cache()
+    return legs
+
+
 def timed_steps(step, steps, warmup, barrier, world, device):
     """The contract's timing: W untimed steps, then exactly K steps between barrier + synchronize, MAX over ranks."""
     for _ in range(warmup):
@@ -761,6 +825,9 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                                         "events around the call; peak = dense matrix-core rate of the operand type"}
     if variants:
         line["variants"] = variants
+    if rank == 0 and world == 1 and on_gpu and not custom and not getattr(args, "no_legs", False) \
+            and not getattr(args, "with_losses", False):
+        line["legs"] = extra_legs(args, device)
     if check is not None:
         line["oracle_check"] = check
     if rank == 0:
@@ -777,7 +844,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle check + baseline)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the labelled f16-split variants")
+    ap.add_argument("--no-variants", action="store_true", help="skip the labelled variants (other FC arithmetic modes)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the compact legs for the other BASELINE configs (config-3 inference, with-losses, trainer "
+                         "step, face bf16) that the default N=1 run appends under `legs`")
     ap.add_argument("--no-vgg-grad", action="store_true",
                     help="treat the VGG features fed to Resample2d as constants (what the reference's training step "
                          "does: they come from a frozen VGG of the input images), i.e. skip d/d input1")

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # the default bench FIRST: after rocprofv3 --pmc passes in the same job the f32-MFMA kernels run ~10 % slower for a while
 ( time timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
-BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants"
+BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-legs"
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_$C -o pmc -- $BENCH > $OUT/pmc_$C.log 2>&1); echo "$C rc=$?"
 done
@@ -21,6 +21,6 @@ bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants > $OUT/mfma.log 2>&1; grep -E "
 # round 1's kernel (agg_fwd_lds_kernel, tuning key 8 = 1) and the table path (agg_coef + agg_fwd_stream) in one run
 bash tools/gpu_pmc_lds.sh $TAG/agg_lds agg_ -- python $PWD/tools/bench_agg_fwd.py --flows smooth --iters 3 > /dev/null 2>&1
 cat $OUT/agg_lds/pmc_summary.txt | cut -c1-330
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_trace -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants > $OUT/rocprof_bench.log 2>&1); echo "trace rc=$?"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_trace -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-legs > $OUT/rocprof_bench.log 2>&1); echo "trace rc=$?"
 cp /tmp/fin_trace/bench_kernel_stats.csv $OUT/ 2>/dev/null
 python tools/trace_steps.py /tmp/fin_trace/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -48 $OUT/steady_state_steps.txt
