@@ -537,7 +537,7 @@ def fc_kernel_probes(hp, iters=10):
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / iters * 1e3
                 row = {"dims": [B, C, H, W, k], "avg_us": round(us, 1)}
-                if mode == 4:
+                if mode == 4 and (which < 4 or k == 5):   # (k = 3 weight gradient: the direct kernel, csrc/fc_block.hip)
                     # Winograd domain: the kernel EXECUTES 36 multiplies per (tile, c, n) -- F(2x2,5x5): 2x2 outputs per
                     # tile, F(4x4,3x3): 4x4.  `TFLOPs` / `frac` are these executed MFMA flops against the f32 peak (what the
                     # hardware does); `effective_TFLOPs` = the reference formulation's flops / time (what the caller gets).
@@ -550,7 +550,7 @@ def fc_kernel_probes(hp, iters=10):
                                 "effective_GFLOP": round(flops / 1e9, 2),
                                 "effective_TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 else:
-                    kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode == 0 else "fc_wgrad_kernel")
+                    kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode in (0, 4) else "fc_wgrad_kernel")
                     row.update({"alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
                 row["frac_mfma_f32_peak"] = round(row["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)

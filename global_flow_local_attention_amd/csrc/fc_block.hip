@@ -112,10 +112,8 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
 
 // the four Winograd weight sets of one layer (mode 4)
 static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream) {
-  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), C, 0, 0, k, stream));
-  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_fs), C, C, 0, k, stream));
-  GFLA_TRY(fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_dt), C, 0, 1, k, stream));
-  return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ds), C, C, 1, k, stream);
+  return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), reinterpret_cast<float *>(ws + L.wu_fs),
+                              reinterpret_cast<float *>(ws + L.wu_dt), reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
 }
 
 static int fc_forward(const float *source, const float *target, const float *flow, const float *w0, const float *b0,
@@ -199,7 +197,10 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
-    if (wino && tuning(19) != 1) {  // (tuning key 19 = 1: the direct weight-gradient kernel under mode 4, for A/B timing)
+    // mode 4: the Winograd-domain weight gradient for k = 5; for k = 3 the 4 x 4 tiling leaves 1-2 k steps per tile row and
+    // the direct kernel measured faster in the step (135 vs 172 us at C256 32x22) -- tuning key 19: 1 = always direct,
+    // 2 = always Winograd
+    if (wino && tuning(19) != 1 && (k == 5 || tuning(19) == 2)) {
       float *part = reinterpret_cast<float *>(sc + L.dwp);
       GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
       GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
@@ -402,7 +403,7 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
       return fc_wino_conv(Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
                           reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, B,
                           kFcHidden / kFcChunk, g.Md, g.Wp, g.Wp, g.Sz, k, stream);
-    if (tuning(19) == 1)
+    if (tuning(19) == 1 || (k != 5 && tuning(19) != 2))
       return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
     return fc_wino_wgrad(X4, reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz * kFcHidden, g.lead,
                          reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream);

@@ -153,15 +153,15 @@ int fc_tr_probe(const short *image, int n_halves, const int *offsets, short *out
 
 // fc_wino.hip (arithmetic mode 4)
 int64_t fc_wino_wpack_bytes(int n_in, int n_out);
-int fc_wino_pack_weights(const float *w0, float *U, int C, int c_off, int dgrad, int k, hipStream_t stream);
+int fc_wino_pack_weights(const float *w0, float *u_ft, float *u_fs, float *u_dt, float *u_ds, int C, int k,
+                         hipStream_t stream);
 bool fc_wino_fits(int M, int Wv, int Wp, int k);
 int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
                  int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream);
 int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k);
 int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
                   int Wo, int Wp, int64_t SX, int k, hipStream_t stream);
-int fc_wino_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
-                         hipStream_t stream);
+int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream);
 
 // fc_sample.hip
 int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,

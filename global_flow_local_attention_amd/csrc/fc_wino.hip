@@ -101,22 +101,32 @@ __device__ __forceinline__ void wn_g(const float (&w)[KS], float (&o)[6]) {
 // 16*chunk + 8*half + {kq, 4 + kq} of output channel 64*ntile + 16*nblock + n.
 // forward:        in = conv0 input channel c_off + ci, out = hidden n, taps as stored;
 // data gradient:  in = hidden n, out = conv0 input channel c_off + co, taps flipped (the transposed convolution).
+struct WnPackJob {
+  float *U;
+  int c_off, dgrad, n_in, n_out;
+};
+struct WnPackJobs {
+  WnPackJob j[4];
+};
+
+// grid (blocks, 4 jobs): forward / data-gradient sets of the target / source half in ONE launch.  Threads run along the
+// OUTPUT channel: the 36 stores of 16 neighbouring threads fill consecutive fragment slots.
 template <int KS>
-__global__ __launch_bounds__(256) void fc_wino_pack_w_kernel(const float *__restrict__ w0, float *__restrict__ U, int C,
-                                                            int c_off, int dgrad, int n_in, int n_out, int nch) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (out channel, in channel)
-  const int ntn = (n_out + kWnN - 1) / kWnN;
-  if (idx >= (int64_t)ntn * kWnN * nch * kFcChunk) return;
-  const int ci = (int)(idx % (nch * kFcChunk)), co = (int)(idx / (nch * kFcChunk));
+__global__ __launch_bounds__(256) void fc_wino_pack_w_kernel(const float *__restrict__ w0, WnPackJobs jobs, int C) {
+  const WnPackJob jb = jobs.j[blockIdx.y];
+  const int nch = (jb.n_in + kFcChunk - 1) / kFcChunk, ntn = (jb.n_out + kWnN - 1) / kWnN;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (in channel, out channel), out fastest
+  if (!jb.U || idx >= (int64_t)ntn * kWnN * nch * kFcChunk) return;
+  const int co = (int)(idx % (ntn * kWnN)), ci = (int)(idx / (ntn * kWnN));
   float w[KS][KS];
 #pragma unroll
   for (int i = 0; i < KS; ++i)
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       float v = 0.f;
-      if (ci < n_in && co < n_out) {
-        v = dgrad ? w0[(((int64_t)ci * 2 * C + c_off + co) * KS + (KS - 1 - i)) * KS + (KS - 1 - j)]
-                  : w0[(((int64_t)co * 2 * C + c_off + ci) * KS + i) * KS + j];
+      if (ci < jb.n_in && co < jb.n_out) {
+        v = jb.dgrad ? w0[(((int64_t)ci * 2 * C + jb.c_off + co) * KS + (KS - 1 - i)) * KS + (KS - 1 - j)]
+                     : w0[(((int64_t)co * 2 * C + jb.c_off + ci) * KS + i) * KS + j];
       }
       w[i][j] = v;
     }
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void fc_wino_pack_w_kernel(const float *__rest
   }
   const int ntile = co / kWnN, nb = (co % kWnN) >> 4, n = co & 15;
   const int cc = ci >> 4, half = (ci >> 3) & 1, ks = (ci >> 2) & 1, kq = ci & 3;
-  float *dst = U + ((((((int64_t)ntile * nch + cc) * 2 + half) * kWnXi) * 4 + nb) * 64 + kq * 16 + n) * 2 + ks;
+  float *dst = jb.U + ((((((int64_t)ntile * nch + cc) * 2 + half) * kWnXi) * 4 + nb) * 64 + kq * 16 + n) * 2 + ks;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     float o[6];
@@ -146,15 +156,25 @@ int64_t fc_wino_wpack_bytes(int n_in, int n_out) {
   return (int64_t)ceil_div(n_out, kWnN) * ceil_div(n_in, kFcChunk) * 2 * kWnXi * 4 * 64 * 2 * 4;
 }
 
-int fc_wino_pack_weights(const float *w0, float *U, int C, int c_off, int dgrad, int k, hipStream_t stream) {
-  const int n_in = dgrad ? kFcHidden : C, n_out = dgrad ? C : kFcHidden;
-  const int nch = (int)ceil_div(n_in, kFcChunk);
-  const int64_t total = ceil_div(n_out, kWnN) * kWnN * (int64_t)nch * kFcChunk;
-  const dim3 grid((unsigned)ceil_div(total, 256));
+// the four weight sets of one layer: forward (C -> 128) and data gradient (128 -> C) of the target / source half
+int fc_wino_pack_weights(const float *w0, float *u_ft, float *u_fs, float *u_dt, float *u_ds, int C, int k,
+                         hipStream_t stream) {
+  WnPackJobs jobs;
+  jobs.j[0] = WnPackJob{u_ft, 0, 0, C, kFcHidden};
+  jobs.j[1] = WnPackJob{u_fs, C, 0, C, kFcHidden};
+  jobs.j[2] = WnPackJob{u_dt, 0, 1, kFcHidden, C};
+  jobs.j[3] = WnPackJob{u_ds, C, 1, kFcHidden, C};
+  int64_t most = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int64_t n = ceil_div(jobs.j[q].n_out, kWnN) * kWnN * ceil_div(jobs.j[q].n_in, kFcChunk) * kFcChunk;
+    if (jobs.j[q].U && n > most) most = n;
+  }
+  if (most == 0) return GFLA_OK;
+  const dim3 grid((unsigned)ceil_div(most, 256), 4);
   if (k == 5)
-    fc_wino_pack_w_kernel<5><<<grid, 256, 0, stream>>>(w0, U, C, c_off, dgrad, n_in, n_out, nch);
+    fc_wino_pack_w_kernel<5><<<grid, 256, 0, stream>>>(w0, jobs, C);
   else if (k == 3)
-    fc_wino_pack_w_kernel<3><<<grid, 256, 0, stream>>>(w0, U, C, c_off, dgrad, n_in, n_out, nch);
+    fc_wino_pack_w_kernel<3><<<grid, 256, 0, stream>>>(w0, jobs, C);
   else
     return GFLA_ERR_UNSUPPORTED;
   return launch_status();
@@ -803,28 +823,36 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
     for (int r = 0; r < 4; ++r) o[((int64_t)q * cpad + 4 * kq + r) * kFcHidden] = acc[q][r];
 }
 
-// conv0.weight.grad[n][c_off + c][i][j] = (G^T (sum_s part[s][.][c][n]) G)[i][j]
+// conv0.weight.grad[n][c_off + c][i][j] = (G^T (sum_s part[s][.][c][n]) G)[i][j], two passes:
+//   (1) dU[point][c][n] = sum over the splits (one thread per element: 36 * cpad * 128 threads, coalesced along n; a single
+//       pass with one thread per (c, n) doing 36 * nsplit dependent loads took 170 us for 75 MB);
+//   (2) one thread per (c, n): 36 values -> G^T dU G -> k*k outputs in conv0.weight.grad's layout.
+__global__ __launch_bounds__(256) void fc_wino_wgrad_sum_kernel(const float *part, int nsplit, float *dusum, int64_t per) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float *p = part + idx;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    s0 += p[(int64_t)s * per];
+    s1 += p[(int64_t)(s + 1) * per];
+    s2 += p[(int64_t)(s + 2) * per];
+    s3 += p[(int64_t)(s + 3) * per];
+  }
+  for (; s < nsplit; ++s) s0 += p[(int64_t)s * per];
+  dusum[idx] = (s0 + s1) + (s2 + s3);
+}
+
 template <int KS>
-__global__ __launch_bounds__(256) void fc_wino_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit,
-                                                                  float *__restrict__ gw, int C, int c_off, int cpad) {
+__global__ __launch_bounds__(256) void fc_wino_wgrad_finish_kernel(const float *__restrict__ dusum, float *__restrict__ gw,
+                                                                  int C, int c_off, int cpad) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (c, n), n fastest: coalesced reads
   if (idx >= (int64_t)cpad * kFcHidden) return;
   const int n = (int)(idx & (kFcHidden - 1)), c = (int)(idx >> 7);
   if (c >= C) return;
-  const int64_t per = (int64_t)kWnXi * cpad * kFcHidden;
   float du[6][6];
 #pragma unroll
-  for (int q = 0; q < kWnXi; ++q) {
-    float s0 = 0.f, s1 = 0.f;
-    const float *p = part + (int64_t)q * cpad * kFcHidden + idx;
-    int s = 0;
-    for (; s + 2 <= nsplit; s += 2) {
-      s0 += p[(int64_t)s * per];
-      s1 += p[(int64_t)(s + 1) * per];
-    }
-    if (s < nsplit) s0 += p[(int64_t)s * per];
-    du[q / 6][q % 6] = s0 + s1;
-  }
+  for (int q = 0; q < kWnXi; ++q) du[q / 6][q % 6] = dusum[(int64_t)q * cpad * kFcHidden + idx];
   // G (6 x k): G[a][i] = p_a^i / f_a for a < 5, G[5][k-1] = 1 (wn_g)
   const float inv_f[5] = {1.f, -1.f / 3.f, 1.f / 3.f, 1.f / 15.f, -16.f / 15.f};
   const float pt[5] = {0.f, 1.f, -1.f, 2.f, -0.5f};
@@ -901,15 +929,17 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
   return launch_status();
 }
 
-int fc_wino_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
-                         hipStream_t stream) {
+// `part` holds nsplit slabs of 36 * cpad * 128 floats; slab 0 is overwritten with their sum
+int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream) {
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  const int64_t per = (int64_t)kWnXi * cpad * kFcHidden;
+  // in place: element idx of slab 0 is read and written by the same thread only
+  fc_wino_wgrad_sum_kernel<<<dim3((unsigned)ceil_div(per, 256)), 256, 0, stream>>>(part, nsplit, part, per);
   const dim3 grid((unsigned)ceil_div((int64_t)cpad * kFcHidden, 256));
   if (k == 5)
-    fc_wino_wgrad_reduce_kernel<5><<<grid, 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad);
-  else if (k == 3)
-    fc_wino_wgrad_reduce_kernel<3><<<grid, 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad);
+    fc_wino_wgrad_finish_kernel<5><<<grid, 256, 0, stream>>>(part, grad_w0, C, c_off, cpad);
   else
-    return GFLA_ERR_UNSUPPORTED;
+    fc_wino_wgrad_finish_kernel<3><<<grid, 256, 0, stream>>>(part, grad_w0, C, c_off, cpad);
   return launch_status();
 }
 
