@@ -590,7 +590,8 @@ struct Ww {
   static constexpr int L = M * SEG + 6 - M;              // raw pixels per row of a unit
   static constexpr int RAW = ((6 * L * kWwPitch + 15) & ~15);
 };
-constexpr int kWwVFloats = kWnXi * 4 * 16 * 4;           // one V buffer: [point][tile & 3][channel][tile >> 2]
+constexpr int kWwVFloats = 4 * 4 * 16 * kWnXi;           // one V buffer: [tile >> 2][tile & 3][channel][point]: a lane's 36
+                                                         // A values of a k step are contiguous (nine ds_read_b128)
 
 struct WwGeo {
   int TH, TW, nseg;
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
   // transform item: tile (wave & 3) + 4 * (lane >> 4) of the step's 16, channel lane & 15, point rows 3*xh..
   const int tq = wave & 3, tks = lane >> 4, tc = lane & 15;
   const int tl = tq + 4 * tks;
-  const int vpos = (xh * 18 * 4 + tq) * 16 * 4 + tc * 4 + tks;   // float offset of V[first point][tq][c][ks]
+  const int vpos = ((tks * 4 + tq) * 16 + tc) * kWnXi + xh * 18;   // float offset of V[ks][tq][c][first point of this half]
   auto transform = [&](auto half_tag, const WwUnit &un, int h, int rbuf, int vb) {
     constexpr int HALF = decltype(half_tag)::value;
     const int tile = min(h * 16 + tl, un.ntx - 1);
@@ -721,8 +722,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
     for (int r = 0; r < 3; ++r) {
       float o[6];
       wn_bt(tm[r], o);
-#pragma unroll
-      for (int e = 0; e < 6; ++e) dst[(r * 6 + e) * 4 * 16 * 4] = o[e];
+      float2 *d2 = reinterpret_cast<float2 *>(dst + r * 6);   // 8-byte aligned: 144-byte records, halves at +72, rows at +24
+      d2[0] = make_float2(o[0], o[1]);
+      d2[1] = make_float2(o[2], o[3]);
+      d2[2] = make_float2(o[4], o[5]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -746,22 +749,28 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
   };
   auto multiply = [&](const WwUnit &un, int h, int vb) {
     const int nks = min(4, (un.ntx - h * 16 + 3) >> 2);
-    const float *va = vbuf + vb * kWwVFloats + (kq * 16 + (lane & 15)) * 4;
-    float dy[M][M], dyn[M][M];
-    load_dy(un, h, 0, dy);
-    for (int ks = 0; ks < nks; ++ks) {
-      if (ks + 1 < nks) load_dy(un, h, ks + 1, dyn);
-      float zh[kWnXi];
-      ww_lift<M>(dy, zh);
+    const float *va = vbuf + vb * kWwVFloats + (kq * 16 + (lane & 15)) * kWnXi;
+    // the dY values run TWO k steps ahead of their use (global loads: an L2 round trip is about one k step of MFMAs)
+    constexpr int AHEAD = M == 2 ? 2 : 1;
+    float dy[AHEAD + 1][M][M];
 #pragma unroll
-      for (int q = 0; q < kWnXi; ++q) {
-        const float a = va[q * 4 * 16 * 4 + ks];
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, zh[q], acc[q], 0, 0, 0);
+    for (int a = 0; a < AHEAD; ++a)
+      if (a < nks) load_dy(un, h, a, dy[a]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < nks) {  // wave-uniform
+        if (ks + AHEAD < nks) load_dy(un, h, ks + AHEAD, dy[(ks + AHEAD) % (AHEAD + 1)]);
+        float zh[kWnXi];
+        ww_lift<M>(dy[ks % (AHEAD + 1)], zh);
+        const f32x4v *vp = reinterpret_cast<const f32x4v *>(va + ks * 4 * 16 * kWnXi);
+#pragma unroll
+        for (int q4 = 0; q4 < kWnXi / 4; ++q4) {
+          const f32x4v a4 = vp[q4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[q4 * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], zh[q4 * 4 + e], acc[q4 * 4 + e], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) dy[i][j] = dyn[i][j];
     }
   };
 
