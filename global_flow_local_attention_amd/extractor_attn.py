@@ -486,6 +486,14 @@ def _fused_attention(self, source, target, flow_field):
         logits = fc_mfma.FcMfmaFunction.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
                                               conv1.bias, k, _tail_slope(act), mode)
         return _aggregate(source_c, flow_c, logits, last, k, None)
+    if getattr(self, "fc_impl", "mfma") == "mfma" and not getattr(self, "_library_warned", False):
+        # nobody should benchmark the vendor libraries by accident: say once that this module left the MFMA path
+        import warnings
+        warnings.warn("ExtractorAttn(kernel_size=%d, %s, %s): this configuration is not taken by the library's own MFMA "
+                      "kernels (kernel_size 3 / 5, float32 or bfloat16 features, 128 hidden channels, maps whose tiles fit the "
+                      "LDS); its FC layers run through torch.mm / F.conv2d (rocBLAS / MIOpen) instead"
+                      % (k, source.dtype, tuple(source.shape)))
+        self._library_warned = True
     # base_function.py:805-807: conv0(cat(block_target, block_source)).  block_target is the
     # zero-flow (replicate-padded) unfold of target, so its half of the convolution equals a
     # stride-1 convolution of the padded target and block_target is never built; block_source's half
