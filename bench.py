@@ -431,8 +431,9 @@ def pmc_traffic_kernel(kernel_label):
         if not key.startswith(name + "<"):
             continue
         args = [x.strip() for x in key[len(name) + 1:].rstrip(">").split(",")]
-        # fc_conv_kernel<MODE, KS, NMB>, fc_wgrad_f32_kernel<KS>, fc_wgrad_kernel<MODE, KS, NB>
-        ks = args[0] if len(args) == 1 else args[1]
+        # fc_conv_kernel<MODE, KS, NMB>, fc_wgrad_f32_kernel<KS>, fc_wgrad_kernel<MODE, KS, NB>,
+        # fc_wino_conv_kernel<KS, DBG, DB>, fc_wino_wgrad_kernel<KS>
+        ks = args[0] if (len(args) == 1 or name.startswith("fc_wino")) else args[1]
         if k is None or ks == k:
             rows += rs
     if not rows:

@@ -16,8 +16,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 F=$(find /tmp/fin_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
-grep -E "fc_conv|fc_wgrad|agg_|be_bwd|rs_lds|patch_" $OUT/pmc_traffic.txt | cut -c1-160 | head -40
-bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants > $OUT/mfma.log 2>&1; grep -E "fc_conv|fc_wgrad" $OUT/mfma/pmc_set1.txt 2>/dev/null | cut -c1-250 | head -12
+grep -E "fc_conv|fc_wgrad|fc_wino|agg_|be_bwd|rs_lds|patch_" $OUT/pmc_traffic.txt | cut -c1-160 | head -40
+bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants --no-legs > $OUT/mfma.log 2>&1; grep -E "fc_conv|fc_wgrad|fc_wino" $OUT/mfma/pmc_set1.txt 2>/dev/null | cut -c1-250 | head -12
 # round 1's kernel (agg_fwd_lds_kernel, tuning key 8 = 1) and the table path (agg_coef + agg_fwd_stream) in one run
 bash tools/gpu_pmc_lds.sh $TAG/agg_lds agg_ -- python $PWD/tools/bench_agg_fwd.py --flows smooth --iters 3 > /dev/null 2>&1
 cat $OUT/agg_lds/pmc_summary.txt | cut -c1-330
