@@ -97,8 +97,9 @@ __device__ __forceinline__ void wn_g(const float (&w)[KS], float (&o)[6]) {
 }
 
 // ---- weights: conv0.weight (128, 2C, k, k) -> U = G w G^T in MFMA B-fragment order -------------------------------
-// U[ntile][chunk][half][point][nblock][lane][2]: lane (kq = lane >> 4, n = lane & 15) holds input channels
-// 16*chunk + 8*half + {kq, 4 + kq} of output channel 64*ntile + 16*nblock + n.
+// U[ntile][chunk][half][point pair][nblock][lane][point & 1][2]: lane (kq = lane >> 4, n = lane & 15) holds input channels
+// 16*chunk + 8*half + {kq, 4 + kq} of output channel 64*ntile + 16*nblock + n, for two neighbouring points: ONE 16-byte
+// load per point pair and step.
 // forward:        in = conv0 input channel c_off + ci, out = hidden n, taps as stored;
 // data gradient:  in = hidden n, out = conv0 input channel c_off + co, taps flipped (the transposed convolution).
 struct WnPackJob {
@@ -142,13 +143,16 @@ __global__ __launch_bounds__(256) void fc_wino_pack_w_kernel(const float *__rest
   }
   const int ntile = co / kWnN, nb = (co % kWnN) >> 4, n = co & 15;
   const int cc = ci >> 4, half = (ci >> 3) & 1, ks = (ci >> 2) & 1, kq = ci & 3;
-  float *dst = jb.U + ((((((int64_t)ntile * nch + cc) * 2 + half) * kWnXi) * 4 + nb) * 64 + kq * 16 + n) * 2 + ks;
+  float *dst = jb.U + ((((((int64_t)ntile * nch + cc) * 2 + half) * (kWnXi / 2)) * 4 + nb) * 64 + kq * 16 + n) * 4 + ks;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     float o[6];
     wn_g<KS>(t[a], o);
 #pragma unroll
-    for (int e = 0; e < 6; ++e) dst[(int64_t)(a * 6 + e) * 4 * 64 * 2] = o[e];
+    for (int e = 0; e < 6; ++e) {
+      const int q = a * 6 + e;
+      dst[(int64_t)(q >> 1) * 4 * 64 * 4 + (q & 1) * 2] = o[e];
+    }
   }
 }
 
@@ -310,10 +314,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc 
   // this lane's B fragments of the current step: U[ntile][cc][half][point][nb][lane][2]
   // (the wave's base offset goes through readfirstlane: a scalar base + one per-lane offset register, no per-load
   // vector address arithmetic in the MFMA stream)
-  const unsigned ub_wave = __builtin_amdgcn_readfirstlane((unsigned)((((unsigned)ntile * nch * 2 * kWnXi + xh * NX) * 4 + nb) * 64));
-  const float2 *ub = reinterpret_cast<const float2 *>(U) + ub_wave;
-  float2 bf[NX];
-  auto load_b = [&](int step, int q) { return (ub + ((unsigned)step * kWnXi + q) * 4 * 64)[lane]; };
+  const unsigned ub_wave = __builtin_amdgcn_readfirstlane((unsigned)((((unsigned)ntile * nch * 2 * (kWnXi / 2) + xh * (NX / 2)) * 4 + nb) * 64));
+  const f32x4v *ub = reinterpret_cast<const f32x4v *>(U) + ub_wave;
+  f32x4v bf[NX / 2];   // [point pair]: (point 0: k step 0, 1; point 1: k step 0, 1)
+  auto load_b = [&](int step, int qp) { return (ub + ((unsigned)step * (kWnXi / 2) + qp) * 4 * 64)[lane]; };
 
   const int arow = ((lane >> 5) * 16 + (lane & 15)) * 4 + ((lane >> 4) & 1) * 2;  // this lane's A fragment inside V[point][block]
 
@@ -369,19 +373,16 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc 
       const int slot = (q >> 1) & 1;
       if (q + 2 < NX) read_pair(q + 2, slot ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      const float2 b0 = bf[q], b1 = bf[q + 1];
-      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].x, b0.x, acc[q][0], 0, 0, 0);
-      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].x, b0.x, acc[q][1], 0, 0, 0);
-      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].x, b1.x, acc[q + 1][0], 0, 0, 0);
-      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].x, b1.x, acc[q + 1][1], 0, 0, 0);
-      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].y, b0.y, acc[q][0], 0, 0, 0);
-      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].y, b0.y, acc[q][1], 0, 0, 0);
-      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].y, b1.y, acc[q + 1][0], 0, 0, 0);
-      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].y, b1.y, acc[q + 1][1], 0, 0, 0);
-      if constexpr (!(DBG & 4)) {  // the registers are free again: next step's slices, a whole step ahead of their use
-        bf[q] = load_b(sn, q);
-        bf[q + 1] = load_b(sn, q + 1);
-      }
+      const f32x4v bq = bf[q >> 1];
+      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].x, bq[0], acc[q][0], 0, 0, 0);
+      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].x, bq[0], acc[q][1], 0, 0, 0);
+      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].x, bq[2], acc[q + 1][0], 0, 0, 0);
+      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].x, bq[2], acc[q + 1][1], 0, 0, 0);
+      acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][0].y, bq[1], acc[q][0], 0, 0, 0);
+      acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][0][1].y, bq[1], acc[q][1], 0, 0, 0);
+      acc[q + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][0].y, bq[3], acc[q + 1][0], 0, 0, 0);
+      acc[q + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][1][1].y, bq[3], acc[q + 1][1], 0, 0, 0);
+      if constexpr (!(DBG & 4)) bf[q >> 1] = load_b(sn, q >> 1);  // the register is free again: next step's slice, a step ahead
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc 
   prefetch(0);
   commit(0);
 #pragma unroll
-  for (int q = 0; q < NX; ++q) bf[q] = load_b(0, q);
+  for (int q = 0; q < NX / 2; ++q) bf[q] = load_b(0, q);
   __syncthreads();
   if (xh == 0) transform(Half0{}, 0);
   else transform(Half1{}, 0);
