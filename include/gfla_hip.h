@@ -348,9 +348,11 @@ GFLA_DECL_FC_TAIL(f64, double)
  *   source, target (B,C,H,W)  flow (B,2,H,W)  w0 = conv0.weight (128, 2C, k, k)  b0 (128) or NULL
  *   w1 = conv1.weight (k*k, 128)  b1 (k*k) or NULL  logits (B,k*k,H,W), overwritten.  fp32; k in {3, 5}.
  *   slope: LeakyReLU negative slope (0 = ReLU).
- *   mode: arithmetic of the contraction -- 0: v_mfma_f32_32x32x2_f32 (exact f32 fma chain); 3: operands as three
- *   f16 terms, six cross products, f32 accumulate (every product term above 2^-32 kept: f32-grade); 2: two f16
- *   terms, three products (2^-21 per product).
+ *   mode: arithmetic of the contraction -- 4: float32 throughout in the Winograd domain (F(2x2,5x5) / F(4x4,3x3) on the
+ *   points {0, 1, -1, 2, -1/2, inf}: 36 multiplies per 6x6 tile instead of 100 / 144, v_mfma_f32_16x16x4_f32; the
+ *   host-side default, csrc/fc_wino.hip); 0: v_mfma_f32_32x32x2_f32, direct convolution (a k-ordered f32 fma chain per
+ *   output); 3: operands as three f16 terms, six cross products, f32 accumulate (every product term above 2^-32 kept:
+ *   f32-grade); 2: two f16 terms, three products (2^-21 per product); 1: one f16 term (exact for bf16 values).
  *   workspace: gfla_fc_workspace_bytes(..., which = 0) bytes, 256-byte aligned; forward fills it and backward
  *   reads it (packed inputs, convolved source map, hidden activations).  scratch: (..., which = 1) bytes.
  * backward: given grad_logits, overwrites whichever of grad_source, grad_target (B,C,H,W), grad_flow (B,2,H,W),
