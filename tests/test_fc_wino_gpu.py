@@ -1,0 +1,114 @@
+"""Winograd-domain FC kernels (arithmetic mode 4, csrc/fc_wino.hip) beyond the shapes test_fc_mfma_gpu.py /
+test_bench_shapes_gpu.py already run in every mode: a sweep over ragged geometries (partial tiles in both directions,
+maps smaller than one tile group, channels that do not fill a chunk, single samples, maps that need the single-buffer
+staging) against float64 convolutions on the host, the mode-4 -> mode-0 fallback, and size-independent properties at the
+bench shape (linearity of each convolution in its input, adjointness of forward and data gradient).
+
+Bars: the same as every other arithmetic mode (forward 1e-5, gradients 2e-5 of the largest reference entry)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import max_abs, randn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FWD_TOL, GRAD_TOL = 1e-5, 2e-5
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def rel_err(got, want):
+    return max_abs(got, want) / max(1e-30, want.double().abs().max().item())
+
+
+def _pads(k, is_source):
+    lo, hi = k // 2, k - 1 - k // 2
+    return (k - 1, k - 1, k - 1, k - 1) if is_source else (lo, hi, lo, hi)
+
+
+def _run_half(B, C, H, W, k, is_source, mode, x, w0, dG):
+    from global_flow_local_attention_amd import _lib, fc_mfma
+    g = fc_mfma.geometry(H, W, k, is_source)
+    ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=DEV)
+    out = torch.full((B, g["Mg"], 128), float("nan"), device=DEV)
+    _lib.call("gfla_fc_conv_fwd_f32", x, _ptr(x), _ptr(w0), is_source, _ptr(ws), _ptr(out), B, C, H, W, k, mode)
+    rows = (torch.arange(g["Ho"])[:, None] * g["Wp"] + torch.arange(g["Wo"])[None, :]).reshape(-1).to(DEV)
+    z = torch.zeros(B, g["Sz"], 128, device=DEV)
+    z[:, g["lead"] + rows, :] = dG.permute(0, 2, 3, 1).reshape(B, -1, 128)
+    sc = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=DEV)
+    gx = torch.full((B, C, H, W), float("nan"), device=DEV)
+    gw = torch.full((128, 2 * C, k, k), float("nan"), device=DEV)
+    _lib.call("gfla_fc_conv_bwd_f32", x, _ptr(z), is_source, _ptr(ws), _ptr(sc), _ptr(gx), _ptr(gw), B, C, H, W, k, mode)
+    fwd = out[:, :g["Ho"] * g["Wo"], :].reshape(B, g["Ho"], g["Wo"], 128).permute(0, 3, 1, 2)
+    return fwd, gx, gw, g
+
+
+SWEEP = [  # (k, B, C, H, W): ragged / tiny / odd / wide
+    (5, 1, 5, 3, 3), (5, 3, 17, 7, 5), (5, 2, 16, 2, 9), (5, 1, 33, 13, 31), (5, 2, 8, 40, 66), (5, 1, 16, 9, 120),
+    (3, 1, 5, 3, 3), (3, 3, 17, 7, 5), (3, 2, 16, 2, 9), (3, 1, 40, 13, 31), (3, 2, 8, 33, 65), (3, 1, 16, 10, 200),
+]
+
+
+@pytest.mark.parametrize("k,B,C,H,W", SWEEP)
+@pytest.mark.parametrize("is_source", [0, 1])
+def test_winograd_half_on_ragged_shapes(gfla, k, B, C, H, W, is_source):
+    from global_flow_local_attention_amd import fc_mfma
+    mode = fc_mfma.resolve_mode(C, H, W, k, 4)
+    assert mode in (4, 0)
+    x = (randn((B, C, H, W), seed=1) * 1.7).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=2) * 0.05).to(DEV)
+    g = fc_mfma.geometry(H, W, k, is_source)
+    dG = (randn((B, 128, g["Ho"], g["Wo"]), seed=3) * 1e-3).to(DEV)
+    fwd, gx, gw, _ = _run_half(B, C, H, W, k, is_source, mode, x, w0, dG)
+    x64 = x.cpu().double().requires_grad_()
+    wh = (w0[:, C:] if is_source else w0[:, :C]).cpu().double().clone().requires_grad_()
+    ref = F.conv2d(F.pad(x64, _pads(k, is_source), mode="replicate"), wh)
+    ref.backward(dG.cpu().double())
+    e_f, e_x = rel_err(fwd.cpu(), ref.detach()), rel_err(gx.cpu(), x64.grad)
+    e_w = rel_err((gw[:, C:] if is_source else gw[:, :C]).cpu(), wh.grad)
+    print("mode %d k %d B %d C %d %dx%d half %d: map %.2e grad_x %.2e grad_w %.2e" % (mode, k, B, C, H, W, is_source, e_f, e_x, e_w))
+    assert e_f <= FWD_TOL and e_x <= GRAD_TOL and e_w <= GRAD_TOL, (e_f, e_x, e_w)
+    other = gw[:, :C] if is_source else gw[:, C:]
+    assert float(other.abs().max()) == 0.0
+
+
+def test_mode4_falls_back_to_the_direct_kernels_where_its_tiles_do_not_fit(gfla):
+    """A map too wide for the Winograd kernel's LDS span: resolve_mode answers 0, the module runs the direct f32 kernels
+    and still matches the reference's op-by-op composition on the library's own ops."""
+    from global_flow_local_attention_amd import _lib, fc_mfma
+    C, H, W, k = 8, 6, 200, 5
+    assert not fc_mfma.supported(C, H, W, k, 4) and fc_mfma.resolve_mode(C, H, W, k) == 0
+    m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    s, t = randn((1, C, H, W), seed=1).to(DEV), randn((1, C, H, W), seed=2).to(DEV)
+    f = (randn((1, 2, H, W), seed=3) * 1.5).to(DEV)
+    before = _lib.path_count(_lib.PATH_FC_FWD_MODE0)
+    a = m(s, t, f)
+    assert _lib.path_count(_lib.PATH_FC_FWD_MODE0) == before + 1
+    m.fused = False
+    assert rel_err(a.cpu(), m(s, t, f).cpu()) <= 2e-5
+
+
+@pytest.mark.parametrize("k,C,H,W", [(5, 128, 64, 44), (3, 256, 32, 22)])
+def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W):
+    """Properties that need no reference at B = 32: conv(a x1 + b x2) = a conv(x1) + b conv(x2);  <conv(x), dG> = <x, convT(dG)>
+    (forward and data gradient are each other's adjoints);  <dW, W> = <conv_W(x), dG> (weight gradient)."""
+    from global_flow_local_attention_amd import fc_mfma
+    B, is_source = 32, 1
+    g = fc_mfma.geometry(H, W, k, is_source)
+    x1, x2 = randn((B, C, H, W), seed=11).to(DEV), randn((B, C, H, W), seed=12).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=13) / (2 * C * k * k) ** 0.5).to(DEV)
+    dG = randn((B, 128, g["Ho"], g["Wo"]), seed=14).to(DEV)
+    f1, gx, gw, _ = _run_half(B, C, H, W, k, is_source, 4, x1, w0, dG)
+    f2, _, _, _ = _run_half(B, C, H, W, k, is_source, 4, x2, w0, dG)
+    f12, _, _, _ = _run_half(B, C, H, W, k, is_source, 4, 0.75 * x1 - 1.5 * x2, w0, dG)
+    assert rel_err(f12, 0.75 * f1 - 1.5 * f2) <= 2e-5
+    lhs = (f1.double() * dG.double()).sum().item()
+    rhs = (x1.double() * gx.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), (f1.double().abs() * dG.double().abs()).sum().item() * 1e-3)
+    wlhs = (gw[:, C:].double() * w0[:, C:].double()).sum().item()
+    assert abs(wlhs - lhs) <= 2e-5 * max(abs(lhs), (f1.double().abs() * dG.double().abs()).sum().item() * 1e-3)
