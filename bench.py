@@ -887,11 +887,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     device = torch.device("cuda", local)
-    if args.fc_impl == "library":  # round 1's path: let the vendor libraries pick / load their tuned kernels
+    if args.fc_impl == "library":  # round 1's path (rocBLAS / MIOpen FC layers), kept as a cross-check only
         torch.backends.cudnn.benchmark = True
-        tune_dir = os.environ.get("GFLA_TUNE_DIR", "/tmp")
-        gfla.seed_conv_db(os.path.join(tune_dir, "gfla_miopen_db_rank%d" % rank))
-        gfla.enable_gemm_tuning(os.path.join(tune_dir, "gfla_tunableop_rank%d.csv" % rank))
 
     def make_hotpath(fc_mode):
         if args.workload == "face_bf16":

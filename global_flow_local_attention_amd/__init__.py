@@ -8,14 +8,12 @@ from ._lib import build, exported_symbols, path_count, set_tuning  # noqa: F401
 from .block_extractor import BlockExtractor, BlockExtractorFunction  # noqa: F401
 from .local_attn_reshape import LocalAttnReshape, LocalAttnReshapeFunction  # noqa: F401
 from .resample2d import Resample2d, Resample2dFunction  # noqa: F401
-from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn, FcTailFunction,  # noqa: F401
-                             LocalAttnAggregateFunction, patch_reference_extractor_attn)
+from .extractor_attn import (BlockExtractorUnfoldFunction, ExtractorAttn, FcTailFunction, GraphedCall,  # noqa: F401
+                             LocalAttnAggregateFunction, graphed_inference, patch_reference_extractor_attn)
 from .losses import AffineRegularizationLoss, MultiAffineRegularizationLoss  # noqa: F401
 from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401
-from .graphs import GraphedCall, graphed_inference  # noqa: F401
 from .install import install  # noqa: F401
 from .trainer import TrainerShell, load_reference_checkpoint  # noqa: F401
 from .warp_generator import RandomFeaturePyramid, WarpGenerator  # noqa: F401
-from .tuning import enable_gemm_tuning, gemm_tuning_results, seed_conv_db  # noqa: F401
 
 __version__ = "0.1.0"

@@ -612,3 +612,37 @@ def patch_reference_extractor_attn(cls):
     cls.forward = _forward
     cls.hook_attn_param = _hook_attn_param
     return cls
+
+
+# ------------------------------------------------------------------------------------- hipGraph capture (inference)
+# At batch 1 an ExtractorAttn forward is a dozen launches of a few microseconds each: the GPU waits for the host.  The
+# C-ABI entry points enqueue on the current torch stream and never allocate or synchronise, so the whole call captures
+# into one hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm) and replays as a single launch.
+class GraphedCall(object):
+    """Capture `fn(*static_inputs)` once; `__call__(*inputs)` copies the inputs into the captured
+    buffers, replays the graph and returns the captured outputs (valid until the next call)."""
+
+    def __init__(self, fn, example_inputs, warmup=3):
+        self.static_inputs = [x.clone() for x in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):  # library autotuning / lazy init must happen outside the capture
+                fn(*self.static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_outputs = fn(*self.static_inputs)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.static_outputs
+
+
+def graphed_inference(module, example_inputs, warmup=3):
+    """hipGraph-captured `module.forward` for fixed input shapes (inference only)."""
+    module.eval()
+    return GraphedCall(module, example_inputs, warmup)
+
