@@ -181,14 +181,13 @@ __device__ __forceinline__ void zero_planes(A *lds, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = 0;
 }
 
-// g[i] += lds[i].  exclusive = this workgroup is the only writer of these planes (plain
+// g[i] += val(i).  exclusive = this workgroup is the only writer of these planes (plain
 // read-modify-write, coalesced); otherwise device-scope atomics.
-template <typename T>
-__device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t *lds, int n, bool exclusive,
-                                             bool overwrite = false) {
+template <typename T, typename F>
+__device__ __forceinline__ void flush_planes_with(T *__restrict__ g, int n, bool exclusive, bool overwrite, F val) {
   using A = typename Num<T>::acc;
   if (exclusive && overwrite) {  // sole writer of planes the caller did not initialise: plain stores
-    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from((A)lds[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from((A)val(i));
     return;
   }
   if (exclusive) {
@@ -198,18 +197,69 @@ __device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t 
         float4 *g4 = reinterpret_cast<float4 *>(g);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
           float4 a = g4[i];
-          const lds_acc_t *d = lds + 4 * i;
-          a.x += (float)d[0]; a.y += (float)d[1]; a.z += (float)d[2]; a.w += (float)d[3];
+          a.x += (float)val(4 * i); a.y += (float)val(4 * i + 1); a.z += (float)val(4 * i + 2); a.w += (float)val(4 * i + 3);
           g4[i] = a;
         }
-        for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)lds[i]);
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)val(i));
         return;
       }
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)lds[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) g[i] = Num<T>::from(Num<T>::ld(g + i) + (A)val(i));
   } else {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) atomic_add(g + i, (T)lds[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomic_add(g + i, (T)val(i));
   }
+}
+template <typename T>
+__device__ __forceinline__ void flush_planes(T *__restrict__ g, const lds_acc_t *lds, int n, bool exclusive,
+                                             bool overwrite = false) {
+  flush_planes_with<T>(g, n, exclusive, overwrite, [lds](int i) { return lds[i]; });
+}
+
+// ---- fixed-point scatter planes (round 3) ------------------------------------------------------------------------------
+// The same microbenchmark (profiles/r1_ubench_lds_atomics.txt) has ds_add_u64 at 5.2-7.7 lanes/clk/CU against ds_add_f64's
+// 3.2-3.9, and a scatter kernel is bound by exactly that rate.  So a kernel that can bound its contributions -- |v| <= max
+// |g| over the gradients the workgroup reads, known after one pass over them -- accumulates 64-bit FIXED POINT instead: the
+// scale is the power of two that puts max |g| at 2^40 (every float contribution down to 2^-16 of the maximum is represented
+// exactly; 22 bits of headroom = 4 M contributions per element before the sum could overflow; smaller ones round at
+// 2^-40 of the maximum), the float -> integer conversion is the 1.5 * 2^52 magic-number add, and the integer sum is
+// exactly associative: the result does not depend on the order the lanes arrive in (bit-reproducible run to run, which
+// neither the reference's float atomics nor the double planes guarantee).  A non-finite gradient cannot be represented:
+// the workgroup then writes NaN to the planes it owns (the reference would poison only the taps the value reaches).
+using lds_fix_t = long long;
+struct FixScale {
+  float up;      // contributions are multiplied by this power of two before the conversion
+  double down;   // its inverse
+  bool finite;
+};
+// amax_bits: the largest |x| bit pattern the workgroup will scatter (non-finite patterns compare above every finite one)
+__device__ __forceinline__ FixScale fix_scale(unsigned amax_bits) {
+  const int e = (int)(amax_bits >> 23);                      // biased exponent of the maximum
+  const int se = min(253, 127 + 40 - (e - 127));             // biased exponent of the scale
+  FixScale f;
+  f.up = __uint_as_float((unsigned)se << 23);
+  f.down = __longlong_as_double((long long)(1023 - (se - 127)) << 52);
+  f.finite = amax_bits < 0x7f800000u;
+  return f;
+}
+__device__ __forceinline__ void lds_add_fix(lds_fix_t *p, float v_scaled) {
+  const double d = (double)v_scaled + 6755399441055744.0;   // 1.5 * 2^52: the integer lands in the low mantissa bits
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
+  __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// workgroup-wide maximum of `v` through the LDS word `slot` (zeroed by the caller before its last barrier)
+__device__ __forceinline__ unsigned block_umax(unsigned v, unsigned *slot) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, v);
+  __syncthreads();
+  return *slot;
+}
+template <typename T>
+__device__ __forceinline__ void flush_planes_fix(T *__restrict__ g, const lds_fix_t *lds, int n, bool exclusive,
+                                                 bool overwrite, FixScale f) {
+  const double down = f.finite ? f.down : __longlong_as_double(0x7ff8000000000000ll);
+  const bool finite = f.finite;
+  flush_planes_with<T>(g, n, exclusive, overwrite, [=](int i) { return finite ? (double)lds[i] * down : down; });
 }
 
 }  // namespace gfla

@@ -15,6 +15,9 @@ int agg_source_bwd_mfma(const float *flow, const float *attn, const float *gout,
 int rs_input1_bwd_mfma(const float *in2, const float *gout, float *gin1, void *workspace, int64_t B, int64_t C,
                        int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int trunc, int accumulate, int adaptive,
                        const unsigned **skip_stat, unsigned *skip_limit, hipStream_t stream);
+// scratch of one op invocation: [patch table + tile rows + dispatch statistic | resample2d's tap records (resample2d.hip)]
+constexpr int kRsTapRecBytes = 48;
+int64_t pm_table_bytes(int64_t B, int64_t H, int64_t W, int entries);     // the first part = offset of the second
 int64_t pm_workspace_bytes(int64_t B, int64_t H, int64_t W, int entries);
 
 }  // namespace gfla

@@ -27,6 +27,7 @@
 //   3. aggregation only: pixels whose taps are not a dense patch (a tap within rounding of an integer position,
 //      lds_plane.h / be_bwd_lds.h) are left out of the table and scattered tap by tap with global atomics.
 #include "gfla_common.h"
+#include "patch_mfma.h"
 #include "rs_taps.h"
 
 namespace gfla {
@@ -674,9 +675,13 @@ int rs_input1_bwd_mfma(const float *in2, const float *gout, float *gin1, void *w
   return pm_scatter(gout, gin1, table, rows, B, C, H, W, Hi, Wi, entries, k, accumulate, stat, limit, stream);
 }
 
+int64_t pm_table_bytes(int64_t B, int64_t H, int64_t W, int entries) {
+  if (B <= 0 || H <= 0 || W <= 0 || entries <= 0) return 0;
+  return (pm_layout(B, H * W, entries).total + 255) & ~(int64_t)255;
+}
 int64_t pm_workspace_bytes(int64_t B, int64_t H, int64_t W, int entries) {
   if (B <= 0 || H <= 0 || W <= 0 || entries <= 0) return 0;
-  return pm_layout(B, H * W, entries).total;
+  return pm_table_bytes(B, H, W, entries) + B * H * W * kRsTapRecBytes;
 }
 
 }  // namespace gfla

@@ -41,6 +41,10 @@ struct LdsPlane {
   template <typename P, typename A>
   static __device__ __forceinline__ void add(P *p, A v) { lds_add(p, (P)v); }
 };
+struct LdsFixPlane {  // fixed-point planes (lds_plane.h): the caller pre-scales the gradient
+  template <typename A>
+  static __device__ __forceinline__ void add(lds_fix_t *p, A v) { lds_add_fix(p, (float)v); }
+};
 
 // ---- per-pixel bodies, shared by the global-memory and the LDS-plane kernels ------------------
 // The tap weights are an outer product w[r][q] = wy[r] * wx[q] of 2*KH row and 2*KH column weights
@@ -77,9 +81,28 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
 }
 
 // d/d input1: scatter SAFE_DIV(w, sum) * grad_out into the gradient planes (:195-198).
+// ro / co: row (x row pitch) and column offsets of the N x N taps in position order, qy = w_y / sum, wx = w_x.
+template <typename T, typename PT, int N, typename A, typename Where>
+__device__ __forceinline__ void rs_bwd1_apply(const int (&ro)[N], const int (&co)[N], const A (&qy)[N], const A (&wx)[N],
+                                              const T *__restrict__ g, int64_t gstride, PT *__restrict__ gplane,
+                                              int64_t plane_sz, int nch, A gscale) {
+  A gnext = Num<T>::ld(g);  // the next channel's gradient is requested before this channel's adds are issued
+  for (int c = 0; c < nch; ++c) {
+    const A go = gnext * gscale;
+    g += gstride;
+    if (c + 1 < nch) gnext = Num<T>::ld(g);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const A gr_ = go * qy[r];
+#pragma unroll
+      for (int q = 0; q < N; ++q) Where::add(gplane + ro[r] + co[q], gr_ * wx[q]);
+    }
+    gplane += plane_sz;
+  }
+}
 template <typename T, typename PT, int KH, typename A, typename Where>
 __device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__restrict__ g, int64_t gstride,
-                                              PT *__restrict__ gplane, int64_t plane_sz, int nch) {
+                                              PT *__restrict__ gplane, int64_t plane_sz, int nch, A gscale = 1) {
   constexpr int N = 2 * KH;
   int ro[N], co[N];
   A qy[N], wx[N];
@@ -90,17 +113,46 @@ __device__ __forceinline__ void rs_bwd1_pixel(const Taps<A, KH> &t, const T *__r
     qy[r] = (A)safe_div<A>(t.row_w(r), t.sum);
     wx[r] = t.col_w(r);
   }
-  for (int c = 0; c < nch; ++c) {
-    const A go = Num<T>::ld(g);
+  rs_bwd1_apply<T, PT, N, A, Where>(ro, co, qy, wx, g, gstride, gplane, plane_sz, nch, gscale);
+}
+
+// Tap records (kernel_size 4 / 5, float): everything rs_bwd1_pixel derives from (dx, dy, sigma) -- eight Gaussians with
+// the reference's exact divisions, their normalisation -- is ~450 instructions per pixel, and a workgroup of the scatter
+// kernel repeats it for every pixel while it owns only G = 2..4 of the C channels: at 64x44 C256 that setup was 70 % of
+// the instruction stream.  With scratch memory the setup runs ONCE per pixel (rs_tap_table_kernel) and the scatter
+// kernel reads 48-byte records (L2-resident: 48 B x B H W) one pixel ahead.  Same expressions, same rounding.
+struct alignas(16) RsTapRec {
+  uint32_t rows[2], cols[2];  // 4 + 4 clamped row / column INDICES, 16 bits each, position order
+  float qy[4], wx[4];
+};
+static_assert(sizeof(RsTapRec) == kRsTapRecBytes, "record size is part of the workspace layout (patch_mfma.h)");
+__global__ __launch_bounds__(256) void rs_tap_table_kernel(const float *__restrict__ in2, RsTapRec *__restrict__ tab,
+                                                          int HW, int W, int Hi, int Wi, int dil, int trunc,
+                                                          const unsigned *__restrict__ skip_stat, unsigned skip_limit) {
+  if (skip_stat) {
+    unsigned tot = 0;
 #pragma unroll
-    for (int r = 0; r < N; ++r) {
-      const A gr_ = go * qy[r];
-#pragma unroll
-      for (int q = 0; q < N; ++q) Where::add(gplane + ro[r] + co[q], gr_ * wx[q]);
-    }
-    gplane += plane_sz;
-    g += gstride;
+    for (int i = 0; i < 32; ++i) tot += skip_stat[i];
+    if (tot <= skip_limit) return;
   }
+  const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (p >= HW) return;
+  const int y = p / W, x = p - y * W;
+  const float *i2 = in2 + (int64_t)b * 3 * HW + p;
+  Taps<float, 2> t;
+  t.template init<true>(i2[0], i2[HW], i2[2 * HW], x, y, Hi, Wi, dil, (trunc & 1) != 0);
+  RsTapRec r;
+  unsigned ri[4], ci[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ri[j] = (unsigned)(t.row_off(j) / Wi);
+    ci[j] = (unsigned)t.col_off(j);
+    r.qy[j] = safe_div<float>(t.row_w(j), t.sum);
+    r.wx[j] = t.col_w(j);
+  }
+  r.rows[0] = ri[0] | ri[1] << 16, r.rows[1] = ri[2] | ri[3] << 16;
+  r.cols[0] = ci[0] | ci[1] << 16, r.cols[1] = ci[2] | ci[3] << 16;
+  tab[(int64_t)b * HW + p] = r;
 }
 
 // d/d input2 = d/d(dx, dy, sigma) for `nch` channels; returns the three partial results (linear in
@@ -225,7 +277,9 @@ struct RsOut {
   using type = typename std::conditional<MODE == 2, typename Num<T>::acc, T>::type;
 };
 
-template <typename T, int KH, int MODE, bool WIN>
+// FIX (MODE 1 only): the scatter planes are 64-bit fixed point (lds_plane.h) instead of double
+// TAB (MODE 1, KH 2, float): in2 points at the tap records of rs_tap_table_kernel instead of (dx, dy, sigma)
+template <typename T, int KH, int MODE, bool WIN, bool FIX = false, bool TAB = false>
 __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
                                                             const T *__restrict__ gout,
                                                             typename RsOut<T, MODE>::type *__restrict__ outp,
@@ -234,8 +288,11 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
                                                             int margin, const unsigned *__restrict__ skip_stat,
                                                             unsigned skip_limit) {
   using A = typename Num<T>::acc;
-  using PT = typename std::conditional<MODE == 1, lds_acc_t, A>::type;  // scatter planes are double
+  using PT = typename std::conditional<MODE == 1, typename std::conditional<FIX, lds_fix_t, lds_acc_t>::type, A>::type;
+  static_assert(!FIX || (MODE == 1 && std::is_same<A, float>::value), "fixed-point planes: float scatter only");
+  static_assert(!TAB || (MODE == 1 && KH == 2 && std::is_same<T, float>::value), "tap records: float scatter, kernel_size 4 / 5");
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  __shared__ unsigned s_amax;
   // adaptive dispatch (patch_mfma.hip): the matrix-core path took this launch when its statistic is within the limit
   if (skip_stat) {  // the statistic is a sum over 32 counters (patch_mfma.hip: kPmStatSlots)
     unsigned tot = 0;
@@ -263,6 +320,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
   if constexpr (MODE == 1) {
     zero_planes<PT>(planes, gc * win_sz);
+    if (FIX && threadIdx.x == 0) s_amax = 0;
   } else {
     for (int c = 0; c < gc; ++c)
       stage_planes<T, PT>(in1_0 + (int64_t)c * plane_sz + win.lo * Wi, planes + (size_t)c * win_sz, win_sz);
@@ -270,6 +328,45 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   __syncthreads();
   PT *planes0 = planes - win.lo * Wi;  // plane-relative offsets index the window
   const int lo_off = win.lo * Wi, hi_off = (win.lo + win.rows) * Wi;
+  FixScale fix{1.f, 1.0, true};
+  if constexpr (FIX) {  // every contribution is a gradient of this range times weights <= 1: its maximum sets the scale
+    unsigned m = 0;
+    for (int c = 0; c < gc; ++c) {
+      const T *go = gout + ((int64_t)b * C + c0 + c) * HW;
+      for (int p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) m = max(m, __float_as_uint(fabsf(Num<T>::ld(go + p))));
+    }
+    fix = fix_scale(block_umax(m, &s_amax));
+  }
+  if constexpr (TAB) {
+    // records one pixel ahead (a workgroup makes only a handful of passes of this loop)
+    const uint4 *rec = reinterpret_cast<const uint4 *>(in2) + (int64_t)b * HW * 3;
+    uint4 na{}, nb{}, nc{};
+    if (p_begin + (int)threadIdx.x < p_end) {
+      const uint4 *r = rec + (int64_t)(p_begin + threadIdx.x) * 3;
+      na = r[0], nb = r[1], nc = r[2];
+    }
+    for (int p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) {
+      const uint4 ra = na, rb = nb, rc = nc;
+      if (p + (int)blockDim.x < p_end) {
+        const uint4 *r = rec + (int64_t)(p + blockDim.x) * 3;
+        na = r[0], nb = r[1], nc = r[2];
+      }
+      const int ro[4] = {(int)(ra.x & 0xffff) * Wi, (int)(ra.x >> 16) * Wi, (int)(ra.y & 0xffff) * Wi, (int)(ra.y >> 16) * Wi};
+      const int co[4] = {(int)(ra.z & 0xffff), (int)(ra.z >> 16), (int)(ra.w & 0xffff), (int)(ra.w >> 16)};
+      const A qy[4] = {__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z), __uint_as_float(rb.w)};
+      const A wx[4] = {__uint_as_float(rc.x), __uint_as_float(rc.y), __uint_as_float(rc.z), __uint_as_float(rc.w)};
+      const bool inside = !WIN || (ro[0] >= lo_off && ro[3] < hi_off);
+      const T *go = gout + ((int64_t)b * C + c0) * HW + p;
+      if (inside) {
+        if constexpr (FIX)
+          rs_bwd1_apply<T, PT, 4, A, LdsFixPlane>(ro, co, qy, wx, go, HW, planes0, win_sz, gc, fix.up);
+        else
+          rs_bwd1_apply<T, PT, 4, A, LdsPlane>(ro, co, qy, wx, go, HW, planes0, win_sz, gc, (A)1);
+      } else {
+        rs_bwd1_apply<T, T, 4, A, GlobalPlane>(ro, co, qy, wx, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc, (A)1);
+      }
+    }
+  } else
   for (int p = p_begin + threadIdx.x; p < p_end; p += blockDim.x) {
     const int y = p / W, x = p - y * W;
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
@@ -286,9 +383,12 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
         rs_fwd_pixel<T, T, KH, A>(t, in1_0, plane_sz, o, HW, gc);
     } else if constexpr (MODE == 1) {
       const T *go = gout + ((int64_t)b * C + c0) * HW + p;
-      if (inside)
-        rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, go, HW, planes0, win_sz, gc);
-      else
+      if (inside) {
+        if constexpr (FIX)
+          rs_bwd1_pixel<T, PT, KH, A, LdsFixPlane>(t, go, HW, planes0, win_sz, gc, fix.up);
+        else
+          rs_bwd1_pixel<T, PT, KH, A, LdsPlane>(t, go, HW, planes0, win_sz, gc);
+      } else
         rs_bwd1_pixel<T, T, KH, A, GlobalPlane>(t, go, HW, outp + ((int64_t)b * C + c0) * plane_sz, plane_sz, gc);
     } else {
       A rx, ry, rs;
@@ -305,9 +405,13 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   }
   if constexpr (MODE == 1) {
     __syncthreads();
-    for (int c = 0; c < gc; ++c)
-      flush_planes<T>(outp + ((int64_t)b * C + c0 + c) * plane_sz + win.lo * Wi, planes + (size_t)c * win_sz, win_sz,
-                      split == 1 && margin < 0, (trunc & 2) != 0);  // bit 1 of the flag word: overwrite (host-checked)
+    for (int c = 0; c < gc; ++c) {  // bit 1 of the flag word: overwrite (host-checked)
+      T *dst = outp + ((int64_t)b * C + c0 + c) * plane_sz + win.lo * Wi;
+      if constexpr (FIX)
+        flush_planes_fix<T>(dst, planes + (size_t)c * win_sz, win_sz, split == 1 && margin < 0, (trunc & 2) != 0, fix);
+      else
+        flush_planes<T>(dst, planes + (size_t)c * win_sz, win_sz, split == 1 && margin < 0, (trunc & 2) != 0);
+    }
   }
 }
 
@@ -372,7 +476,7 @@ template <typename T>
 static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, typename Num<T>::acc *gin2, int64_t B,
                           int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k, int dil,
                           int trunc, gfla_stream_t stream_, const unsigned *skip_stat = nullptr,
-                          unsigned skip_limit = 0) {
+                          unsigned skip_limit = 0, void *tap_records = nullptr) {
   int st = check<T>(in1, in2, B, C, Hi, Wi, H, W, k, dil);
   if (st != GFLA_OK) return st;
   if (!gout) return GFLA_ERR_NULL_POINTER;
@@ -394,8 +498,32 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
     if (gin1) {
       const int64_t blocks = B * pg1.ngroups * pg1.split;
       if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) launch_lds(rs_lds_kernel<T, KH, 1, false>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit);
-                                else launch_lds(rs_lds_kernel<T, KH, 1, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit));
+#define GFLA_RS_SCATTER(FIX_)                                                                                                                                       \
+      GFLA_KH_SWITCH(k / 2, if (pg1.margin < 0) launch_lds(rs_lds_kernel<T, KH, 1, false, FIX_>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit); \
+                                else launch_lds(rs_lds_kernel<T, KH, 1, true, FIX_>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit))
+      // fixed-point planes (lds_plane.h); tuning key 23 = 1: round 1's double planes
+      if constexpr (std::is_same<T, float>::value) {
+        // scratch given, kernel_size 4 / 5: the per-pixel setup runs once (rs_tap_table_kernel); tuning key 23 = 2: never
+        if (tap_records && k / 2 == 2 && Hi <= 65535 && Wi <= 65535 && tuning(23) == 0) {
+          RsTapRec *tab = static_cast<RsTapRec *>(tap_records);
+          rs_tap_table_kernel<<<dim3((unsigned)ceil_div(H * W, 256), (unsigned)B), 256, 0, stream>>>(
+              in2, tab, (int)(H * W), (int)W, (int)Hi, (int)Wi, dil, trunc, skip_stat, skip_limit);
+          const float *recs = reinterpret_cast<const float *>(tab);
+          if (pg1.margin < 0)
+            launch_lds(rs_lds_kernel<T, 2, 1, false, true, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, recs, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit);
+          else
+            launch_lds(rs_lds_kernel<T, 2, 1, true, true, true>, dim3((unsigned)blocks), dim3(kLdsThreads), pg1.lds_bytes, stream, in1, recs, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, pg1.G, pg1.ngroups, pg1.split, pg1.per, pg1.margin, skip_stat, skip_limit);
+        } else if (tuning(23) == 1) {
+          GFLA_RS_SCATTER(false);
+        } else {
+          GFLA_RS_SCATTER(true);
+        }
+      } else if constexpr (std::is_same<A, float>::value) {
+        GFLA_RS_SCATTER(true);
+      } else {
+        GFLA_RS_SCATTER(false);
+      }
+#undef GFLA_RS_SCATTER
       st = launch_status();
       if (st != GFLA_OK) return st;
     }
@@ -494,7 +622,8 @@ int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, 
     }
     if (!g1 && !g2) return GFLA_OK;
   }
-  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st, skip_stat, skip_limit);
+  void *taps = (workspace && g1) ? static_cast<unsigned char *>(workspace) + gfla::pm_table_bytes(B, H, W, k * k) : nullptr;
+  return gfla::resample2d_bwd<float>(a, b, go, g1, g2, B, C, Hi, Wi, H, W, k, d, trunc, st, skip_stat, skip_limit, taps);
 }
 /* bf16 storage: grad_in1 bf16; grad_in2 (B,3,H,W) FLOAT32 (a reduction over the channels) */
 int gfla_resample2d_bwd_bf16(const uint16_t *a, const uint16_t *b, const uint16_t *go, uint16_t *g1, float *g2, int64_t B,

@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rows", default="0,1,2,4")
     ap.add_argument("--flows", default="zero,smooth,coherent,wild")
+    ap.add_argument("--tuning", default="", help="key=value,... applied before anything runs")
     args = ap.parse_args()
+    for kv in filter(None, args.tuning.split(",")):
+        _lib.lib().gfla_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     lib = _lib.lib()
     B = 32
     for kind in args.flows.split(","):
@@ -44,7 +47,6 @@ def main():
             row = {"op": "aggregate d/d source", "shape": name, "flow": kind, "lds_atomic_us": round(time_fn(lambda: run(None), args.iters), 1)}
             row["adaptive_us"] = round(time_fn(lambda: run(ws), args.iters), 1)
             torch.cuda.synchronize()
-            row["rows_per_tile"] = round(int(ws[-256:-128].view(torch.int32).sum().item()) / (B * ((H * W + 31) // 32)), 2)
             lib.gfla_set_tuning(15, 100000)  # always the matrix-core path
             for r in args.rows.split(","):
                 lib.gfla_set_tuning(13, int(r))
@@ -64,10 +66,21 @@ def main():
             def run(w):
                 _lib.call("gfla_resample2d_bwd_ws_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(g1), None,
                           _lib.ptr(w), *tail)
+            g_fix = None
+            run(None)
+            g_fix = g1.clone()
             row = {"op": "resample2d d/d input1", "shape": name, "flow": kind, "lds_atomic_us": round(time_fn(lambda: run(None), args.iters), 1)}
+            lib.gfla_set_tuning(23, 1)      # round 1's double planes instead of the fixed-point ones
+            g1.zero_()
+            run(None)
+            row["fix_vs_f64_maxdiff"] = float((g1 - g_fix).abs().max() / g1.abs().max())
+            row["lds_atomic_f64_us"] = round(time_fn(lambda: run(None), args.iters), 1)
+            lib.gfla_set_tuning(23, 0)
+            g1.zero_()
+            run(ws)
+            row["ws_vs_nows_maxdiff"] = float((g1 - g_fix).abs().max() / g_fix.abs().max())
             row["adaptive_us"] = round(time_fn(lambda: run(ws), args.iters), 1)
             torch.cuda.synchronize()
-            row["rows_per_tile"] = round(int(ws[-256:-128].view(torch.int32).sum().item()) / (B * ((H * W + 31) // 32)), 2)
             lib.gfla_set_tuning(15, 100000)
             for r in args.rows.split(","):
                 lib.gfla_set_tuning(13, int(r))
