@@ -241,11 +241,13 @@ __device__ __forceinline__ FixScale fix_scale(unsigned amax_bits) {
   f.finite = amax_bits < 0x7f800000u;
   return f;
 }
-__device__ __forceinline__ void lds_add_fix(lds_fix_t *p, float v_scaled) {
-  const double d = (double)v_scaled + 6755399441055744.0;   // 1.5 * 2^52: the integer lands in the low mantissa bits
+constexpr double kFixMagic = 6755399441055744.0;   // 1.5 * 2^52: (x + magic) carries rint(x) in its low mantissa bits
+// d = x + kFixMagic, |x| < 2^51
+__device__ __forceinline__ void lds_add_fix_biased(lds_fix_t *p, double d) {
   const unsigned long long bits = (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
   __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void lds_add_fix(lds_fix_t *p, float v_scaled) { lds_add_fix_biased(p, (double)v_scaled + kFixMagic); }
 // workgroup-wide maximum of `v` through the LDS word `slot` (zeroed by the caller before its last barrier)
 __device__ __forceinline__ unsigned block_umax(unsigned v, unsigned *slot) {
 #pragma unroll
