@@ -846,6 +846,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle check + baseline)")
     ap.add_argument("--no-variants", action="store_true", help="skip the labelled variants (other FC arithmetic modes)")
+    ap.add_argument("--tuning", default="", help="library tuning keys for A/B runs: key=value[,key=value...] (include/gfla_hip.h)")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the compact legs for the other BASELINE configs (config-3 inference, with-losses, trainer "
                          "step, face bf16) that the default N=1 run appends under `legs`")
@@ -887,6 +888,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     device = torch.device("cuda", local)
+    for kv in filter(None, args.tuning.split(",")):
+        gfla.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     if args.fc_impl == "library":  # round 1's path (rocBLAS / MIOpen FC layers), kept as a cross-check only
         torch.backends.cudnn.benchmark = True
 

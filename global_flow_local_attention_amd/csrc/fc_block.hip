@@ -143,10 +143,12 @@ static int fc_forward(const float *source, const float *target, const float *flo
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
   if (wino) {
     GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
-    GFLA_TRY(fc_wino_conv(xs, reinterpret_cast<const float *>(ws + L.wu_fs), gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden,
-                          B, L.nch_c, L.hs.Mv, L.hs.Wo, L.hs.Wp, L.hs.Sx, k, stream));
-    GFLA_TRY(fc_wino_conv(xt, reinterpret_cast<const float *>(ws + L.wu_ft), gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden,
-                          B, L.nch_c, L.ht.Mv, L.ht.Wo, L.ht.Wp, L.ht.Sx, k, stream));
+    const WnConvJob jobs[2] = {   // both halves in one launch (fc_wino.hip: they share the half-empty last round)
+        {xs, reinterpret_cast<const float *>(ws + L.wu_fs), gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, L.hs.Mv, L.hs.Wo,
+         L.hs.Wp, L.hs.Sx},
+        {xt, reinterpret_cast<const float *>(ws + L.wu_ft), gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, L.ht.Mv, L.ht.Wo,
+         L.ht.Wp, L.ht.Sx}};
+    GFLA_TRY(fc_wino_conv_jobs(jobs, 2, B, L.nch_c, k, stream));
   } else {
     GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
     const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
@@ -163,7 +165,7 @@ static int fc_forward(const float *source, const float *target, const float *flo
 // Z-layout gradient map
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
                             float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode_,
-                            hipStream_t stream, int acc_x = 0) {
+                            hipStream_t stream, int acc_x = 0, bool dgrad_done = false) {
   const bool wino = mode_ == 4;
   const int mode = fc_base_mode(mode_);
   const bool want_w = g_w0 != nullptr;
@@ -186,8 +188,9 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   if (g_x) {
     float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
     if (wino) {
-      GFLA_TRY(fc_wino_conv(Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C,
-                            C, B, nch_h, g.Md, g.Wp, g.Wp, g.Sz, k, stream));
+      if (!dgrad_done)
+        GFLA_TRY(fc_wino_conv(Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C,
+                              C, B, nch_h, g.Md, g.Wp, g.Wp, g.Sz, k, stream));
     } else {
       const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
       GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
@@ -253,10 +256,22 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
     if (g_b1 && hipMemcpyAsync(g_b1, red + 32 * kFcHidden, (size_t)L.KK * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
       return GFLA_ERR_LAUNCH;
   }
+  // mode 4: the data-gradient convolutions of both halves in one launch (fc_wino.hip)
+  const bool both_dgrads = mode_ == 4 && g_source && g_target;
+  if (both_dgrads) {
+    const int nch_h = kFcHidden / kFcChunk;
+    const WnConvJob jobs[2] = {
+        {fc_desc_nhwc(dzs, L.hs.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_ds),
+         reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
+        {fc_desc_nhwc(dzt, L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
+         reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
+    GFLA_TRY(fc_wino_conv_jobs(jobs, 2, B, nch_h, k, stream));
+  }
   if (need_s)
     GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode_, stream,
-                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0));
-  if (need_t) GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream));
+                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads));
+  if (need_t)
+    GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream, 0, both_dgrads));
   if (g_w0 && mode != 0) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),

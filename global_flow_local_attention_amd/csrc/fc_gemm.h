@@ -156,6 +156,15 @@ int64_t fc_wino_wpack_bytes(int n_in, int n_out);
 int fc_wino_pack_weights(const float *w0, float *u_ft, float *u_fs, float *u_dt, float *u_ds, int C, int k,
                          hipStream_t stream);
 bool fc_wino_fits(int M, int Wv, int Wp, int k);
+struct WnConvJob {   // one convolution of fc_wino_conv_jobs: the arguments of fc_wino_conv that may differ between the jobs
+  PackedDesc X;
+  const float *U;
+  float *out;
+  int64_t out_bs;
+  int ldo, n_valid, M, Wv, Wp;
+  int64_t S;
+};
+int fc_wino_conv_jobs(const WnConvJob *jobs, int njobs, int64_t B, int nch, int k, hipStream_t stream);
 int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
                  int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream);
 int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k);

@@ -26,6 +26,7 @@
 //   epilogue: A^T M A: each wave reduces its three point rows to an m x m partial per (tile, channel) in registers, the
 //   wave pairs swap partials through LDS, stores go to the same (pixel, channel) f32 map fc_conv writes.
 #include "fc_gemm.h"
+#include <algorithm>
 
 namespace gfla {
 
@@ -227,13 +228,39 @@ typedef Half0 No;
 // 6 x 6 point grid), both 16-tile blocks: 18 x 2 accumulators of 16x16 = 144 registers, two waves per SIMD.  Waves w and
 // w + 4 sit on the same SIMD and run the two halves of a step in OPPOSITE order -- one multiplies (matrix cores) while the
 // other transforms the next step's input (vector ALUs, LDS).
+//
+// One launch carries up to TWO independent convolutions (the target and the source half of a layer: same weights' shape,
+// different maps): workgroups [0, n0) belong to job 0, the rest to job 1.  A workgroup lives for ~1/6 of a launch, so a
+// launch of 5.5 or 6.4 rounds of 256 workgroups spends its last round half empty; two jobs in one grid share that tail
+// (L2, k = 5: 6 + 7 and 7 + 8 rounds become 12 and 14).
+struct WnKArgs {
+  PackedDesc X;
+  const float *U;
+  float *out;
+  int64_t out_bs;
+  int ldo, n_valid, Ho, Wv, Wp;
+  WnGeo geo;
+  int ntn;
+  int64_t total_groups, S;
+};
 template <int KS, int DBG = 0, bool DB = true>
-__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc X, const float *__restrict__ U,
-                                                                    float *__restrict__ out, int64_t out_bs, int ldo,
-                                                                    int n_valid, int Ho, int Wv, int Wp, int nch,
-                                                                    WnGeo geo, int ntn, int64_t total_groups, int64_t S,
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0, WnKArgs a1, unsigned n0, int nch,
                                                                     unsigned long long *stamps) {
   constexpr int M = Wn<KS>::M, PITCH = Wn<KS>::PITCH, NX = kWnXi / 2;
+  // the job's parameters: workgroup-uniform selects (scalar registers)
+  const bool second = blockIdx.x >= n0;
+#define GFLA_PICK(f) (second ? a1.f : a0.f)
+  PackedDesc X;
+  X.base = GFLA_PICK(X.base), X.split_stride = 0, X.batch_stride = GFLA_PICK(X.batch_stride);
+  X.chunk_stride = GFLA_PICK(X.chunk_stride), X.pix_stride = GFLA_PICK(X.pix_stride);
+  const float *__restrict__ U = GFLA_PICK(U);
+  float *__restrict__ out = GFLA_PICK(out);
+  const int64_t out_bs = GFLA_PICK(out_bs), total_groups = GFLA_PICK(total_groups), S = GFLA_PICK(S);
+  const int ldo = GFLA_PICK(ldo), n_valid = GFLA_PICK(n_valid), Ho = GFLA_PICK(Ho), Wv = GFLA_PICK(Wv), Wp = GFLA_PICK(Wp);
+  const int ntn = GFLA_PICK(ntn);
+  WnGeo geo;
+  geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.ngroups = GFLA_PICK(geo.ngroups), geo.span = GFLA_PICK(geo.span);
+#undef GFLA_PICK
   // DBG & 16: per-wave phase timing (s_memtime) summed over the steps -> stamps[workgroup][wave][6]
   unsigned long long tk0 = 0, t_first = 0, t_second = 0, t_bar = 0, t_pro = 0, t_epi = 0;
   if constexpr (DBG & 16) tk0 = __builtin_amdgcn_s_memtime();
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(PackedDesc 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nb = wave & 3, xh = wave >> 2;
   // workgroup -> (group of tiles, output-channel tile).  Ids x and x + 8 run on the same XCD: the workgroups that
   // share one group's input pixels (different channel tiles) are neighbours in that XCD's queue (shared L2).
-  const int64_t x = blockIdx.x;
+  const int64_t x = blockIdx.x - (second ? n0 : 0u);   // n0 is a multiple of 8: id & 7 is still the XCD
   const int xcd = (int)(x & 7);
   const int64_t slot = x >> 3;
   const int ntile = (int)(slot % ntn);
@@ -526,43 +553,65 @@ bool fc_wino_fits(int M, int Wv, int Wp, int k) {
 // with the weights given as the transformed U of fc_wino_pack_weights.  S = pixels per sample X may be read for.
 static unsigned long long *g_wino_stamps = nullptr;  // timing probe buffer (gfla_fc_wino_debug_buffer; tools only)
 
-int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
-                 int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream) {
-  if (B <= 0) return GFLA_OK;
+template <int K_>
+static int wn_launch(const WnConvJob *jobs, int njobs, int64_t B, int nch, hipStream_t stream) {
   unsigned long long *stamps = g_wino_stamps;
-  if (!fc_wino_fits(M, Wv, Wp, k)) return GFLA_ERR_UNSUPPORTED;
-  const int ntn = (int)ceil_div(n_valid, kWnN);
-#define GFLA_WINO_LAUNCH(K_, D_, DB_)                                                                                   \
+  WnKArgs a[2];
+  int64_t wgs[2] = {0, 0};
+  bool db = tuning(21) != 1;
+  unsigned lds = 0;
+  for (int j = 0; j < njobs; ++j) db = db && wn_lds_bytes<K_>(wn_geometry<K_>(jobs[j].M, jobs[j].Wv, jobs[j].Wp), true) <= kWnLdsLimit;
+  for (int j = 0; j < 2; ++j) {
+    const WnConvJob &J = jobs[j < njobs ? j : 0];
+    const WnGeo g = wn_geometry<K_>(J.M, J.Wv, J.Wp);
+    const int ntn = (int)ceil_div(J.n_valid, kWnN);
+    const int64_t groups = B * g.ngroups;
+    a[j] = WnKArgs{J.X, J.U, J.out, J.out_bs, J.ldo, J.n_valid, J.M / J.Wv, J.Wv, J.Wp, g, ntn, groups, J.S};
+    if (j < njobs) {
+      wgs[j] = ceil_div(groups, 8) * 8 * ntn;
+      lds = std::max(lds, wn_lds_bytes<K_>(g, db));
+    }
+  }
+  if (wgs[0] + wgs[1] > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+#define GFLA_WINO_LAUNCH(D_, DB_)                                                                                       \
   {                                                                                                                    \
     auto kern = fc_wino_conv_kernel<K_, D_, DB_>;                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    kern<<<dim3((unsigned)wgs), kWnThreads, lds, stream>>>(X, U, out, out_bs, ldo, n_valid, M / Wv, Wv, Wp, nch, g, ntn, groups, S, stamps); \
+    kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, stamps);     \
   }
-#define GFLA_WINO(K_)                                                                                                  \
-  {                                                                                                                    \
-    const WnGeo g = wn_geometry<K_>(M, Wv, Wp);                                                                        \
-    const bool db = wn_lds_bytes<K_>(g, true) <= kWnLdsLimit && tuning(21) != 1;                                       \
-    const unsigned lds = wn_lds_bytes<K_>(g, db);                                                                      \
-    const int64_t groups = B * g.ngroups;                                                                              \
-    const int64_t wgs = ceil_div(groups, 8) * 8 * ntn;                                                                 \
-    if (wgs > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;                                                               \
-    if (!db) GFLA_WINO_LAUNCH(K_, 0, false)                                                                            \
-    else switch (K_ == 5 ? tuning(20) : 0) { /* timing ablations of the k = 5 kernel (results are garbage) */         \
-      case 1: GFLA_WINO_LAUNCH(K_, 1, true) break;                                                                     \
-      case 2: GFLA_WINO_LAUNCH(K_, 2, true) break;                                                                     \
-      case 4: GFLA_WINO_LAUNCH(K_, 4, true) break;                                                                     \
-      case 8: GFLA_WINO_LAUNCH(K_, 8, true) break;                                                                     \
-      case 3: GFLA_WINO_LAUNCH(K_, 3, true) break;                                                                     \
-      case 16: GFLA_WINO_LAUNCH(K_, 16, true) break;                                                                   \
-      case 5: GFLA_WINO_LAUNCH(K_, 5, true) break;                                                                     \
-      case 13: GFLA_WINO_LAUNCH(K_, 13, true) break;                                                                   \
-      default: GFLA_WINO_LAUNCH(K_, 0, true) break;                                                                    \
-    }                                                                                                                  \
+  if (!db) GFLA_WINO_LAUNCH(0, false)
+  else switch (K_ == 5 ? tuning(20) : 0) { /* timing ablations of the k = 5 kernel (results are garbage) */
+    case 1: GFLA_WINO_LAUNCH(1, true) break;
+    case 2: GFLA_WINO_LAUNCH(2, true) break;
+    case 4: GFLA_WINO_LAUNCH(4, true) break;
+    case 8: GFLA_WINO_LAUNCH(8, true) break;
+    case 3: GFLA_WINO_LAUNCH(3, true) break;
+    case 16: GFLA_WINO_LAUNCH(16, true) break;
+    case 5: GFLA_WINO_LAUNCH(5, true) break;
+    case 13: GFLA_WINO_LAUNCH(13, true) break;
+    default: GFLA_WINO_LAUNCH(0, true) break;
   }
-  if (k == 5) GFLA_WINO(5) else GFLA_WINO(3)
 #undef GFLA_WINO_LAUNCH
-#undef GFLA_WINO
   return launch_status();
+}
+
+// one or two convolutions (same B, input chunks nch, k) in one launch; tuning key 21 = 2: one launch per job
+int fc_wino_conv_jobs(const WnConvJob *jobs, int njobs, int64_t B, int nch, int k, hipStream_t stream) {
+  if (B <= 0 || njobs <= 0) return GFLA_OK;
+  if (njobs > 2) return GFLA_ERR_UNSUPPORTED;
+  for (int j = 0; j < njobs; ++j)
+    if (!fc_wino_fits(jobs[j].M, jobs[j].Wv, jobs[j].Wp, k)) return GFLA_ERR_UNSUPPORTED;
+  if (njobs == 2 && tuning(21) == 2) {
+    const int st = fc_wino_conv_jobs(jobs, 1, B, nch, k, stream);
+    return st != GFLA_OK ? st : fc_wino_conv_jobs(jobs + 1, 1, B, nch, k, stream);
+  }
+  return k == 5 ? wn_launch<5>(jobs, njobs, B, nch, stream) : wn_launch<3>(jobs, njobs, B, nch, stream);
+}
+
+int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
+                 int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream) {
+  const WnConvJob job{X, U, out, out_bs, ldo, n_valid, M, Wv, Wp, S};
+  return fc_wino_conv_jobs(&job, 1, B, nch, k, stream);
 }
 
 // =====================================================================================================================
