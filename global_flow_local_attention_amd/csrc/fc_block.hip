@@ -18,7 +18,7 @@ struct FcLayout {
   // forward workspace, kept for backward
   int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, wu_ft, wu_fs, wu_dt, wu_ds, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
-  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, splat, bwd_total;
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, bwd_total;
 };
 
 static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
@@ -83,7 +83,6 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
     if (w > dwp) dwp = w;
   }
   L.dwp = take(dwp);
-  L.splat = take(fc_splat_scratch_bytes(B, H, W, k));   // cell lists of the source map's gradient (fc_splat.hip)
   L.bwd_total = o;
   return L;
 }
@@ -233,29 +232,18 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
+  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
   const float *gs = reinterpret_cast<const float *>(ws + L.gs);
   const float *hid = reinterpret_cast<const float *>(ws + L.hid);
   const bool need_s = g_source || g_w0, need_t = g_target || g_w0;
-  // the source map's gradient: gathered from per-step cell lists (fc_splat.hip; it writes the whole map, zeros included),
-  // or -- tuning key 18 = 1 -- scattered with float atomics by the tail kernel into a zeroed map
-  const bool gather = need_s && tuning(18) != 1;
-  if (gather) {
-    if (hipMemsetAsync(sc + L.dzt, 0, L.zero_bytes - L.dzt, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-    if (hipMemsetAsync(sc + L.splat, 0, fc_splat_zero_bytes(B, H, W, k), stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  } else if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) {
-    return GFLA_ERR_LAUNCH;
-  }
-  if (hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
   float *dzs = need_s ? reinterpret_cast<float *>(sc + L.dzs) : nullptr;
-  float *dzt = (need_t || gather) ? reinterpret_cast<float *>(sc + L.dzt) : nullptr;
+  float *dzt = need_t ? reinterpret_cast<float *>(sc + L.dzt) : nullptr;
   float *b0p = g_b0 ? reinterpret_cast<float *>(sc + L.b0p) : nullptr;
   const int64_t tiles = ceil_div((int64_t)H * W, 64);
-  GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, gather ? nullptr : dzs, dzt, g_flow, b0p, B, H, W, k,
-                              L.hs.Mg * kFcHidden, L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden,
-                              L.hs.lead, L.ht.lead, slope, flags & GFLA_FC_ACCUMULATE_FLOW, stream));
-  if (gather)
-    GFLA_TRY(fc_splat_gather(flow, dzt, dzs, sc + L.splat, B, H, W, k, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden,
-                             L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, L.hs.Sz, stream));
+  GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
+                              L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
+                              flags & GFLA_FC_ACCUMULATE_FLOW, stream));
   float *red = reinterpret_cast<float *>(sc + L.red);
   float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
   if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, red_tmp, stream));

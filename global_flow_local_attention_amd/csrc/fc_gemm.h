@@ -156,12 +156,6 @@ int64_t fc_wino_wpack_bytes(int n_in, int n_out);
 int fc_wino_pack_weights(const float *w0, float *u_ft, float *u_fs, float *u_dt, float *u_ds, int C, int k,
                          hipStream_t stream);
 bool fc_wino_fits(int M, int Wv, int Wp, int k);
-// fc_splat.hip: the gradient of the sampled source map as a gather over per-step cell lists (no float atomics)
-int64_t fc_splat_scratch_bytes(int64_t B, int H, int W, int k);
-int64_t fc_splat_zero_bytes(int64_t B, int H, int W, int k);
-int fc_splat_gather(const float *flow, const float *dzt, float *dzs, void *scratch, int64_t B, int H, int W, int k, int wpz,
-                    int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, int64_t sz, hipStream_t stream);
-
 struct WnConvJob {   // one convolution of fc_wino_conv_jobs: the arguments of fc_wino_conv that may differ between the jobs
   PackedDesc X;
   const float *U;
