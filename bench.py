@@ -502,7 +502,8 @@ def fc_kernel_probes(hp, iters=10):
     (H+k-1) x (W+k-1), the data gradient runs on the padded domain), which is NOT counted as achieved work."""
     from global_flow_local_attention_amd import fc_mfma
     names = ("conv fwd source", "conv fwd target", "data-grad source", "data-grad target", "weight-grad source",
-             "weight-grad target")
+             "weight-grad target", "conv fwd source + target (one launch, as in the step)",
+             "data-grad source + target (one launch, as in the step)")
     rows = []
     for mod, (src, tgt, flow) in zip(hp.attn, hp.inputs):
         mode = getattr(mod, "fc_mode", None)
@@ -527,7 +528,10 @@ def fc_kernel_probes(hp, iters=10):
                       _lib.ptr(gs), _lib.ptr(gt), _lib.ptr(gf), _lib.ptr(gw0), None, None, None, B, C, H, W, k, 0.1, mode, 0)
             stream = torch.cuda.current_stream(s.device)
             flops = 2.0 * B * H * W * C * k * k * 128
+            layer_rows = []
             for which, nm in enumerate(names):
+                if which > 5 and mode != 4:
+                    continue
                 for _ in range(2):
                     _lib.call("gfla_fc_kernel_f32", s, which, _lib.ptr(ws), _lib.ptr(sc), B, C, H, W, k, mode)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -538,7 +542,15 @@ def fc_kernel_probes(hp, iters=10):
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / iters * 1e3
                 row = {"dims": [B, C, H, W, k], "avg_us": round(us, 1)}
-                if mode == 4 and (which < 4 or k == 5):   # (k = 3 weight gradient: the direct kernel, csrc/fc_block.hip)
+                if which > 5:   # two jobs in one launch: the sums of the two halves' rows above
+                    halves = layer_rows[0:2] if which == 6 else layer_rows[2:4]
+                    done = sum(r["alg_GFLOP"] for r in halves) * 1e9
+                    eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
+                    kern = "fc_wino_conv_kernel"
+                    row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
+                                "in_step": True})
+                elif mode == 4 and (which < 4 or k == 5):   # (k = 3 weight gradient: the direct kernel, csrc/fc_block.hip)
                     # Winograd domain: the kernel EXECUTES 36 multiplies per (tile, c, n) -- F(2x2,5x5): 2x2 outputs per
                     # tile, F(4x4,3x3): 4x4.  `TFLOPs` / `frac` are these executed MFMA flops against the f32 peak (what the
                     # hardware does); `effective_TFLOPs` = the reference formulation's flops / time (what the caller gets).
@@ -556,6 +568,7 @@ def fc_kernel_probes(hp, iters=10):
                 row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
                 row["frac_mfma_f32_peak"] = round(row["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
                 rows.append(row)
+                layer_rows.append(row)
     return rows
 
 
@@ -795,6 +808,17 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
         # with the longest launch
         dom = max(probes, key=lambda r: r["avg_us"])
+        step_rows = [r for r in probes if r.get("in_step") and r["dims"] == dom["dims"]]
+        if dom.get("in_step") and len(step_rows) > 1:
+            # the step launches this kernel twice per layer (forward of both halves, data gradient of both halves): the
+            # object describes the kernel over both launches, so its average duration is the one a kernel trace shows
+            tus = sum(r["avg_us"] for r in step_rows)
+            alg, eff = sum(r["alg_GFLOP"] for r in step_rows), sum(r["effective_GFLOP"] for r in step_rows)
+            dom = dict(dom, kernel=dom["kernel"].split(":")[0] + ": both launches of the step (forward and data gradient, "
+                                   "source + target halves in one launch each)",
+                       avg_us=round(tus / len(step_rows), 1), alg_GFLOP=round(alg / len(step_rows), 2),
+                       TFLOPs=round(alg * 1e9 / (tus * 1e-6) / 1e12, 1), effective_TFLOPs=round(eff * 1e9 / (tus * 1e-6) / 1e12, 1))
+            dom["frac_mfma_f32_peak"] = round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "dims": dom["dims"],
                             "achieved": dom["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],

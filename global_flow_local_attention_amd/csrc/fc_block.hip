@@ -394,11 +394,12 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
 
 /* ONE internal kernel of the path, on the state a forward + backward of the same shape left in workspace / scratch:
  * per-kernel timing for bench.py and the profiles (results land in scratch areas the next real call overwrites).
- * which: 0 / 1 convolution forward source / target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient. */
+ * which: 0 / 1 convolution forward source / target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient;
+ * mode 4 only: 6 / 7 = the forward / data-gradient convolutions of BOTH halves in one launch, as the step issues them. */
 int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C_, int64_t H_, int64_t W_,
                        int kernel_size, int mode, gfla_stream_t stream_) {
   if (!workspace || !scratch) return GFLA_ERR_NULL_POINTER;
-  if (which < 0 || which > 5) return GFLA_ERR_BAD_SHAPE;
+  if (which < 0 || which > 7 || (which > 5 && mode != 4)) return GFLA_ERR_BAD_SHAPE;
   const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
   if (B == 0) return GFLA_OK;
@@ -407,6 +408,22 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
   const bool source = (which & 1) == 0;
   const FcHalf &g = source ? L.hs : L.ht;
   unsigned char *ws = static_cast<unsigned char *>(workspace), *sc = static_cast<unsigned char *>(scratch);
+  if (which == 6) {
+    const WnConvJob jobs[2] = {
+        {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, 0), reinterpret_cast<const float *>(ws + L.wu_fs),
+         reinterpret_cast<float *>(ws + L.gs), L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, L.hs.Mv, L.hs.Wo, L.hs.Wp, L.hs.Sx},
+        {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, 0), reinterpret_cast<const float *>(ws + L.wu_ft),
+         reinterpret_cast<float *>(ws + L.gt), L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, L.ht.Mv, L.ht.Wo, L.ht.Wp, L.ht.Sx}};
+    return fc_wino_conv_jobs(jobs, 2, B, L.nch_c, k, stream);
+  }
+  if (which == 7) {
+    const WnConvJob jobs[2] = {
+        {fc_desc_nhwc(reinterpret_cast<float *>(sc + L.dzs), L.hs.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_ds),
+         reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
+        {fc_desc_nhwc(reinterpret_cast<float *>(sc + L.dzt), L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
+         reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
+    return fc_wino_conv_jobs(jobs, 2, B, kFcHidden / kFcChunk, k, stream);
+  }
   if (mode == 4) {
     const PackedDesc X4 = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, 0);
     const PackedDesc Z4 = fc_desc_nhwc(reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz, kFcHidden);

@@ -463,12 +463,22 @@ __global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ 
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 64 * W; i += 256) {
-    const int cl = i / W, x = i - cl * W;
-    if (c0 + cl >= C) break;
-    float *g = grad + ((b * C + c0 + cl) * H + y) * (int64_t)W + x;
-    const float v = tile[cl * (W + 1) + x];
-    *g = accumulate ? *g + v : v;
+  // four elements per thread and pass: when accumulating, their four loads are one round trip instead of four
+  const int n = min(64, C - c0) * W;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+    float *g[4];
+    float v[4], old[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + 256 * u, n - 1);
+      const int cl = i / W, x = i - cl * W;
+      g[u] = grad + ((b * C + c0 + cl) * H + y) * (int64_t)W + x;
+      v[u] = tile[cl * (W + 1) + x];
+      old[u] = accumulate ? *g[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + 256 * u < n) *g[u] = old[u] + v[u];
   }
 }
 

@@ -112,3 +112,42 @@ def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W):
     assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), (f1.double().abs() * dG.double().abs()).sum().item() * 1e-3)
     wlhs = (gw[:, C:].double() * w0[:, C:].double()).sum().item()
     assert abs(wlhs - lhs) <= 2e-5 * max(abs(lhs), (f1.double().abs() * dG.double().abs()).sum().item() * 1e-3)
+
+
+@pytest.mark.parametrize("k,B,C,H,W", [(5, 3, 24, 11, 9), (3, 2, 40, 9, 14), (5, 2, 128, 64, 44)])
+def test_two_job_launch_equals_one_launch_per_half(gfla, k, B, C, H, W):
+    """gfla_fc_forward / gfla_fc_backward issue the convolutions of the target and the source half as ONE launch (workgroups
+    [0, n0) = job 0, the rest job 1; csrc/fc_wino.hip).  Tuning key 21 = 2 launches them separately: every output must be
+    bit-identical (the jobs share nothing but the grid)."""
+    from global_flow_local_attention_amd import _lib, fc_mfma
+    mode = 4
+    if fc_mfma.resolve_mode(C, H, W, k, mode) != 4:
+        pytest.skip("shape falls back to the direct kernels")
+    s, t = randn((B, C, H, W), seed=1).to(DEV), randn((B, C, H, W), seed=2).to(DEV)
+    f = (randn((B, 2, H, W), seed=3) * 1.5).to(DEV)
+    w0, w1 = (randn((128, 2 * C, k, k), seed=4) * 0.05).to(DEV), (randn((k * k, 128), seed=5) * 0.1).to(DEV)
+    gl = (randn((B, k * k, H, W), seed=6) * 1e-2).to(DEV)
+
+    def run():
+        ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=DEV)
+        sc = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=DEV)
+        logits = torch.empty(B, k * k, H, W, device=DEV)
+        gs, gt, gf, gw0 = torch.zeros_like(s), torch.empty_like(t), torch.zeros_like(f), torch.empty_like(w0)
+        _lib.call("gfla_fc_forward_f32", s, _ptr(s), _ptr(t), _ptr(f), _ptr(w0), None, _ptr(w1), None, _ptr(ws), _ptr(logits),
+                  B, C, H, W, k, 0.1, mode)
+        _lib.call("gfla_fc_backward_f32", s, _ptr(ws), _ptr(f), _ptr(w1), _ptr(gl), _ptr(sc), _ptr(gs), _ptr(gt), _ptr(gf),
+                  _ptr(gw0), None, None, None, B, C, H, W, k, 0.1, mode, 0)
+        torch.cuda.synchronize()
+        return logits, gs, gt, gw0
+
+    merged = run()
+    old = gfla.set_tuning(21, 2)
+    try:
+        separate = run()
+    finally:
+        gfla.set_tuning(21, old)
+    for name, a, b in zip(("logits", "grad_source", "grad_target", "grad_w0"), merged, separate):
+        if name in ("grad_source", "grad_w0"):  # behind the splat into the source map's gradient: float atomics, whose
+            assert rel_err(a, b) < 1e-6, name   # order moves the last bits from run to run
+        else:
+            assert torch.equal(a, b), name
