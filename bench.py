@@ -415,10 +415,11 @@ def pmc_traffic(entry, dims, ptrs=""):
     return total
 
 
-def pmc_traffic_kernel(kernel_label):
+def pmc_traffic_kernel(kernel_label, in_step=False):
     """HBM bytes per launch of one FC kernel from the committed PMC profile (profiles/pmc_traffic.json), matched by the
     kernel template and the layer's kernel size; when several launches match (source / target half, forward / data
-    gradient of the convolution kernel) the LARGEST is reported, i.e. an upper bound for the probed launch."""
+    gradient of the convolution kernel) the LARGEST is reported, i.e. an upper bound for the probed launch.
+    in_step: the mean of the two largest grids = the two two-job launches of the step (forward, data gradient)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
@@ -438,6 +439,9 @@ def pmc_traffic_kernel(kernel_label):
             rows += rs
     if not rows:
         return None
+    if in_step and len(rows) >= 2 and all("grid" in r for r in rows):
+        top = sorted(rows, key=lambda r: -int(r["grid"]))[:2]
+        return int(sum(r["traffic_bytes"] for r in top) / 2)
     return max(r["traffic_bytes"] for r in rows)
 
 
@@ -824,7 +828,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                             "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
                             **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
-                            "traffic": pmc_traffic_kernel(dom["kernel"]),
+                            "traffic": pmc_traffic_kernel(dom["kernel"], in_step=bool(dom.get("in_step"))),
                             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                               "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
                             "flops": ("Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "

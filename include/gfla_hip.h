@@ -64,7 +64,12 @@ const char *gfla_status_string(int status);
  *   key 5: split, workgroups sharing one (b, channel group) (0 auto)
  *   key 6: resample2d fwd/bwd        0 auto, 1 force global kernels
  *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)
- *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)                                     */
+ *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)
+ *   key 19: FC weight gradient in arithmetic mode 4   0 auto (Winograd domain for k = 5), 1 direct, 2 Winograd
+ *   key 20: timing ablations of the Winograd convolution kernel (results are garbage; tools/probe_wino.py)
+ *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one
+ *   key 23: resample2d d/d input1 LDS planes   0 fixed point + tap records (with scratch), 1 double planes (round 1)
+ * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 
 /* Dispatch trace (tests): number of times a kernel path has been enqueued by this process, from any host thread
