@@ -188,7 +188,7 @@ def set_tuning(key, value):
     return lib().gfla_set_tuning(int(key), int(value))
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
 PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_COUNT = 0, 1, 2, 7, 12
 
