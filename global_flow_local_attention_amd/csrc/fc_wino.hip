@@ -689,7 +689,9 @@ struct WwUnit {
   int ty, tx0, ntx;
 };
 
-template <int KS>
+// DBG (timing ablations, tools only; results are garbage): 1 no input transform, 2 no MFMAs / A reads, 4 no dY loads,
+// 8 no lift of dY to the 36 points, 16 no raw staging
+template <int KS, int DBG = 0>
 __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc X, const float *__restrict__ Z,
                                                                      int64_t z_bs, int64_t z_lead,
                                                                      float *__restrict__ part, int cpad, int Wp,
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) {
-        const float v = zp[(int64_t)(i * Wp + j) * kFcHidden];
+        const float v = (DBG & 4) ? 1.f : zp[(int64_t)(i * Wp + j) * kFcHidden];
         // columns Wo .. Wp-1 and the rows behind Ho are zero in the Z layout, but a partial tile of a 4 x 4 tiling can reach
         // column Wp = the next row's first output: masked
         dy[i][j] = (live && (M == 2 || xo0 + j < Wo)) ? v : 0.f;
@@ -811,14 +813,24 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
       if (ks < nks) {  // wave-uniform
         if (ks + AHEAD < nks) load_dy(un, h, ks + AHEAD, dy[(ks + AHEAD) % (AHEAD + 1)]);
         float zh[kWnXi];
-        ww_lift<M>(dy[ks % (AHEAD + 1)], zh);
+        if constexpr (DBG & 8) {
+#pragma unroll
+          for (int q = 0; q < kWnXi; ++q) zh[q] = dy[ks % (AHEAD + 1)][q & 1][(q >> 1) & 1];
+        } else {
+          ww_lift<M>(dy[ks % (AHEAD + 1)], zh);
+        }
         const f32x4v *vp = reinterpret_cast<const f32x4v *>(va + ks * 4 * 16 * kWnXi);
+        if constexpr (DBG & 2) {
 #pragma unroll
-        for (int q4 = 0; q4 < kWnXi / 4; ++q4) {
-          const f32x4v a4 = vp[q4];
+          for (int q = 0; q < kWnXi; ++q) acc[q][0] += zh[q];
+        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[q4 * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], zh[q4 * 4 + e], acc[q4 * 4 + e], 0, 0, 0);
+          for (int q4 = 0; q4 < kWnXi / 4; ++q4) {
+            const f32x4v a4 = vp[q4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[q4 * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], zh[q4 * 4 + e], acc[q4 * 4 + e], 0, 0, 0);
+          }
         }
       }
     }
@@ -842,8 +854,8 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
         const bool last_h = h + 1 == nh;
         // the transform half of this step prepares the unit's next 16 tiles, or (last step of a two-step unit) the next
         // unit's first 16 -- whose raw rows were written during the unit's first step
-        const bool t_same = !last_h, t_next = last_h && has_next && nh > 1;
-        const bool stage = h == 0 && has_next;   // the next unit's raw rows: requested / written around the transform
+        const bool t_same = !(DBG & 1) && !last_h, t_next = !(DBG & 1) && last_h && has_next && nh > 1;
+        const bool stage = !(DBG & 16) && h == 0 && has_next;   // the next unit's raw rows: requested / written around the transform
         if (xh == 0) {
           multiply(cur, h, vb);
           __builtin_amdgcn_sched_barrier(0);
@@ -863,8 +875,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
         if (last_h && has_next && nh == 1) {
           // a unit of ONE step: the next unit's raw rows were written during this very step, so its first transform runs
           // here, between two barriers (k = 3 layers and narrow maps: one exposed transform per unit)
-          if (xh == 0) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
-          else transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if constexpr (!(DBG & 1)) {
+            if (xh == 0) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+            else transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          }
           __syncthreads();
         }
         vb ^= 1;
@@ -976,14 +990,27 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
   const WwGeo g = ww_geometry(Ho, Wo, k);
   const int nsplit = fc_wino_wgrad_splits(B, Ho, Wo, cpad, k);
   const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)nsplit);
-#define GFLA_WW(K_)                                                                                                    \
+#define GFLA_WW(K_, D_)                                                                                                \
   {                                                                                                                    \
     const unsigned lds = (unsigned)(2 * kWwVFloats * 4 + 2 * Ww<K_>::RAW);                                             \
-    auto kern = fc_wino_wgrad_kernel<K_>;                                                                              \
+    auto kern = fc_wino_wgrad_kernel<K_, D_>;                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     kern<<<grid, kWnThreads, lds, stream>>>(X, Z, z_bs, z_lead, part, cpad, Wp, Wo, g, B * g.TH * g.nseg, nsplit, SX);   \
   }
-  if (k == 5) GFLA_WW(5) else GFLA_WW(3)
+  if (k == 5) {
+    switch (tuning(20) >= 32 ? tuning(20) - 32 : 0) {   // timing ablations (tuning key 20 = 32 + bits; results are garbage)
+      case 1: GFLA_WW(5, 1) break;
+      case 2: GFLA_WW(5, 2) break;
+      case 4: GFLA_WW(5, 4) break;
+      case 8: GFLA_WW(5, 8) break;
+      case 16: GFLA_WW(5, 16) break;
+      case 12: GFLA_WW(5, 12) break;
+      case 29: GFLA_WW(5, 29) break;
+      default: GFLA_WW(5, 0) break;
+    }
+  } else {
+    GFLA_WW(3, 0)
+  }
 #undef GFLA_WW
   return launch_status();
 }
