@@ -50,7 +50,7 @@ typedef void *gfla_stream_t; /* hipStream_t */
 
 /* Bumped whenever an entry point is added or a signature changes.
  *   1: round 1 (the three ops + aggregate)   2: round 2 (fc_*, *_ws, bf16 backward, max_cosine, correctness_map)
- *   3: round 3 (gfla_path_count, process-global tuning, aggregate flags)
+ *   3: round 3 (gfla_path_count, process-global tuning, arithmetic mode 4)
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records) */
 #define GFLA_ABI_VERSION 4
 int gfla_abi_version(void);
