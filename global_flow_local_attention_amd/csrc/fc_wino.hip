@@ -38,6 +38,8 @@ constexpr int kWnThreads = 512;
 constexpr unsigned kWnLdsLimit = 160 * 1024;
 constexpr int kWnPF = 5;        // 16-byte pieces of the raw span a thread holds in registers across half a step
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 template <int KS>
 struct Wn {
   static constexpr int M = KS == 5 ? 2 : 4;        // output tile edge
@@ -54,9 +56,19 @@ __device__ __forceinline__ void wn_bt(const float (&d)[6], float (&o)[6]) {
   o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
   o[5] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
 }
+// The same six outputs as three PAIRS -- (1, 2), (3, 4), (0, 5) -- of packed-f32 fma chains: coefficient pairs are scalar
+// constants, the inputs are broadcast by op_sel, so a row costs ~10 v_pk_fma_f32 (+ a few moves) instead of ~22 scalar ops
+__device__ __forceinline__ void wn_bt_pk(const float (&d)[6], float (&o)[6]) {
+  const f32x2v s1{d[1], d[1]}, s2{d[2], d[2]}, s3{d[3], d[3]}, s4{d[4], d[4]};
+  const f32x2v p12 = s4 + f32x2v{-1.f, 1.f} * s1 + f32x2v{-2.5f, 0.5f} * s2 + f32x2v{-0.5f, -2.5f} * s3;
+  const f32x2v p34 = s4 + f32x2v{-0.5f, 2.f} * s1 + f32x2v{-1.f, -1.f} * s2 + f32x2v{0.5f, -2.f} * s3;
+  const f32x2v p05 = f32x2v{d[0], d[5]} + f32x2v{1.5f, 1.f} * s1 + f32x2v{-2.f, 1.5f} * s2 + f32x2v{-1.5f, -2.f} * s3 +
+                     f32x2v{1.f, -1.5f} * s4;
+  o[0] = p05[0], o[5] = p05[1], o[1] = p12[0], o[2] = p12[1], o[3] = p34[0], o[4] = p34[1];
+}
 // rows 3*HALF .. 3*HALF + 2 of B^T d
-template <int HALF>
-__device__ __forceinline__ void wn_bt3(const float (&d)[6], float (&o)[3]) {
+template <int HALF, typename T = float>
+__device__ __forceinline__ void wn_bt3(const T (&d)[6], T (&o)[3]) {
   if constexpr (HALF == 0) {
     o[0] = d[0] + 1.5f * d[1] - 2.f * d[2] - 1.5f * d[3] + d[4];
     o[1] = -d[1] - 2.5f * d[2] - 0.5f * d[3] + d[4];
@@ -360,20 +372,24 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
     const unsigned char *src = raw + (DB ? ((step >> 1) & 1) * raw_bytes : 0) + toff + (step & 1) * 32;
     float *dst = vbuf + (step & 1) * kWnVFloats + vpos;
     __builtin_amdgcn_s_setprio(3);  // the short phase goes first whenever both waves of the SIMD can issue
+    // column pass on PAIRS of columns: the same fma chain for columns j, j + 1 is one v_pk_fma_f32 / v_pk_add_f32 each
+    // (vector instructions add to the MFMA time here, so half as many of them is worth having)
     float tm[3][6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float d[6], o[3];
+    for (int jp = 0; jp < 3; ++jp) {
+      f32x2v d[6], o[3];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float *>(src + (i * Wp + j) * PITCH);
-      wn_bt3<HALF>(d, o);
+      for (int i = 0; i < 6; ++i)
+        d[i] = f32x2v{*reinterpret_cast<const float *>(src + (i * Wp + 2 * jp) * PITCH),
+                      *reinterpret_cast<const float *>(src + (i * Wp + 2 * jp + 1) * PITCH)};
+      wn_bt3<HALF, f32x2v>(d, o);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) tm[r][j] = o[r];
+      for (int r = 0; r < 3; ++r) tm[r][2 * jp] = o[r][0], tm[r][2 * jp + 1] = o[r][1];
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float o[6];
-      wn_bt(tm[r], o);
+      wn_bt_pk(tm[r], o);
 #pragma unroll
       for (int e = 0; e < 6; ++e) dst[(r * 6 + e) * kWnTiles * 8] = o[e];
     }
@@ -762,18 +778,20 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
     __builtin_amdgcn_s_setprio(3);
     float tm[3][6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float d[6], o[3];
+    for (int jp = 0; jp < 3; ++jp) {   // column pass on pairs of columns (packed f32 instructions, as in the convolution kernel)
+      f32x2v d[6], o[3];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float *>(src + (i * L + j) * PITCH);
-      wn_bt3<HALF>(d, o);
+      for (int i = 0; i < 6; ++i)
+        d[i] = f32x2v{*reinterpret_cast<const float *>(src + (i * L + 2 * jp) * PITCH),
+                      *reinterpret_cast<const float *>(src + (i * L + 2 * jp + 1) * PITCH)};
+      wn_bt3<HALF, f32x2v>(d, o);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) tm[r][j] = o[r];
+      for (int r = 0; r < 3; ++r) tm[r][2 * jp] = o[r][0], tm[r][2 * jp + 1] = o[r][1];
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float o[6];
-      wn_bt(tm[r], o);
+      wn_bt_pk(tm[r], o);
       float2 *d2 = reinterpret_cast<float2 *>(dst + r * 6);   // 8-byte aligned: 144-byte records, halves at +72, rows at +24
       d2[0] = make_float2(o[0], o[1]);
       d2[1] = make_float2(o[2], o[3]);

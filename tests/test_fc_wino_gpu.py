@@ -148,6 +148,6 @@ def test_two_job_launch_equals_one_launch_per_half(gfla, k, B, C, H, W):
         gfla.set_tuning(21, old)
     for name, a, b in zip(("logits", "grad_source", "grad_target", "grad_w0"), merged, separate):
         if name in ("grad_source", "grad_w0"):  # behind the splat into the source map's gradient: float atomics, whose
-            assert rel_err(a, b) < 1e-6, name   # order moves the last bits from run to run
+            assert rel_err(a, b) < 1e-5, name   # order moves the last bits from run to run (1.2e-6 seen)
         else:
             assert torch.equal(a, b), name
