@@ -811,10 +811,22 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) {
-        const float v = (DBG & 4) ? 1.f : zp[(int64_t)(i * Wp + j) * kFcHidden];
+        dy[i][j] = (DBG & 4) ? 1.f : zp[(int64_t)(i * Wp + j) * kFcHidden];   // RAW: masked at use (mask_dy)
+      }
+  };
+  // The masks are applied where the values are consumed, not where they are loaded: a select right behind the load made
+  // every load_dy wait for its own round trip -- the "two k steps ahead" never happened (80 of the kernel's 385 us).
+  auto mask_dy = [&](const WwUnit &un, int h, int ks, float (&dy)[M][M]) {
+    const int tile = h * 16 + 4 * ks + kq;
+    const bool live = tile < un.ntx;
+    const int xo0 = M * (un.tx0 + (live ? tile : 0));
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
         // columns Wo .. Wp-1 and the rows behind Ho are zero in the Z layout, but a partial tile of a 4 x 4 tiling can reach
         // column Wp = the next row's first output: masked
-        dy[i][j] = (live && (M == 2 || xo0 + j < Wo)) ? v : 0.f;
+        dy[i][j] = (live && (M == 2 || xo0 + j < Wo)) ? dy[i][j] : 0.f;
       }
   };
   auto multiply = [&](const WwUnit &un, int h, int vb) {
@@ -831,6 +843,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
       if (ks < nks) {  // wave-uniform
         if (ks + AHEAD < nks) load_dy(un, h, ks + AHEAD, dy[(ks + AHEAD) % (AHEAD + 1)]);
         float zh[kWnXi];
+        mask_dy(un, h, ks, dy[ks % (AHEAD + 1)]);
         if constexpr (DBG & 8) {
 #pragma unroll
           for (int q = 0; q < kWnXi; ++q) zh[q] = dy[ks % (AHEAD + 1)][q & 1][(q >> 1) & 1];
