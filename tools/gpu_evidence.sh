@@ -28,5 +28,12 @@ GFLA_DIST_BACKEND=gloo GFLA_DEVICE=0 timeout 600 python -m torch.distributed.run
   done
   echo "--- mode 0 (direct f32 MFMA convolution), same launches"
   PROBE_K=5 timeout 120 python tools/probe_wino.py 0 10 2>&1 | grep "which [0-3]"
+  echo
+  echo "fc_wino_wgrad_kernel<5>, same shapes (which 4 / 5 = weight gradient of the source / target half)"
+  echo "tuning key 20 = 32 + bits: 1 no input transform, 2 no MFMAs / A reads, 4 no dY loads, 8 no lift of dY to the 36 points, 16 no raw staging"
+  for D in 0 1 2 4 8 16 12 29; do
+    echo "--- tuning 20 = 32 + $D"
+    PROBE_K=5 timeout 120 python tools/probe_wino.py 4 10 20=$((32+D)) 2>&1 | grep "which [45]"
+  done
 } > $OUT/wino_ablations.txt 2>&1; tail -5 $OUT/wino_ablations.txt
 timeout 120 python tools/probe_wino_phases.py > $OUT/wino_phases.txt 2>&1; cat $OUT/wino_phases.txt
