@@ -339,12 +339,14 @@ __global__ __launch_bounds__(256) void fc_dw1_kernel(const float *__restrict__ h
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int i = t + 256 * j, q = i >> 6, pp = i & 63;
-      gq[j] = (q < KK && pc + pp < p_end) ? g_logits[(b * KK + q) * (int64_t)HW + min(pc + pp, HW - 1)] : 0.f;
+      // RAW values: masks and the activation are applied when the registers are written to LDS (a select or a multiply
+      // right behind a load makes the load synchronous, and this fetch is meant to fly under the MFMAs)
+      gq[j] = g_logits[(b * KK + min(q, KK - 1)) * (int64_t)HW + min(pc + pp, HW - 1)];
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const int i = t + 256 * j, pp = i >> 7, n = i & 127;
-      hq[j] = pc + pp < p_end ? lrelu_f(hid[(b * HW + min(pc + pp, HW - 1)) * (int64_t)kFcHidden + n], slope) : 0.f;
+      hq[j] = hid[(b * HW + min(pc + pp, HW - 1)) * (int64_t)kFcHidden + n];
     }
   };
   if (p_begin < p_end) fetch(p_begin);
@@ -352,13 +354,13 @@ __global__ __launch_bounds__(256) void fc_dw1_kernel(const float *__restrict__ h
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int i = t + 256 * j;
-      gls[i >> 6][i & 63] = gq[j];
+      const int i = t + 256 * j, q = i >> 6, pp = i & 63;
+      gls[q][pp] = (q < KK && pc + pp < p_end) ? gq[j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-      const int i = t + 256 * j;
-      hs[i >> 7][i & 127] = hq[j];
+      const int i = t + 256 * j, pp = i >> 7;
+      hs[pp][i & 127] = pc + pp < p_end ? lrelu_f(hq[j], slope) : 0.f;
     }
     __syncthreads();
     if (pc + 64 < p_end) fetch(pc + 64);
