@@ -519,17 +519,25 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
     }
   }
   // C/D layout: column = lane & 31 (band position), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
+  // One base pointer per lane, the 16 rows as multiples of the plane pitch; when accumulating, ALL old values are requested
+  // before the first is used (a load + wait + add + store per element was 16 NB dependent round trips per workgroup)
+  const int64_t plane = (int64_t)Hs * Ws;
+  const int cb = c0 + wave * 32 + 4 * kh;
+  float *ob = dS + ((b * C + cb) * (int64_t)Hs + by0) * Ws + l31;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const int q = 32 * j + l31;
-    if (q >= nq) continue;
+    const bool col_ok = 32 * j + l31 < nq;
+    float oldv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = c0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (c < C) {
-        float *o = dS + ((b * C + c) * (int64_t)Hs + by0) * Ws + q;
-        *o = accumulate ? *o + acc[j][r] : acc[j][r];
-      }
+      const int dc = (r & 3) + 8 * (r >> 2);
+      const bool ok = col_ok && cb + dc < C;
+      oldv[r] = (accumulate && ok) ? ob[dc * plane + 32 * j] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dc = (r & 3) + 8 * (r >> 2);
+      if (col_ok && cb + dc < C) ob[dc * plane + 32 * j] = oldv[r] + acc[j][r];
     }
   }
 }
