@@ -1012,6 +1012,67 @@ def test_resample2d_backward_with_empty_flow_returns_zeros(gfla):
     assert torch.equal(i1.grad, torch.zeros_like(i1))
 
 
+def _rs_bwd_in1(gfla, i1, i2, go, ws=None, k=4):
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = i1.shape
+    g1 = torch.full_like(i1, float("nan"))
+    tail = (B, C, H, W, i2.shape[2], i2.shape[3], k, 1, 1 | 2)   # reference int() quirk + overwrite
+    if ws is None:
+        _lib.call("gfla_resample2d_bwd_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(g1), None, *tail)
+    else:
+        _lib.call("gfla_resample2d_bwd_ws_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(go), _lib.ptr(g1), None, _lib.ptr(ws),
+                  *tail)
+    torch.cuda.synchronize()
+    return g1
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 64, 44), (2, 7, 33, 21)])
+def test_resample2d_input1_gradient_fixed_point_planes(gfla, kernel_variant, shape):
+    """d/d input1 on the 64-bit fixed-point LDS planes (csrc/lds_plane.h): (1) an integer sum does not depend on the order
+    the lanes arrive in -- two runs are bit-identical, on rough flows too; (2) the tap-record path (scratch given) equals
+    the in-kernel setup bit for bit; (3) it agrees with round 1's double planes (tuning key 23 = 1) to float rounding."""
+    if kernel_variant == "global":
+        pytest.skip("the global-memory kernels scatter with float atomics")
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = shape
+    i1 = randn((B, C, H, W), seed=1).to(DEV)
+    go = (randn((B, C, H, W), seed=2) * 3.0).to(DEV)
+    for kind, seed in (("smooth", 3), ("wild", 4)):
+        flow = make_flow(kind, B, H, W, seed=seed).to(DEV)
+        i2 = torch.cat((flow, torch.full((B, 1, H, W), 2.0, device=DEV)), 1).contiguous()
+        a, b = _rs_bwd_in1(gfla, i1, i2, go), _rs_bwd_in1(gfla, i1, i2, go)
+        assert torch.equal(a, b), kind
+        ws = _lib.scatter_workspace(i1, B, H, W, 16)
+        old = gfla.set_tuning(14, 1)   # key 14 = 1: never the matrix-core scatter -> the LDS kernel reading tap records
+        try:
+            c = _rs_bwd_in1(gfla, i1, i2, go, ws)
+        finally:
+            gfla.set_tuning(14, old)
+        assert torch.equal(a, c), kind
+        old = gfla.set_tuning(23, 1)
+        try:
+            d = _rs_bwd_in1(gfla, i1, i2, go)
+        finally:
+            gfla.set_tuning(23, old)
+        assert max_abs(a, d) <= 2e-6 * d.abs().max().item(), kind
+
+
+def test_resample2d_input1_gradient_non_finite_is_not_silently_lost(gfla, kernel_variant):
+    """A non-finite incoming gradient cannot be represented in fixed point: the workgroup's planes come out NaN (the
+    reference would poison only the taps the value reaches) -- never a finite garbage value."""
+    if kernel_variant == "global":
+        pytest.skip("fixed-point planes are the LDS kernels'")
+    B, C, H, W = 1, 4, 16, 12
+    i1 = randn((B, C, H, W), seed=1).to(DEV)
+    go = randn((B, C, H, W), seed=2).to(DEV)
+    go[0, 1, 5, 6] = float("inf")
+    flow = make_flow("smooth", B, H, W, seed=3).to(DEV)
+    i2 = torch.cat((flow, torch.full((B, 1, H, W), 2.0, device=DEV)), 1).contiguous()
+    g = _rs_bwd_in1(gfla, i1, i2, go)
+    assert not torch.isfinite(g[0, 1]).all()
+    assert torch.isfinite(g[0, 3]).all() or not torch.isfinite(g[0, 3]).any()   # a plane is poisoned as a whole or not at all
+
+
 def test_bf16_features_beyond_the_lds_backward_fall_back_to_f32(gfla, oracle, kernel_variant):
     """128x128 bf16 maps: the bf16 aggregation backward does not take planes that large; the block must
     still train -- evaluated in float32, results handed back in bf16 -- instead of raising in backward."""
