@@ -132,6 +132,26 @@ class HotPath:
         return outs
 
 
+def capture_step(hp, resample, warmup=2):
+    """One whole step of `hp` (forward AND backward: ~90 kernel launches, every one enqueued by a C-ABI call on the current
+    stream; nothing allocates outside torch's caching allocator or synchronises) captured into ONE hipGraph
+    (torch.cuda.CUDAGraph is hipGraph on ROCm).  Returns (graph, outputs); `graph.replay()` re-runs the step on the same
+    buffers: inputs are read from, and gradients written to, the tensors of the capture (`hp.inputs[i][j].grad` etc. are
+    static across replays -- a training loop copies its batch into the captured input tensors, as with any graphed step).
+    Single rank only: the reducer's collectives stay outside the graph."""
+    assert hp.upstream is not None, "run one eager step first (lazy initialisation must not be captured)"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            hp.step(resample, allreduce=False)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = hp.step(resample, allreduce=False)
+    return graph, outs
+
+
 FACE_LAYERS = (  # (name, C, H, W, k): FaceGenerator at 256x256, layers=3, ngf=64 (generator.py:388-505)
     ("attn3", 256, 32, 32, 3),
     ("attn2", 128, 64, 64, 5),
@@ -576,42 +596,110 @@ def fc_kernel_probes(hp, iters=10):
     return rows
 
 
+def op_roofline(device, B=32, iters=20, layers=None, flow_kind="smooth"):
+    """The north star's own figure (BASELINE.json: ">= 60 % of the HBM3E peak on block_extractor + local-attn forward at
+    256x176, attn_layer=2,3"), measured op by op through the C ABI at the attention-layer shapes of the headline:
+    `gfla_block_extractor_fwd_f32` in the REFERENCE layout (B,C,kH,kW) (block_extractor_kernel.cu:20-85) and
+    `gfla_local_attn_aggregate_fwd_ws_f32` (softmax + reshape + multiply + avg-pool of base_function.py:803-809), each
+    HIP-event timed over `iters` back-to-back launches on the launch stream; achieved = SURVEY 8(d)'s algorithmic bytes /
+    time, frac = achieved / 8 TB/s, per op and for the pair (sum of bytes / sum of times)."""
+    out = {"peak_GBps": HBM_PEAK_GBS, "flow": flow_kind, "batch": B, "layers": {},
+           "what": "block_extractor forward (reference layout) + local-attention forward (softmax/aggregate), "
+                   "algorithmic bytes (SURVEY 8d) / HIP-event time / 8 TB/s; `pair` = both ops, sum of bytes / sum of times"}
+    gen = torch.Generator(device=device).manual_seed(77)
+    stream = torch.cuda.current_stream(device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3  # us
+
+    for (name, C, H, W, k) in (layers or LAYERS):
+        src = torch.randn(B, C, H, W, device=device, generator=gen)
+        flow = (smooth_flow(B, H, W, device, gen) if flow_kind == "smooth"
+                else torch.zeros(B, 2, H, W, device=device))
+        logits = torch.randn(B, k * k, H, W, device=device, generator=gen)
+        blocks = torch.empty(B, C, k * H, k * W, device=device)
+        agg, attn = torch.empty_like(src), torch.empty_like(logits)
+        n = _lib.lib().gfla_aggregate_fwd_workspace_bytes(B, H, W, k)
+        scratch = torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+        be_args = (_lib.ptr(src), _lib.ptr(flow), _lib.ptr(blocks), B, C, H, W, H, W, k)
+        ag_args = (_lib.ptr(src), _lib.ptr(flow), _lib.ptr(logits), _lib.ptr(agg), _lib.ptr(attn), _lib.ptr(scratch),
+                   B, C, H, W, H, W, k, 1)
+        t_be = timed(lambda: _lib.call("gfla_block_extractor_fwd_f32", src, *be_args))
+        t_ag = timed(lambda: _lib.call("gfla_local_attn_aggregate_fwd_ws_f32", src, *ag_args))
+        b_be = algorithmic_bytes("gfla_block_extractor_fwd_f32", (1, 1, 1, B, C, H, W, H, W, k))
+        b_ag = algorithmic_bytes("gfla_local_attn_aggregate_fwd_ws_f32", (1, 1, 1, 1, 1, 1, B, C, H, W, H, W, k, 1))
+
+        def row(nbytes, us):
+            gbs = nbytes / (us * 1e-6) / 1e9
+            return {"alg_MB": round(nbytes / 1e6, 2), "us": round(us, 1), "GBps": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        out["layers"][name] = {"dims": [B, C, H, W, k], "block_extractor_fwd": row(b_be, t_be),
+                               "local_attn_fwd": row(b_ag, t_ag), "pair": row(b_be + b_ag, t_be + t_ag)}
+        del src, flow, logits, blocks, agg, attn, scratch
+    return out
+
+
 def oracle_check(hp, resample, tol=1e-4):
-    """Sample 0 of the timed configuration through the reference composition with the CPU oracle kernels (the checker
-    only): forward outputs and the gradients of source, target, flow and the warped VGG features of that sample
-    (every op on the path is per-sample, so they do not depend on the rest of the batch).  Raises on a mismatch."""
+    """Samples 0 and B-1 of the timed configuration through the reference composition with the CPU oracle kernels (the
+    checker only): forward outputs and the gradients of source, target, flow and the warped VGG features of those samples
+    (every op on the path is per-sample, so they do not depend on the rest of the batch).  The backward of this pass is
+    driven by O(1) upstream gradients (the timed steps scale theirs by 1/numel, which would hide absolute errors).
+    Reported per tensor: max |got - want| (`max_abs`, the north star's measure) and that over max |want| (`max_rel`).
+    Raises when a forward output exceeds `tol` in max-abs or any tensor exceeds it relative to its largest entry."""
     from oracle import cpu_modules, cpu_oracle
     cpu_oracle.build()
-    outs = hp.step(resample, allreduce=False)
-    report = {}
+    timed_upstream = hp.upstream
+    gen = torch.Generator(device=timed_upstream[0].device).manual_seed(9876)
+    hp.upstream = [torch.randn(u.shape, device=u.device, generator=gen) for u in timed_upstream]
+    try:
+        outs = hp.step(resample, allreduce=False)
+    finally:
+        upstream, hp.upstream = hp.upstream, timed_upstream
+    max_abs, max_rel = {}, {}
 
-    def cmp(name, got, want):
+    def cmp(name, got, want, forward):
         want = want.detach().double()
-        err = (got.detach().double().cpu() - want).abs().max().item() / max(1e-30, want.abs().max().item())
-        report[name] = float("%.2e" % err)
-        if not err <= tol:
-            raise SystemExit("bench.py: %s of the timed configuration differs from the CPU oracle: rel err %.3e" % (name, err))
+        err = (got.detach().double().cpu() - want).abs().max().item()
+        rel = err / max(1e-30, want.abs().max().item())
+        max_abs[name] = max(max_abs.get(name, 0.0), float("%.2e" % err))
+        max_rel[name] = max(max_rel.get(name, 0.0), float("%.2e" % rel))
+        if not rel <= tol or (forward and not err <= tol):
+            raise SystemExit("bench.py: %s of the timed configuration differs from the CPU oracle: max abs %.3e, relative "
+                             "to the largest entry %.3e" % (name, err, rel))
 
     rs = cpu_modules.Resample2dCPU(4, 1, 2)
-    for i, (mod, (src, tgt, flow)) in enumerate(zip(hp.attn, hp.inputs)):
-        name, C, H, W, k = LAYERS[i]
-        ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
-        ref.load_state_dict({kk: v.detach().cpu() for kk, v in mod.state_dict().items()})
-        a = [x[:1].detach().cpu().clone().requires_grad_() for x in (src, tgt, flow)]
-        want = ref(*a)
-        want.backward(hp.upstream[i][:1].cpu())
-        cmp(name + " out", outs[i][:1], want)
-        # the layer's flow also warps the VGG features of the same resolution (HotPath.step): its gradient is the sum
-        feat, j = hp.vgg[i], len(hp.attn) + i
-        f1 = feat[:1].detach().cpu().clone().requires_grad_(feat.requires_grad)
-        warped = rs(f1, a[2])
-        warped.backward(hp.upstream[j][:1].cpu())
-        cmp(VGG[i][0] + " warp", outs[j][:1], warped)
-        for nm, x, w in zip(("grad source", "grad target", "grad flow (attention + warp)"), (src, tgt, flow), a):
-            cmp(name + " " + nm, x.grad[:1], w.grad)
-        if feat.requires_grad:
-            cmp(VGG[i][0] + " grad input1", feat.grad[:1], f1.grad)
-    return {"tolerance": tol, "max_rel_err": report}
+    samples = sorted({0, hp.B - 1})
+    for n in samples:
+        sl = slice(n, n + 1)
+        for i, (mod, (src, tgt, flow)) in enumerate(zip(hp.attn, hp.inputs)):
+            name, C, H, W, k = LAYERS[i]
+            ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+            ref.load_state_dict({kk: v.detach().cpu() for kk, v in mod.state_dict().items()})
+            a = [x[sl].detach().cpu().clone().requires_grad_() for x in (src, tgt, flow)]
+            want = ref(*a)
+            want.backward(upstream[i][sl].cpu())
+            cmp(name + " out", outs[i][sl], want, True)
+            # the layer's flow also warps the VGG features of the same resolution (HotPath.step): its gradient is the sum
+            feat, j = hp.vgg[i], len(hp.attn) + i
+            f1 = feat[sl].detach().cpu().clone().requires_grad_(feat.requires_grad)
+            warped = rs(f1, a[2])
+            warped.backward(upstream[j][sl].cpu())
+            cmp(VGG[i][0] + " warp", outs[j][sl], warped, True)
+            for nm, x, w in zip(("grad source", "grad target", "grad flow (attention + warp)"), (src, tgt, flow), a):
+                cmp(name + " " + nm, x.grad[sl], w.grad, False)
+            if feat.requires_grad:
+                cmp(VGG[i][0] + " grad input1", feat.grad[sl], f1.grad, False)
+    return {"tolerance": tol, "samples": samples, "upstream": "O(1): randn of the output's shape",
+            "gate": "forward outputs: max_abs <= tolerance; every tensor: max_abs / max|reference| <= tolerance",
+            "max_abs": max_abs, "max_rel": max_rel}
 
 
 def cpu_baseline(budget_s=20.0):
@@ -636,7 +724,16 @@ def cpu_baseline(budget_s=20.0):
         if time.perf_counter() - t0 > budget_s or n >= 50:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+    host = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host
+    return {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "host_logical_cpus": host,
+            "host_cpus_usable_by_this_process": usable, "kind": "port",
+            "threads_note": "the literal port keeps the reference's atomics (omp atomic); beyond ~16 threads they thrash "
+                            "(0.055 images/s on 256 threads vs 1.3 on 8), so `cores` = the %d threads used, not the host's %d "
+                            "logical CPUs" % (cores, host),
             "sample": "%d step(s) of batch %d of the same workload (reference op-by-op composition, oracle/gfla_oracle.c "
                       "kernels with OpenMP + torch CPU convolutions), %.1f s" % (n, b, dt)}
 
@@ -703,6 +800,47 @@ def extra_legs(args, device):
     del fp
     torch.cuda.empty_cache()
     return legs
+
+
+def dist_leg(args, rank, world, device, on_gpu, barrier, tile_shape=None, iters=10):
+    """N > 1 only, called by EVERY rank: what the process group is (backend, world size as the group sees it, RCCL
+    version) and the one data exchange the north star names -- the all-gather of the generated tiles
+    ((B/N, 3, H, W) per rank, face_model.py:81-93 = nn.DataParallel's gather) through dist.all_gather_tiles, timed
+    between barrier + synchronize, MAX over ranks."""
+    import torch.distributed as td
+    info = {"backend": td.get_backend(), "world_size_seen_by_group": td.get_world_size(), "rank0_device": str(device)}
+    if on_gpu:
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # a torch build without the binding
+            info["rccl_version"] = "unavailable (%s)" % type(exc).__name__
+        info["gpus_visible"] = torch.cuda.device_count()
+    # one all-reduce of rank ids proves every rank is in the collective
+    t = torch.tensor([float(rank + 1)], device=device)
+    td.all_reduce(t)
+    info["allreduce_of_rank_ids"] = t.item()
+    info["allreduce_expected"] = world * (world + 1) / 2.0
+    shape = tuple(tile_shape or (args.batch, 3, 256, 176))
+    tiles = torch.full(shape, float(rank), device=device)
+    out = gdist.all_gather_tiles(tiles)
+    ok = out.shape[0] == shape[0] * world and all(bool((out[r * shape[0]] == float(r)).all()) for r in range(world))
+    for _ in range(2):
+        gdist.all_gather_tiles(tiles)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        gdist.all_gather_tiles(tiles)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = tt.item()
+    nbytes = tiles.numel() * tiles.element_size()
+    info["all_gather_tiles"] = {"tile_shape_per_rank": list(shape), "dtype": "f32", "correct": bool(ok),
+                                "us": round(dt / iters * 1e6, 1), "MB_received_per_rank": round(nbytes * (world - 1) / 1e6, 2),
+                                "GBps_received_per_rank": round(nbytes * (world - 1) / (dt / iters) / 1e9, 2)}
+    return info
 
 
 def timed_steps(step, steps, warmup, barrier, world, device):
@@ -858,11 +996,49 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                                         "events around the call; peak = dense matrix-core rate of the operand type"}
     if variants:
         line["variants"] = variants
+    if rank == 0 and world == 1 and on_gpu and not custom and not getattr(args, "no_graph", False):
+        # the same step replayed from one hipGraph: identical kernels and buffers, no per-launch host work
+        try:
+            leaves = [x for tup in hp.inputs for x in tup] + hp.vgg + hp.params()
+            hp.step(resample, allreduce=False)
+            eager = [None if t.grad is None else t.grad.detach().clone() for t in leaves]
+            graph, _ = capture_step(hp, resample)
+            graph.replay()
+            torch.cuda.synchronize()
+            worst = 0.0
+            for t, e in zip(leaves, eager):
+                if e is not None:
+                    worst = max(worst, (t.grad - e).abs().max().item() / max(1e-30, e.abs().max().item()))
+            n = args.steps
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                graph.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            line["hipgraph_step"] = {"what": "the headline step (forward + backward, every launch of it) captured once into a "
+                                             "hipGraph and replayed: same kernels, same buffers",
+                                     "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(args.batch / dt, 1),
+                                     "max_rel_diff_of_any_gradient_vs_eager": float("%.2e" % worst)}
+            del graph
+        except Exception as exc:  # capture is an optimisation, never a reason to lose the headline
+            line["hipgraph_step"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    if world > 1:   # every rank takes part (collectives); the fingerprint proves N ranks met on the backend
+        line["dist"] = dist_leg(args, rank, world, device, on_gpu, barrier,
+                                tile_shape=None if on_gpu else (args.batch, 3, 8, 6))
+    if rank == 0 and world == 1 and on_gpu and not custom and not getattr(args, "no_legs", False):
+        # the north star's own figure: block_extractor (reference layout) + local-attention forward against the HBM roofline
+        line["north_star"] = op_roofline(device, B=args.batch)
     if rank == 0 and world == 1 and on_gpu and not custom and not getattr(args, "no_legs", False) \
             and not getattr(args, "with_losses", False):
         line["legs"] = extra_legs(args, device)
     if check is not None:
         line["oracle_check"] = check
+    # calls of this process that left the library's own MFMA kernels for rocBLAS / MIOpen (0 unless --fc-impl library)
+    from global_flow_local_attention_amd import extractor_attn as _ea
+    line["vendor_fallback_calls"] = _ea.vendor_fallback_calls
     if rank == 0:
         if world == 1 and on_gpu and not args.no_cpu_baseline and not custom:
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
@@ -879,6 +1055,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle check + baseline)")
     ap.add_argument("--no-variants", action="store_true", help="skip the labelled variants (other FC arithmetic modes)")
     ap.add_argument("--tuning", default="", help="library tuning keys for A/B runs: key=value[,key=value...] (include/gfla_hip.h)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the headline step")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the compact legs for the other BASELINE configs (config-3 inference, with-losses, trainer "
                          "step, face bf16) that the default N=1 run appends under `legs`")

@@ -55,6 +55,7 @@ _SINGLE = {
     "gfla_scatter_workspace_bytes": [_i64] * 3 + [_int],
     "gfla_aggregate_fwd_workspace_bytes": [_i64] * 3 + [_int],
     "gfla_aggregate_fwd_geometry": [_i64] * 6 + [_int, _ptr],
+    "gfla_aggregate_bwd_supported": [_i64, _i64, _int],
     "gfla_local_attn_aggregate_fwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
@@ -188,9 +189,9 @@ def set_tuning(key, value):
     return lib().gfla_set_tuning(int(key), int(value))
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
-PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_COUNT = 0, 1, 2, 7, 12
+PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_BE_FWD_PIX, PATH_COUNT = 0, 1, 2, 7, 12, 13
 
 
 def path_count(path):

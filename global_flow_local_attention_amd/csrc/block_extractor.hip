@@ -16,6 +16,8 @@
 //            double-precision LDS planes (ds_add_f64) flushed once, or relaxed device-scope float atomics when the plane does not fit.
 #include "gfla_common.h"
 #include "be_bwd_lds.h"
+#include "be_fwd_pix.h"
+#include "be_fwd_wrow.h"
 
 namespace gfla {
 
@@ -215,6 +217,37 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
                       int64_t Hf, int64_t Wf, int k, hipStream_t stream) {
   using A = typename Num<T>::acc;
   const int variant = tuning(0);
+  // key 0: 0 auto, 1 global-gather kernel, 2 round 1's planes-in-LDS kernel (lane = output quad), 3 the lane-per-pixel
+  // kernel with direct stores (be_fwd_pix.h), 4 the wave-per-flow-row kernel (be_fwd_wrow.h).
+  // auto: flow rows of up to 64 pixels go to the wave-per-flow-row kernel (contiguous pieces whatever the width: 4.6-5.6
+  // TB/s), wider ones to the lane-per-pixel kernel (5.2 TB/s when its output rows are whole 128-byte lines, 3.8-4.7
+  // otherwise), planes beyond the LDS budget to round 1's windowed kernel
+  if constexpr (sizeof(T) >= 4) {
+    if ((variant == 4 || variant == 0) && k >= 2 && k <= 5) {
+      bool done = false;
+      int st = GFLA_OK;
+      switch (k) {
+        case 2: st = launch_fwd_wrow<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 3: st = launch_fwd_wrow<T, 3>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 4: st = launch_fwd_wrow<T, 4>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        default: st = launch_fwd_wrow<T, 5>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+      }
+      if (done) note_path(GFLA_PATH_BE_FWD_PIX);
+      if (done || st != GFLA_OK) return st;
+    }
+    if (variant != 1 && variant != 2 && variant != 4 && k >= 2 && k <= 5) {  // lane = flow pixel, direct stores (be_fwd_pix.h)
+      bool done = false;
+      int st = GFLA_OK;
+      switch (k) {
+        case 2: st = launch_fwd_pix<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 3: st = launch_fwd_pix<T, 3>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 4: st = launch_fwd_pix<T, 4>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        default: st = launch_fwd_pix<T, 5>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+      }
+      if (done) note_path(GFLA_PATH_BE_FWD_PIX);
+      if (done || st != GFLA_OK) return st;
+    }
+  }
   if (variant != 1) {
     // work items = output positions; one flow row = k output rows of (k*Wf)/V positions
     PlaneGeo g = lds_geometry(Hs, Ws, sizeof(A), B, C, Hf, (int64_t)k * ((k * Wf) / V), k + 1, 1);

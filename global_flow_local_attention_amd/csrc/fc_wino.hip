@@ -596,7 +596,9 @@ static int wn_launch(const WnConvJob *jobs, int njobs, int64_t B, int nch, hipSt
     kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, stamps);     \
   }
   if (!db) GFLA_WINO_LAUNCH(0, false)
-  else switch (K_ == 5 ? tuning(20) : 0) { /* timing ablations of the k = 5 kernel (results are garbage) */
+#ifdef GFLA_PROBES  // `make PROBES=1`: timing ablations of the k = 5 kernel (tuning key 20; their results are garbage, so
+                    // a default build does not contain them and a stray key 20 cannot corrupt a forward / backward)
+  else switch (K_ == 5 ? tuning(20) : 0) {
     case 1: GFLA_WINO_LAUNCH(1, true) break;
     case 2: GFLA_WINO_LAUNCH(2, true) break;
     case 4: GFLA_WINO_LAUNCH(4, true) break;
@@ -607,6 +609,9 @@ static int wn_launch(const WnConvJob *jobs, int njobs, int64_t B, int nch, hipSt
     case 13: GFLA_WINO_LAUNCH(13, true) break;
     default: GFLA_WINO_LAUNCH(0, true) break;
   }
+#else
+  else GFLA_WINO_LAUNCH(0, true)
+#endif
 #undef GFLA_WINO_LAUNCH
   return launch_status();
 }
@@ -1029,7 +1034,8 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
     kern<<<grid, kWnThreads, lds, stream>>>(X, Z, z_bs, z_lead, part, cpad, Wp, Wo, g, B * g.TH * g.nseg, nsplit, SX);   \
   }
   if (k == 5) {
-    switch (tuning(20) >= 32 ? tuning(20) - 32 : 0) {   // timing ablations (tuning key 20 = 32 + bits; results are garbage)
+#ifdef GFLA_PROBES  // timing ablations (tuning key 20 = 32 + bits; results are garbage): `make PROBES=1` builds only
+    switch (tuning(20) >= 32 ? tuning(20) - 32 : 0) {
       case 1: GFLA_WW(5, 1) break;
       case 2: GFLA_WW(5, 2) break;
       case 4: GFLA_WW(5, 4) break;
@@ -1039,6 +1045,9 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
       case 29: GFLA_WW(5, 29) break;
       default: GFLA_WW(5, 0) break;
     }
+#else
+    GFLA_WW(5, 0)
+#endif
   } else {
     GFLA_WW(3, 0)
   }
@@ -1066,7 +1075,12 @@ extern "C" {
 /* tools only: device buffer (workgroups x 8 waves x 6 uint64) that the DBG=16 instantiation of the Winograd kernel (tuning
  * key 20 = 16) fills with per-wave phase times in shader cycles; NULL switches it off */
 int gfla_fc_wino_debug_buffer(void *buffer) {
+#ifdef GFLA_PROBES
   gfla::g_wino_stamps = static_cast<unsigned long long *>(buffer);
   return GFLA_OK;
+#else
+  (void)buffer;   // the probe instantiations are not part of a default build (make PROBES=1)
+  return GFLA_ERR_UNSUPPORTED;
+#endif
 }
 }

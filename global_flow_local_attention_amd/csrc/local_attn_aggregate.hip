@@ -1548,6 +1548,15 @@ int gfla_local_attn_aggregate_bwd_ws_f32(const float *s, const float *f, const f
                                          int64_t Ws, int64_t H, int64_t W, int k, int sm, gfla_stream_t st) {
   return gfla::aggregate_bwd<float>(s, f, a, go, gs, gf, gl, B, C, Hs, Ws, H, W, k, sm, st, workspace);
 }
+/* 1 when gfla_local_attn_aggregate_bwd_<storage> takes source planes of Hs x Ws (elem_size 2 = bf16, 4 = f32, 8 = f64).
+ * f32 / f64 always do (global-memory kernels behind the planes-in-LDS ones); bf16 storage exists for the planes-in-LDS
+ * kernels only: a double accumulator plane + an arithmetic-type source plane per position within the LDS budget (tuning
+ * key 10).  The host side asks here instead of duplicating the budget. */
+int gfla_aggregate_bwd_supported(int64_t Hs, int64_t Ws, int elem_size) {
+  if (Hs <= 0 || Ws <= 0 || (elem_size != 2 && elem_size != 4 && elem_size != 8)) return 0;
+  if (elem_size != 2) return 1;
+  return Hs * Ws * (int64_t)(sizeof(gfla::lds_acc_t) + sizeof(float)) <= gfla::lds_budget() ? 1 : 0;
+}
 /* bf16 storage: grad_source bf16; grad_flow and grad_logits FLOAT32 (reductions over channels, accumulated across
  * workgroups) */
 int gfla_local_attn_aggregate_bwd_bf16(const uint16_t *s, const uint16_t *f, const uint16_t *a, const uint16_t *go,

@@ -111,11 +111,15 @@ __device__ __forceinline__ void rs_bwd1_apply_fix(const int (&ro)[N], const int 
                                                   int64_t gstride, lds_fix_t *__restrict__ gplane, int64_t plane_sz, int nch,
                                                   float gscale) {
   // g_first = the first channel's gradient at g (the caller requested it an iteration ahead)
-  double wxd[N];
+  // The product (gradient x row weight / sum) is formed in DOUBLE: qy = w_y / sum alone is not bounded by 1 (only qy * wx
+  // is), and with a sigma small enough for the column weights to underflow go * qy overflows float while the contribution
+  // itself is <= |go| (advisor finding, round 3).
+  double wxd[N], qyd[N];
   bool consecutive = true;
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     wxd[q] = (double)wx[q];
+    qyd[q] = (double)qy[q];
     consecutive = consecutive && co[q] == co[0] + q;
   }
   float gnext = g_first;
@@ -126,7 +130,7 @@ __device__ __forceinline__ void rs_bwd1_apply_fix(const int (&ro)[N], const int 
       if (c + 1 < nch) gnext = Num<T>::ld(g);
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const double gr_ = (double)(go * qy[r]);
+        const double gr_ = (double)go * qyd[r];
         lds_fix_t *row = gplane + ro[r] + co[0];
 #pragma unroll
         for (int q = 0; q < N; ++q) lds_add_fix_biased(row + q, __builtin_fma(gr_, wxd[q], kFixMagic));
@@ -140,7 +144,7 @@ __device__ __forceinline__ void rs_bwd1_apply_fix(const int (&ro)[N], const int 
       if (c + 1 < nch) gnext = Num<T>::ld(g);
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const double gr_ = (double)(go * qy[r]);
+        const double gr_ = (double)go * qyd[r];
 #pragma unroll
         for (int q = 0; q < N; ++q) lds_add_fix_biased(gplane + ro[r] + co[q], __builtin_fma(gr_, wxd[q], kFixMagic));
       }

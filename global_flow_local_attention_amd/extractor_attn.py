@@ -27,6 +27,22 @@ from .local_attn_reshape import LocalAttnReshape
 
 _FUSED_MAX_K = 5  # kernel sizes the fused tail is instantiated for
 
+# What happens when a module's FC layers are NOT taken by this library's own MFMA kernels (kernel_size other than 3 / 5 --
+# the reference's constructor default is 4, base_function.py:791 --, float64 features, maps whose tiles exceed the LDS)
+# and would run through torch.mm / F.conv2d, i.e. rocBLAS / MIOpen:
+#   "warn"  (package default)  warn once per module, then run the vendor path
+#   "error" (what install() sets unless allow_vendor_fallback=True)  raise: nobody benchmarks or ships the vendor
+#           libraries by accident
+#   "allow" run it silently
+# A module attribute `vendor_fallback` overrides the policy for that module; `module.fc_impl = "library"` is an explicit
+# request for the vendor path and is always honoured.  Every call that took it is counted (bench.py reports the count).
+VENDOR_FALLBACK = "warn"
+vendor_fallback_calls = 0
+
+
+class VendorFallbackError(RuntimeError):
+    pass
+
 
 class _SourceGradLink(object):
     """Joins the two backward nodes that scatter into (source, flow) inside one ExtractorAttn call (library FC path).
@@ -299,9 +315,11 @@ def _mfma_mode(self, source, target, flow_field, conv0, act, conv1, k):
     return fc_mfma.resolve_mode(source.size(1), source.size(2), source.size(3), k, getattr(self, "fc_mode", None))
 
 
-# bf16 features: the aggregation's backward keeps a (double accumulator + f32 source) plane pair per position in LDS
-# (csrc/local_attn_aggregate.hip: Hs*Ws*(sizeof(lds_acc_t)+4) <= kLdsBudget); larger maps have no bf16 backward
-_BF16_BWD_MAX_POSITIONS = (64 * 1024) // 12
+def _bf16_backward_supported(hs, ws):
+    """bf16 features: the aggregation's backward keeps a (double accumulator + f32 source) plane pair per position in
+    LDS; larger maps have no bf16 backward.  The library answers (gfla_aggregate_bwd_supported) -- its LDS budget is
+    tunable, a constant duplicated here would drift."""
+    return bool(_lib.lib().gfla_aggregate_bwd_supported(int(hs), int(ws), 2))
 
 
 def _bf16_path_ok(self, source, target, flow_field, conv0, act, conv1, last, k):
@@ -313,7 +331,7 @@ def _bf16_path_ok(self, source, target, flow_field, conv0, act, conv1, last, k):
         return False
     needs_bwd = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or flow_field.requires_grad
                                              or conv0.weight.requires_grad or conv1.weight.requires_grad)
-    return not needs_bwd or source.size(2) * source.size(3) <= _BF16_BWD_MAX_POSITIONS
+    return not needs_bwd or _bf16_backward_supported(source.size(2), source.size(3))
 
 
 class FusedAttnFunction(Function):
@@ -486,14 +504,21 @@ def _fused_attention(self, source, target, flow_field):
         logits = fc_mfma.FcMfmaFunction.apply(source_c, target, flow_c, conv0.weight, conv0.bias, conv1.weight,
                                               conv1.bias, k, _tail_slope(act), mode)
         return _aggregate(source_c, flow_c, logits, last, k, None)
-    if getattr(self, "fc_impl", "mfma") == "mfma" and not getattr(self, "_library_warned", False):
-        # nobody should benchmark the vendor libraries by accident: say once that this module left the MFMA path
-        import warnings
-        warnings.warn("ExtractorAttn(kernel_size=%d, %s, %s): this configuration is not taken by the library's own MFMA "
-                      "kernels (kernel_size 3 / 5, float32 or bfloat16 features, 128 hidden channels, maps whose tiles fit the "
-                      "LDS); its FC layers run through torch.mm / F.conv2d (rocBLAS / MIOpen) instead"
-                      % (k, source.dtype, tuple(source.shape)))
-        self._library_warned = True
+    global vendor_fallback_calls
+    vendor_fallback_calls += 1
+    if getattr(self, "fc_impl", "mfma") == "mfma":   # not an explicit request for the vendor path
+        policy = getattr(self, "vendor_fallback", VENDOR_FALLBACK)
+        what = ("ExtractorAttn(kernel_size=%d, %s, %s): this configuration is not taken by the library's own MFMA kernels "
+                "(kernel_size 3 / 5, float32 or bfloat16 features, 128 hidden channels, maps whose tiles fit the LDS); its FC "
+                "layers would run through torch.mm / F.conv2d (rocBLAS / MIOpen)" % (k, source.dtype, tuple(source.shape)))
+        if policy == "error":
+            raise VendorFallbackError(what + ".  Pass allow_vendor_fallback=True to install(), or set module.vendor_fallback = "
+                                      "'allow' / module.fc_impl = 'library', to run it that way")
+        if policy == "warn" and not getattr(self, "_library_warned", False):
+            # nobody should benchmark the vendor libraries by accident: say once that this module left the MFMA path
+            import warnings
+            warnings.warn(what + " instead")
+            self._library_warned = True
     # base_function.py:805-807: conv0(cat(block_target, block_source)).  block_target is the
     # zero-flow (replicate-padded) unfold of target, so its half of the convolution equals a
     # stride-1 convolution of the padded target and block_target is never built; block_source's half
@@ -517,27 +542,36 @@ def _fused_attention(self, source, target, flow_field):
 
 
 def _fused_attention_f32_module(self, source, target, flow_field):
-    """_fused_attention on float32 inputs with the module's parameters viewed as float32 (bf16 modules)."""
+    """_fused_attention on float32 inputs with the module's parameters viewed as float32 (bf16 modules).  The float32
+    twins of the convolutions are built ONCE, on the meta device (no initialisation: the global RNG is not consumed, no
+    host allocation) with every attribute of the original (dilation, groups, padding_mode included); each call only
+    re-derives their weights as differentiable float32 views of the bf16 parameters."""
     fc = self.fully_connect_layer
     if fc[0].weight.dtype == torch.float32:
         return _fused_attention(self, source, target, flow_field)
     import copy
-    shadow = copy.copy(self)              # shares nothing mutable we touch; parameters are re-derived below
-    shadow._modules = dict(self._modules)
-    layers = []
-    for m in fc:
+    shadow = self.__dict__.get("_f32_shadow")
+    if shadow is None:
+        shadow = copy.copy(self)              # shares nothing mutable we touch; parameters are re-derived below
+        shadow._modules = dict(self._modules)
+        layers = []
+        for m in fc:
+            if isinstance(m, nn.Conv2d):
+                m32 = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
+                                bias=m.bias is not None, padding_mode=m.padding_mode, device="meta")
+                del m32.weight
+                if m.bias is not None:
+                    del m32.bias
+                layers.append(m32)
+            else:
+                layers.append(m)
+        shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
+        self.__dict__["_f32_shadow"] = shadow
+    for m, m32 in zip(fc, shadow._modules["fully_connect_layer"]):
         if isinstance(m, nn.Conv2d):
-            m32 = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=m.bias is not None)
-            m32 = m32.to(m.weight.device)
-            del m32.weight                 # differentiable float32 views of the bf16 parameters
-            m32.weight = m.weight.float()
+            m32.weight = m.weight.float()      # differentiable float32 views of the bf16 parameters
             if m.bias is not None:
-                del m32.bias
                 m32.bias = m.bias.float()
-            layers.append(m32)
-        else:
-            layers.append(m)
-    shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
     return _fused_attention(shadow, source, target, flow_field)
 
 

@@ -34,11 +34,18 @@ def _namespace(name, path=None):
     return mod
 
 
-def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True):
+def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, allow_vendor_fallback=False):
     """Alias the three op modules; optionally patch the reference's ExtractorAttn with the fused
     forward.  `reference_root` (a checkout of the reference) is only needed if `model` is not
     already importable.  Returns the reference's `model.networks.base_function` module when it
-    could be imported, else None."""
+    could be imported, else None.
+
+    allow_vendor_fallback: an ExtractorAttn configuration this library's own MFMA kernels do not take (kernel_size other
+    than 3 / 5 -- the reference's constructor default is 4 --, float64 features, maps too large for the LDS tiles) would
+    run its FC layers through rocBLAS / MIOpen.  After install() that RAISES (extractor_attn.VendorFallbackError) unless
+    this flag is True (then it warns once per module); the production configurations (kernel_size 2=5, 3=3) never reach it."""
+    from . import extractor_attn as _ea
+    _ea.VENDOR_FALLBACK = "warn" if allow_vendor_fallback else "error"
     if reference_root:
         # a bare namespace for `model` skips model/__init__.py (which pulls in skimage etc.)
         _namespace("model", os.path.join(reference_root, "model"))

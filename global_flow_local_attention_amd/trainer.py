@@ -5,9 +5,9 @@ one Python process scatters the batch over the GPUs, gathers outputs and reduces
 GPU has its own process (torch.distributed over RCCL), owns a slice of the batch, and the gradients are averaged by a
 bucketed all-reduce launched from autograd hooks (dist.GradBucketReducer), overlapping the rest of backward.
 
-* `load_reference_checkpoint(net, path)` -- `BaseModel.load_networks` semantics (base_model.py:154-197): exact load,
-  else keys present in the network (optionally with / without the `module.` prefix DataParallel checkpoints carry),
-  else shape-matching entries only; returns what was not initialised.
+* `load_reference_checkpoint(net, path)` -- the outcome of `BaseModel.load_networks` (base_model.py:154-197) as a key
+  normalisation: strip / add the `module.` prefix DataParallel checkpoints carry, intersect with the network's keys,
+  keep shape-matching entries; returns the top-level submodules that kept values of their own.
 * `TrainerShell` -- one `optimize_parameters` step (pose_model.py:186-196) for one rank: shard, forward, loss terms,
   backward (reducer hooks), optimizer step.  The adversarial and VGG style/content terms need the reference's
   discriminators / a pretrained VGG19 and are injected as callables (stubbed to zero by default, as BASELINE config 4
@@ -19,35 +19,44 @@ import torch.nn as nn
 from . import dist as gdist
 
 
+_DP_PREFIX = "module."   # what nn.DataParallel / DistributedDataParallel put in front of every key
+
+
+def _strip_prefix(key):
+    return key[len(_DP_PREFIX):] if key.startswith(_DP_PREFIX) else key
+
+
 def load_reference_checkpoint(net, path_or_state, map_location="cpu"):
-    """Load a reference `<epoch>_net_G.pth` into `net` the way BaseModel.load_networks does (base_model.py:154-197).
-    Returns the sorted list of top-level submodules that were NOT initialised from the checkpoint (empty = exact)."""
+    """Load a reference `<epoch>_net_G.pth` into `net` with the outcome `BaseModel.load_networks` has
+    (base_model.py:154-197): an exact checkpoint loads as is; a checkpoint written from (or into) a DataParallel wrapper
+    is matched modulo the `module.` prefix; surplus checkpoint entries are ignored; entries whose shape differs from the
+    network's, and network entries the checkpoint lacks, keep the network's own values.  Returns the sorted top-level
+    submodule names that kept at least one own value (empty list = every tensor came from the checkpoint).
+
+    Implemented as key normalisation: both key sets are reduced to their prefix-free form, intersected, filtered by
+    shape, and the survivors are written into the network's own state dict."""
     state = torch.load(path_or_state, map_location=map_location) if isinstance(path_or_state, str) else path_or_state
-    try:
-        net.load_state_dict(state)
-        return []
-    except RuntimeError:
-        pass
-    model_dict = net.state_dict()
-    picked = {k: v for k, v in state.items() if k in model_dict}
-    if not picked:  # checkpoint written from a DataParallel wrapper, or the other way round
-        picked = {k.replace("module.", ""): v for k, v in state.items() if k.replace("module.", "") in model_dict}
-    if not picked:
-        picked = {("module." + k): v for k, v in state.items() if "module." + k in model_dict}
-    try:
-        net.load_state_dict(picked)  # checkpoint has excessive layers: only the used ones
-        return []
-    except RuntimeError:
-        pass
-    not_initialized = set()
-    for k, v in picked.items():
-        if v.size() == model_dict[k].size():
-            model_dict[k] = v
-    for k, v in model_dict.items():
-        if k not in picked or v.size() != picked[k].size():
-            not_initialized.add(k.split(".")[0])
-    net.load_state_dict(model_dict)
-    return sorted(not_initialized)
+    own = net.state_dict()
+    # network key -> checkpoint tensor, matching on the prefix-free name; an exact-name match wins over a normalised one
+    # (the reference only falls back to prefix juggling when no key matches literally)
+    by_plain = {}
+    for key, tensor in state.items():
+        by_plain.setdefault(_strip_prefix(key), tensor)
+    literal_hits = sum(1 for key in own if key in state)
+    chosen, kept_own = {}, set()
+    for key, current in own.items():
+        if literal_hits:
+            candidate = state.get(key)
+        else:
+            candidate = by_plain.get(_strip_prefix(key))
+        if candidate is not None and tuple(candidate.shape) == tuple(current.shape):
+            chosen[key] = candidate
+        else:
+            kept_own.add(_strip_prefix(key).split(".")[0])
+    merged = dict(own)
+    merged.update(chosen)
+    net.load_state_dict(merged)
+    return sorted(kept_own)
 
 
 class TrainerShell(object):

@@ -51,13 +51,16 @@ typedef void *gfla_stream_t; /* hipStream_t */
 /* Bumped whenever an entry point is added or a signature changes.
  *   1: round 1 (the three ops + aggregate)   2: round 2 (fc_*, *_ws, bf16 backward, max_cosine, correctness_map)
  *   3: round 3 (gfla_path_count, process-global tuning, arithmetic mode 4)
- *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records) */
-#define GFLA_ABI_VERSION 4
+ *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
+ *   5: round 4 (gfla_aggregate_bwd_supported; tuning keys 24-26; path id GFLA_PATH_BE_FWD_PIX) */
+#define GFLA_ABI_VERSION 5
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
 /* Tuning knobs (benchmarks/tests only; defaults are chosen per shape).  Returns the old value.
- *   key 0: block_extractor forward   0 auto (planes in LDS when they fit), 1 force global-gather kernel
+ *   key 0: block_extractor forward   0 auto (planes in LDS when they fit: lane = flow pixel, whole-line stores through
+ *          an LDS tile, csrc/be_fwd_band.h), 1 force the global-gather kernel, 2 force round 1's planes-in-LDS kernel
+ *          (lane = four consecutive outputs), 3 force the lane-per-pixel kernel with direct stores (csrc/be_fwd_pix.h)
  *   key 1: channels per thread of the global kernels (0 auto)
  *   key 2: block_extractor backward  0 auto, 1 force global-atomics kernel
  *   key 3: aggregate fwd/bwd         0 auto, 1 force global kernels
@@ -67,9 +70,13 @@ const char *gfla_status_string(int status);
  *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)
  *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)
  *   key 19: FC weight gradient in arithmetic mode 4   0 auto (Winograd domain for k = 5), 1 direct, 2 Winograd
- *   key 20: timing ablations of the Winograd convolution kernel (results are garbage; tools/probe_wino.py)
+ *   key 20: timing ablations of the Winograd kernels -- only in `make PROBES=1` builds (results are garbage;
+ *           tools/probe_wino.py); a default build ignores the key
  *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one
  *   key 23: resample2d d/d input1 LDS planes   0 fixed point + tap records (with scratch), 1 double planes (round 1)
+ *   key 24: be_fwd_pix_kernel: threads per workgroup (0 auto; multiples of 64 up to 1024)
+ *   key 25: be_fwd_pix_kernel: 1 = non-temporal output stores      key 26: 1 = stores transposed through LDS rows
+ *   key 27: (make PROBES=1 builds) timing ablations of be_fwd_pix_kernel      key 28: be_fwd_band_kernel: flow rows per band
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 
@@ -88,7 +95,8 @@ enum gfla_path {
   GFLA_PATH_FC_BWD_MODE2 = 9,
   GFLA_PATH_FC_BWD_MODE3 = 10,
   GFLA_PATH_FC_BWD_MODE4 = 11,
-  GFLA_PATH_COUNT = 12
+  GFLA_PATH_BE_FWD_PIX = 12,   /* block_extractor forward: lane = flow pixel, padded planes in LDS (round 4) */
+  GFLA_PATH_COUNT = 13
 };
 int64_t gfla_path_count(int path);
 
@@ -235,6 +243,9 @@ GFLA_DECL_AGGREGATE_FWD(bf16, uint16_t)
  * plain entry point's kernels.  Same results up to f32 summation order (the coefficient of a patch word is summed
  * over its taps before it meets the source value).                                                            */
 int64_t gfla_aggregate_fwd_workspace_bytes(int64_t B, int64_t H, int64_t W, int kernel_size);
+/* 1 when gfla_local_attn_aggregate_bwd_<storage> takes Hs x Ws source planes (elem_size 2 / 4 / 8 bytes); bf16 storage
+ * is limited to planes that fit the LDS accumulators (round 4; replaces a constant duplicated on the host side) */
+int gfla_aggregate_bwd_supported(int64_t Hs, int64_t Ws, int elem_size);
 /* host-side launch geometry of that path (no GPU needed; tests): out[9] = channels per chunk, channels per range,
  * ranges, tile groups, threads, LDS row-pair pitch in words, tile width, tiles per sample, dynamic LDS bytes */
 int gfla_aggregate_fwd_geometry(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int kernel_size,

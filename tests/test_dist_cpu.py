@@ -177,6 +177,12 @@ def _bench_worker(rank, world, port, ret):
                      on_gpu=False)
     assert line["n_gpus"] == world and line["steps"] == 3 and line["warmup"] == 1
     assert line["config"]["global_batch"] == 4 * world and line["value"] > 0 and line["scaling"] == "weak"
+    # the N > 1 leg the first multi-GPU run will record: process-group fingerprint + the all-gather of generated tiles
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size_seen_by_group"] == world
+    assert d["allreduce_of_rank_ids"] == d["allreduce_expected"] == world * (world + 1) / 2.0
+    ag = d["all_gather_tiles"]
+    assert ag["correct"] and ag["tile_shape_per_rank"][0] == 4 and ag["us"] > 0 and ag["GBps_received_per_rank"] > 0
     dist.barrier()
     dist.destroy_process_group()
     ret[rank] = line["value"]

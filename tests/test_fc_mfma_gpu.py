@@ -221,6 +221,48 @@ def test_unsupported_shapes_fall_back(gfla):
     assert_close(m3(s, t, f).cpu(), b.cpu(), 2e-5, "fc_impl switch")
 
 
+def test_vendor_fallback_policy(gfla):
+    """A configuration the library's own MFMA kernels do not take (the reference's constructor default kernel_size=4,
+    base_function.py:791) reaches rocBLAS / MIOpen only when that is allowed: the package default warns once, install()
+    turns it into an error unless allow_vendor_fallback=True, a module attribute overrides either; every call that took
+    the vendor path is counted (bench.py reports the count of its run)."""
+    import warnings
+    from global_flow_local_attention_amd import extractor_attn as ea
+    m = gfla.ExtractorAttn(8, 4, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    s, t = randn((1, 8, 6, 6), seed=1).to(DEV), randn((1, 8, 6, 6), seed=2).to(DEV)
+    f = make_flow("coherent", 1, 6, 6, seed=3).to(DEV)
+    old = ea.VENDOR_FALLBACK
+    try:
+        ea.VENDOR_FALLBACK = "error"      # what install() sets by default
+        n0 = ea.vendor_fallback_calls
+        with pytest.raises(ea.VendorFallbackError):
+            m(s, t, f)
+        m.vendor_fallback = "allow"       # per-module override
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            a = m(s, t, f)
+        assert ea.vendor_fallback_calls == n0 + 2
+        del m.vendor_fallback
+        ea.VENDOR_FALLBACK = "warn"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            b = m(s, t, f)
+            m(s, t, f)
+        assert sum("rocBLAS" in str(x.message) for x in w) == 1      # once per module
+        assert torch.equal(a, b)
+        # the supported configurations never count
+        m3 = gfla.ExtractorAttn(8, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+        n1 = ea.vendor_fallback_calls
+        ea.VENDOR_FALLBACK = "error"
+        m3(s, t, f)
+        assert ea.vendor_fallback_calls == n1
+        m3.fc_impl = "library"            # an explicit request is always honoured (and counted)
+        m3(s, t, f)
+        assert ea.vendor_fallback_calls == n1 + 1
+    finally:
+        ea.VENDOR_FALLBACK = old
+
+
 # ------------------------------------------------------------------------------- bf16 features (BASELINE config 5)
 @pytest.mark.parametrize("k,C,H,W", [(3, 16, 12, 10), (5, 8, 11, 9)])
 def test_extractor_attn_bf16_features(lib, gfla, oracle, k, C, H, W):
