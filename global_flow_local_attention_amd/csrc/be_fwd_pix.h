@@ -1,30 +1,28 @@
-// block_extractor forward in the REFERENCE layout (B, C, K*Hf, K*Wf), lane = flow pixel (round 4).
+// block_extractor forward in the REFERENCE layout (B, C, K*Hf, K*Wf), lane = flow pixel, direct stores (round 4).
 //
-// What bounded the first planes-in-LDS kernel (be_fwd_lds_kernel, lane = 4 consecutive output x): its per-lane setup --
+// What bounded round 1's planes-in-LDS kernel (be_fwd_lds_kernel, lane = 4 consecutive output x): its per-lane setup --
 // four flow lookups, four floor/clamp/weight sets, integer divisions by a run-time k -- is paid per output QUAD and per
 // channel group, ~120 vector instructions against the ~40 of the four channels it is amortised over, and every output
-// costs four ds_read_b32 (block_extractor_kernel.cu:78-84 read tap by tap).  Measured 0.54 of the HBM peak at
-// (32,128,64,44) k=5 whatever the flow, while the same values in the unfold layout -- lane = flow pixel, one setup per
-// k*k outputs, the (k+1)^2 dense patch read once -- stream at 0.63-0.70.
+// costs four ds_read_b32 (block_extractor_kernel.cu:78-84 read tap by tap): 4.2-4.5 TB/s whatever the map width.
 //
-// Here the flow pixel owns the lane for the reference layout too:
+// Here the flow pixel owns the lane:
 //   * setup once per pixel and chunk of CH channels: one flow pair, K floor/fraction pairs, the patch origin;
 //   * the planes sit in LDS REPLICATE-PADDED by K columns on either side, so a dense patch row is K+1 consecutive words
 //     at (row base + immediate offset): no per-tap address arithmetic and no column clamp in the channel loop;
 //   * the four weights of an output (xL_P*yT_P, ... -- the reference's products, block_extractor_kernel.cu:73-84, same
-//     order of accumulation) are formed once per (i, j) and used for the CH channels of the chunk;
+//     order of accumulation, fused multiply-adds) are formed once per (i, j) and used for the CH channels of the chunk;
 //   * a lane's K outputs of an output row are K consecutive floats: ONE 16-byte + one 4-byte store (k = 5), 8 + 4
-//     (k = 3); the 64 lanes of a wave cover 64*K*4 contiguous bytes of the row, so every line is written whole by two
-//     back-to-back instructions of one wave.
+//     (k = 3), at a K*4-byte lane stride.
+// Measured (profiles/r4_be_fwd_pix_ablations.jsonl, r4_be_fwd_widths*.jsonl): 80 us of arithmetic at (32,128,64,44) k=5
+// (stores compiled out) but 340 us with them, with or without the LDS reads: bound by the write stream, which runs at
+// 5.1-5.2 TB/s when an output row is a whole number of 128-byte lines (Wf = 32, 64, 96) and 3.5-4.1 TB/s otherwise.
+// So this kernel serves flow rows WIDER than 64 pixels; up to 64 the wave-per-flow-row kernel (be_fwd_wrow.h) takes
+// over.  Tried on top and dropped: non-temporal stores (they skip the L2's merging: half the rate), the K outputs
+// transposed through a per-wave LDS row so that the lanes of a store are consecutive (two LDS round trips per output
+// row: 3.2 TB/s, and a store-only micro-benchmark shows the pattern itself is no faster, tools/ubench/store_patterns.hip).
 // A pixel whose taps are not a dense patch (a coordinate within rounding of an integer) is evaluated tap by tap, as the
 // reference does, on the same padded planes.
 #pragma once
-#ifndef GFLA_PIX_CH5
-#define GFLA_PIX_CH5 4
-#endif
-#ifndef GFLA_PIX_WPRE
-#define GFLA_PIX_WPRE 0
-#endif
 
 #include "lds_plane.h"
 
@@ -72,21 +70,14 @@ __device__ __forceinline__ void store_row(T *p, const T (&o)[K]) {
   }
 }
 
-// XP: the K outputs a lane owns per output row leave through a per-wave LDS row (64*K elements) and are stored with the
-// LANES consecutive in memory -- 64 elements = full 64-byte segments per store instruction.  Measured without it
-// (profiles/r4_north_star_sweep.jsonl): the direct 16 + 4 byte stores at a 20-byte lane stride reach 0.71 of the HBM peak
-// at (32,256,32,22) k=3 and 0.62 at (32,128,64,64) k=5 but 0.45 at (32,128,64,44) k=5 -- every quad of lanes straddles a
-// 64-byte segment, so the L2 takes ~2.6x the write requests of a contiguous stream (non-temporal stores, which skip the
-// L2's merging, halve the rate again: 0.22).
-template <typename T, int K, int CH, bool NT, bool XP, bool WPRE, int ABL = 0>
+template <typename T, int K, int CH, bool NT, int ABL = 0>
 __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf,
-    int G, int ngroups, int split, int stage_off) {
+    int G, int ngroups, int split) {
   using A = typename Num<T>::acc;
   constexpr int PAD = K;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   A *planes = reinterpret_cast<A *>(gfla_smem);
-  T *stage = reinterpret_cast<T *>(gfla_smem + stage_off) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (64 * K);  // this wave's row
   int bid = blockIdx.x;
   const int sp = bid % split;
   bid /= split;
@@ -179,26 +170,7 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
     const A *plc = planes + cbase * plane_p;
     T *oplane0 = out + ((int64_t)b * C + c0 + cbase) * oplane;   // output plane of the chunk's first channel
     const int ooff = (K * yf) * Wo + K * xf;                     // this lane's pixel: first output of its first row
-    // transposed stores: in round r this lane stores element t = 64 r + lane of the wave's row = output j of pixel t / K;
-    // goff < 0: nothing to store (beyond the last pixel, or a pixel that is not a dense patch -- those store their own
-    // rows below)
-    int goff[XP ? K : 1];
-    if constexpr (XP) {
-#pragma unroll
-      for (int r = 0; r < K; ++r) {
-        const int t = 64 * r + lane;
-        const int q = t / K, j = t - q * K;
-        const int p2 = p0 + (blk << 6) + q;
-        const bool ok = (p2 < p1) & (__shfl((int)dense, q) != 0);
-        const int pc = p2 < p1 ? p2 : p1 - 1;
-        const int y2 = pc / Wf, x2 = pc - y2 * Wf;
-        goff[r] = ok ? (K * y2) * Wo + K * x2 + j : -1;
-      }
-    }
-    // XP: every lane walks the dense-patch code (it feeds other lanes' stores); its reads are clamped into the planes
-    const bool run_dense = XP ? (__any((int)dense) != 0) : dense;
-
-    if (run_dense) {
+    if (dense) {
       // padded column of tap 0 and the row bases (clamped rows; replicated columns are in the plane)
       const int x0c = clampi(x0, -PAD, Ws - 1) + PAD;
       const int y0c = clampi(y0, -(K + 1), Hs);
@@ -217,10 +189,9 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
         const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;   // as in the setup loop: the same bits
         const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
         const int rowx = clampi(y0c + i + 1, 0, Hs - 1) * Wp + x0c;
-        // the four weights of an output (:73-76) as the reference forms them; WPRE keeps them in registers for the CH
-        // channels of the chunk, otherwise they are re-formed per channel (4 multiplies more per output, 20 registers less)
-        A w[WPRE ? K : 1][4];
-        if constexpr (WPRE) {
+        // the four weights of an output (:73-76) as the reference forms them, kept for the CH channels of the chunk
+        A w[K][4];
+        {
 #pragma unroll
           for (int j = 0; j < K; ++j) {
             const A xR_P = ax[j], xL_P = 1 - xR_P;
@@ -239,39 +210,14 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
           T o[K];
 #pragma unroll
           for (int j = 0; j < K; ++j) {
-            A w0, w1, w2, w3;
-            if constexpr (WPRE) {
-              w0 = w[j][0], w1 = w[j][1], w2 = w[j][2], w3 = w[j][3];
-            } else {
-              const A xR_P = ax[j], xL_P = 1 - xR_P;
-              w0 = xL_P * yT_P, w1 = xR_P * yT_P, w2 = xL_P * yB_P, w3 = xR_P * yB_P;
-            }
-            A s = w0 * vA[cc][j];  // :78-84, same order of accumulation (contracted to fma as nvcc does)
-            s = fma_t(w1, vA[cc][j + 1], s);
-            s = fma_t(w2, vB[j], s);
-            s = fma_t(w3, vB[j + 1], s);
+            A s = w[j][0] * vA[cc][j];  // :78-84, same order of accumulation (contracted to fma as nvcc does)
+            s = fma_t(w[j][1], vA[cc][j + 1], s);
+            s = fma_t(w[j][2], vB[j], s);
+            s = fma_t(w[j][3], vB[j + 1], s);
             o[j] = Num<T>::from(s);
           }
           T *oc = oplane0 + cc * oplane + (int64_t)i * Wo;
-          if constexpr (XP) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) stage[K * lane + j] = o[j];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            if (cc < ncc) {
-#pragma unroll
-              for (int r = 0; r < K; ++r) {
-                const T val = stage[64 * r + lane];
-                if constexpr (ABL & 2) {
-                  if (goff[r] >= 0 && (A)val == (A)12345.678) oc[goff[r]] = val;
-                } else {
-                  if (goff[r] >= 0) oc[goff[r]] = val;
-                }
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-          } else if constexpr (ABL & 2) {   // timing ablation: no stores (one impossible store keeps the arithmetic alive)
+          if constexpr (ABL & 2) {   // timing ablation: no stores (one impossible store keeps the arithmetic alive)
             A sum = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) sum += (A)o[j];
@@ -372,35 +318,23 @@ template <typename T, int K>
 static int launch_fwd_pix(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
                           int64_t Wf, hipStream_t stream, bool *done) {
   using A = typename Num<T>::acc;
-  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 5 ? GFLA_PIX_CH5 : 4);
-  constexpr bool WPRE = GFLA_PIX_WPRE != 0;  // register budget: CH x (K+1) patch values + K x 4 weights per lane
+  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : 4;  // register budget: CH x (K+1) patch values + K x 4 weights
   *done = false;
   const PixGeo g = pix_geometry<CH>(B, C, Hs, Ws, Hf, Wf, K, (int)sizeof(A));
   if (g.G <= 0) return GFLA_OK;
   const int64_t blocks = B * g.ngroups * g.split;
   if (blocks > 0x7fffffffLL) return GFLA_OK;
   const dim3 grid((unsigned)blocks), block((unsigned)g.threads);
-  // key 26 = 1: stores transposed through a per-wave LDS row (measured slower: the LDS round trips serialise);
-  // key 25 = 1: non-temporal direct stores (half the rate: they skip the L2's merging) -- both kept for A/B
-  const bool direct = tuning(26) != 1;
-  const unsigned stage_bytes = direct ? 0u : (unsigned)((g.threads / 64) * 64 * K * sizeof(T));
-  const int stage_off = (int)((g.lds_bytes + 15u) & ~15u);
-  const unsigned lds = (unsigned)stage_off + stage_bytes;
-#define GFLA_PIX_LAUNCH(NT_, XP_)                                                                                       \
-  launch_lds(be_fwd_pix_kernel<T, K, CH, NT_, XP_, WPRE>, grid, block, lds, stream, src, flow, out, (int)C, (int)Hs, (int)Ws, \
-             (int)Hf, (int)Wf, g.G, g.ngroups, g.split, stage_off)
-#ifdef GFLA_PROBES
-  if (!direct && tuning(27) == 2) launch_lds(be_fwd_pix_kernel<T, K, CH, false, true, WPRE, 2>, grid, block, lds, stream, src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, stage_off);
-  else
-#endif
-  if (!direct) GFLA_PIX_LAUNCH(false, true);
-  else if (tuning(25) == 1) GFLA_PIX_LAUNCH(true, false);
+#define GFLA_PIX_LAUNCH(NT_, ABL_)                                                                                      \
+  launch_lds(be_fwd_pix_kernel<T, K, CH, NT_, ABL_>, grid, block, g.lds_bytes, stream, src, flow, out, (int)C, (int)Hs,   \
+             (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split)
+  if (tuning(25) == 1) GFLA_PIX_LAUNCH(true, 0);   // non-temporal stores: measured at half the rate, kept for A/B
 #ifdef GFLA_PROBES   // timing ablations (results are garbage): key 27 bit 0 = no patch reads, bit 1 = no stores
-  else if (tuning(27) == 1) launch_lds(be_fwd_pix_kernel<T, K, CH, false, false, WPRE, 1>, grid, block, lds, stream, src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, stage_off);
-  else if (tuning(27) == 2) launch_lds(be_fwd_pix_kernel<T, K, CH, false, false, WPRE, 2>, grid, block, lds, stream, src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, stage_off);
-  else if (tuning(27) == 3) launch_lds(be_fwd_pix_kernel<T, K, CH, false, false, WPRE, 3>, grid, block, lds, stream, src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.split, stage_off);
+  else if (tuning(27) == 1) GFLA_PIX_LAUNCH(false, 1);
+  else if (tuning(27) == 2) GFLA_PIX_LAUNCH(false, 2);
+  else if (tuning(27) == 3) GFLA_PIX_LAUNCH(false, 3);
 #endif
-  else GFLA_PIX_LAUNCH(false, false);
+  else GFLA_PIX_LAUNCH(false, 0);
 #undef GFLA_PIX_LAUNCH
   *done = true;
   return launch_status();

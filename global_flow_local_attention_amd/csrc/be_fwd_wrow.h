@@ -24,7 +24,7 @@
 
 namespace gfla {
 
-template <typename T, int K>
+template <typename T, int K, int ABL = 0>
 __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf,
     int G, int ngroups, int rpw, int tile_off, int tile_stride) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
           {
             const A *pr = pc + clampi(y0c, 0, Hs - 1) * Wp + x0c;
 #pragma unroll
-            for (int s = 0; s <= K; ++s) vA[s] = pr[s];
+            for (int s = 0; s <= K; ++s) vA[s] = (ABL & 1) ? (A)(lane + s) : pr[s];
           }
 #pragma unroll
           for (int i = 0; i < K; ++i) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
             const A *pr = pc + clampi(y0c + i + 1, 0, Hs - 1) * Wp + x0c;
             A vB[K + 1];
 #pragma unroll
-            for (int s = 0; s <= K; ++s) vB[s] = pr[s];
+            for (int s = 0; s <= K; ++s) vB[s] = (ABL & 1) ? (A)(lane + s + i) : pr[s];
             T *to = tl + trow + i * Wo;
 #pragma unroll
             for (int j = 0; j < K; ++j) {  // :73-84
@@ -201,7 +201,14 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
         const V4 *t4 = reinterpret_cast<const V4 *>(tl + head);
         V4 *d4 = reinterpret_cast<V4 *>(dst + head);
 #pragma unroll 2
-        for (int m = lane; m < body; m += 64) d4[m] = t4[m];
+        for (int m = lane; m < body; m += 64) {
+          const V4 val = t4[m];
+          if constexpr (ABL & 2) {   // timing ablation (make PROBES=1): no stores; one impossible store keeps the reads alive
+            if (val[0] == (T)12345.678) d4[m] = val;
+          } else {
+            d4[m] = val;
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
@@ -278,6 +285,16 @@ static int launch_fwd_wrow(const T *src, const T *flow, T *out, int64_t B, int64
   if (g.G <= 0) return GFLA_OK;
   const int64_t blocks = B * g.ngroups;
   if (blocks > 0x7fffffffLL || (int64_t)K * K * Hf * Wf > 0x7fffffffLL) return GFLA_OK;
+#ifdef GFLA_PROBES   // timing ablations (results are garbage): key 27 bit 0 = no patch reads, bit 1 = no output stores
+#define GFLA_WROW_ABL(N_)                                                                                                 \
+  launch_lds(be_fwd_wrow_kernel<T, K, N_>, dim3((unsigned)blocks), dim3((unsigned)g.threads), g.lds_bytes, stream, src,    \
+             flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.rpw, g.tile_off, g.tile_stride)
+  if (tuning(27) == 1) GFLA_WROW_ABL(1);
+  else if (tuning(27) == 2) GFLA_WROW_ABL(2);
+  else if (tuning(27) == 3) GFLA_WROW_ABL(3);
+  else
+#undef GFLA_WROW_ABL
+#endif
   launch_lds(be_fwd_wrow_kernel<T, K>, dim3((unsigned)blocks), dim3((unsigned)g.threads), g.lds_bytes, stream, src, flow,
              out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.G, g.ngroups, g.rpw, g.tile_off, g.tile_stride);
   *done = true;

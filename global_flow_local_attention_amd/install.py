@@ -34,7 +34,8 @@ def _namespace(name, path=None):
     return mod
 
 
-def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, allow_vendor_fallback=False):
+def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, allow_vendor_fallback=False,
+            dual_stream_face=False):
     """Alias the three op modules; optionally patch the reference's ExtractorAttn with the fused
     forward.  `reference_root` (a checkout of the reference) is only needed if `model` is not
     already importable.  Returns the reference's `model.networks.base_function` module when it
@@ -43,7 +44,11 @@ def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, al
     allow_vendor_fallback: an ExtractorAttn configuration this library's own MFMA kernels do not take (kernel_size other
     than 3 / 5 -- the reference's constructor default is 4 --, float64 features, maps too large for the LDS tiles) would
     run its FC layers through rocBLAS / MIOpen.  After install() that RAISES (extractor_attn.VendorFallbackError) unless
-    this flag is True (then it warns once per module); the production configurations (kernel_size 2=5, 3=3) never reach it."""
+    this flag is True (then it warns once per module); the production configurations (kernel_size 2=5, 3=3) never reach it.
+
+    dual_stream_face: also patch the reference's FaceTargetNet.forward (generator.py:480-505) so that the two ExtractorAttn
+    of an attention layer (previous frame / reference frame) run on two HIP streams (face_step.py).  Imports the
+    reference's generator module."""
     from . import extractor_attn as _ea
     _ea.VENDOR_FALLBACK = "warn" if allow_vendor_fallback else "error"
     if reference_root:
@@ -78,4 +83,8 @@ def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, al
             base_function = None
     if base_function is not None and fuse_extractor_attn and hasattr(base_function, "ExtractorAttn"):
         patch_reference_extractor_attn(base_function.ExtractorAttn)
+    if base_function is not None and dual_stream_face:
+        from .face_step import patch_reference_face_target_net
+        generator = importlib.import_module("model.networks.generator")
+        patch_reference_face_target_net(generator.FaceTargetNet)
     return base_function

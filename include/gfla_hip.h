@@ -58,9 +58,10 @@ int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
 /* Tuning knobs (benchmarks/tests only; defaults are chosen per shape).  Returns the old value.
- *   key 0: block_extractor forward   0 auto (planes in LDS when they fit: lane = flow pixel, whole-line stores through
- *          an LDS tile, csrc/be_fwd_band.h), 1 force the global-gather kernel, 2 force round 1's planes-in-LDS kernel
- *          (lane = four consecutive outputs), 3 force the lane-per-pixel kernel with direct stores (csrc/be_fwd_pix.h)
+ *   key 0: block_extractor forward   0 auto (planes in LDS when they fit: flow rows of up to 64 pixels -> the
+ *          wave-per-flow-row kernel, csrc/be_fwd_wrow.h; wider -> the lane-per-pixel kernel, csrc/be_fwd_pix.h),
+ *          1 force the global-gather kernel, 2 force round 1's planes-in-LDS kernel (lane = four consecutive outputs),
+ *          3 force the lane-per-pixel kernel, 4 force the wave-per-flow-row kernel
  *   key 1: channels per thread of the global kernels (0 auto)
  *   key 2: block_extractor backward  0 auto, 1 force global-atomics kernel
  *   key 3: aggregate fwd/bwd         0 auto, 1 force global kernels
@@ -74,9 +75,9 @@ const char *gfla_status_string(int status);
  *           tools/probe_wino.py); a default build ignores the key
  *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one
  *   key 23: resample2d d/d input1 LDS planes   0 fixed point + tap records (with scratch), 1 double planes (round 1)
- *   key 24: be_fwd_pix_kernel: threads per workgroup (0 auto; multiples of 64 up to 1024)
- *   key 25: be_fwd_pix_kernel: 1 = non-temporal output stores      key 26: 1 = stores transposed through LDS rows
- *   key 27: (make PROBES=1 builds) timing ablations of be_fwd_pix_kernel      key 28: be_fwd_band_kernel: flow rows per band
+ *   key 24: be_fwd_pix_kernel / be_fwd_wrow_kernel: threads per workgroup (0 auto; multiples of 64 up to 1024)
+ *   key 25: be_fwd_pix_kernel: 1 = non-temporal output stores (A/B only: half the rate)
+ *   key 27: (make PROBES=1 builds) timing ablations of the two round-4 block_extractor forward kernels
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 

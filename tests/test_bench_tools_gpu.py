@@ -1,6 +1,5 @@
-"""bench.py's own machinery on a small batch: the hipGraph capture of a whole forward + backward step, the north star's
-op-level roofline leg, and the oracle check (max-abs on two samples) -- so that a typo there does not burn the driver's one
-bench run."""
+"""bench.py's own machinery on a small batch: the north star's op-level roofline leg and the oracle check (max-abs on two
+samples) -- so that a typo there does not burn the driver's one bench run."""
 import pytest
 import torch
 
@@ -13,30 +12,6 @@ def _hotpath(B=2):
     import global_flow_local_attention_amd as gfla
     hp = bench.HotPath(B, DEV, seed=5, fc_impl="mfma", fc_mode=4)
     return bench, hp, gfla.Resample2d(4, 1, 2)
-
-
-def test_whole_step_hipgraph_matches_eager():
-    bench, hp, resample = _hotpath()
-    hp.step(resample, allreduce=False)
-    leaves = [x for tup in hp.inputs for x in tup] + hp.vgg + hp.params()
-    eager = [t.grad.detach().clone() for t in leaves]
-    graph, outs = bench.capture_step(hp, resample)
-    for _ in range(2):      # replays land in the same buffers
-        graph.replay()
-    torch.cuda.synchronize()
-    for t, e in zip(leaves, eager):
-        err = (t.grad - e).abs().max().item() / max(1e-30, e.abs().max().item())
-        assert err <= 1e-5, err     # (the FC tail's splat uses float atomics: not bit-reproducible run to run)
-    # new inputs are copied into the captured tensors; the replayed step sees them
-    with torch.no_grad():
-        hp.inputs[0][0].mul_(2.0)
-    graph.replay()
-    torch.cuda.synchronize()
-    replayed = [t.grad.detach().clone() for t in leaves]
-    hp.step(resample, allreduce=False)
-    for t, r in zip(leaves, replayed):
-        err = (t.grad - r).abs().max().item() / max(1e-30, r.abs().max().item())
-        assert err <= 1e-5, err
 
 
 def test_north_star_leg_and_oracle_check_run():

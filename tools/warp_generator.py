@@ -1,7 +1,8 @@
 """A generator-SHAPED network around the hot path.
 
-The reference generators (model/networks/generator.py) are consumed unchanged through `install()` where the reference
-checkout exists; it does not exist on the GPU box.  `WarpGenerator` is this package's own small network with the same
+TEST / BENCH INFRASTRUCTURE (not part of the product package).  The reference generators (model/networks/generator.py)
+are consumed unchanged through `install()` where the reference checkout exists; it does not exist on the GPU box.
+`WarpGenerator` is a small stand-in network with the same
 *shape* of autograd graph around the ops -- what the trainer shell, the gradient reducer and `bench.py --workload
 trainer_step` need to exercise on hardware:
 
@@ -25,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .extractor_attn import ExtractorAttn
+from global_flow_local_attention_amd.extractor_attn import ExtractorAttn
 
 
 def _act():
