@@ -100,6 +100,9 @@ class HotPath:
             self.inputs.append((src, tgt, flow))
         self.upstream = None
         self.reducer = None
+        # the loss-side warps on a second HIP stream (step()): measured 4.54 against 4.66 ms per step
+        # (profiles/r4_two_streams.txt); `variants.one_stream` in the line is the same step on one stream
+        self.two_streams = True
         for (name, C, H, W) in VGG:
             feat = torch.randn(B, C, H, W, device=device, generator=gen).requires_grad_(vgg_grad)
             self.vgg.append(feat)
@@ -118,7 +121,25 @@ class HotPath:
     def step(self, resample, allreduce=True):
         """Forward through both attention layers and both resample sites, then backward from fixed
         upstream gradients (what the rest of the generator / the losses would send back) -- no
-        synthetic loss kernels inside the timed region."""
+        synthetic loss kernels inside the timed region.
+        self.two_streams: the warps of the sampling-correctness loss (Resample2d of the VGG features by the flow fields,
+        external_function.py:274) are a branch of the training graph that shares only the flow fields with the generator's
+        attention layers; they are issued on a side stream (forward here, backward by autograd on the same stream)."""
+        if getattr(self, "two_streams", False) and self.losses is None and self.inputs[0][0].is_cuda:
+            cur = torch.cuda.current_stream(self.inputs[0][0].device)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.inputs[0][0].device)
+            ready = cur.record_event()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                warps = [resample(feat, flow) for feat, (_, _, flow) in zip(self.vgg, self.inputs)]
+                done = self._side.record_event()
+            outs = [mod(src, tgt, flow) for mod, (src, tgt, flow) in zip(self.attn, self.inputs)]
+            cur.wait_event(done)
+            for w in warps:
+                w.record_stream(cur)
+            outs += warps
+            return self._backward(outs, allreduce)
         outs = [mod(src, tgt, flow) for mod, (src, tgt, flow) in zip(self.attn, self.inputs)]
         if self.losses is not None:
             corr, reg = self.losses
@@ -129,6 +150,9 @@ class HotPath:
             outs.append(loss.reshape(1))
         else:
             outs += [resample(feat, flow) for feat, (_, _, flow) in zip(self.vgg, self.inputs)]
+        return self._backward(outs, allreduce)
+
+    def _backward(self, outs, allreduce):
         if self.upstream is None:
             gen = torch.Generator(device=outs[0].device).manual_seed(4321)
             self.upstream = [torch.randn(o.shape, device=o.device, generator=gen) / o[0].numel() for o in outs]
@@ -564,6 +588,7 @@ def fc_kernel_probes(hp, iters=10):
                     eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
                     kern = "fc_wino_conv_kernel"
                     row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
                                 "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
                                 "in_step": True})
                 elif mode == 4 and (which < 4 or k == 5):   # (k = 3 weight gradient: the direct kernel, csrc/fc_block.hip)
@@ -575,7 +600,11 @@ def fc_kernel_probes(hp, iters=10):
                     ext = {0: k - 1, 1: 0, 2: 2 * (k - 1), 3: k - 1, 4: k - 1, 5: 0}[which]
                     tiles = B * (-(-(H + ext) // m)) * (-(-(W + ext) // m))
                     done = 2.0 * 36 * tiles * C * 128
+                    # `useful`: the same count over the UN-extended H x W domain -- the tiles whose outputs the caller keeps
+                    # (the source half convolves an (H+k-1) x (W+k-1) map, the data gradients the padded domain)
+                    useful = 2.0 * 36 * B * (-(-H // m)) * (-(-W // m)) * C * 128
                     row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "useful_GFLOP": round(useful / 1e9, 2),
                                 "effective_GFLOP": round(flops / 1e9, 2),
                                 "effective_TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 else:
@@ -921,6 +950,17 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         notes = {0: "float32, DIRECT convolution kernels (a k-ordered fma chain per output): the same step without the "
                     "Winograd-domain formulation",
                  4: "float32, Winograd-domain convolutions and weight gradient (the product default)"}
+        # the same step with the loss-side warps on a side stream (HotPath.step)
+        hv = make_hotpath(args.fc_mode)
+        hv.two_streams = not getattr(hp, "two_streams", False)
+        hv.step(resample)
+        n = max(3, args.steps // 2)
+        ev = timed_steps(lambda: hv.step(resample), n, 2, barrier, world, device)
+        variants["warps_on_side_stream" if hv.two_streams else "one_stream"] = {
+            "value": round(args.batch * world * n / ev, 2), "unit": "images/s", "ms_per_step": round(ev / n * 1e3, 3),
+            "note": "the Resample2d sites (a branch of the training graph that shares only the flow fields with the attention "
+                    "layers) issued on %s" % ("a second HIP stream" if hv.two_streams else "the same stream as the attention layers")}
+        del hv
         for mode, label in ((0, "fc_mode0_f32_direct"), (4, "fc_mode4_f32_winograd"), (3, "fc_mode3_f16x3_split"),
                             (2, "fc_mode2_f16x2_split")):
             if mode == args.fc_mode:
@@ -976,6 +1016,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
             # object describes the kernel over both launches, so its average duration is the one a kernel trace shows
             tus = sum(r["avg_us"] for r in step_rows)
             alg, eff = sum(r["alg_GFLOP"] for r in step_rows), sum(r["effective_GFLOP"] for r in step_rows)
+            if all("useful_GFLOP" in r for r in step_rows):
+                dom = dict(dom, useful_GFLOP=round(sum(r["useful_GFLOP"] for r in step_rows) / len(step_rows), 2))
             dom = dict(dom, kernel=dom["kernel"].split(":")[0] + ": both launches of the step (forward and data gradient, "
                                    "source + target halves in one launch each)",
                        avg_us=round(tus / len(step_rows), 1), alg_GFLOP=round(alg / len(step_rows), 2),
@@ -986,6 +1028,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
                             "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
                             **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
+                            **({"useful_frac": round(dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                "useful_frac_note": "executed Winograd-domain flops over the UN-extended output domain only (the "
+                                                    "tiles whose outputs the caller keeps) / time / peak"}
+                               if "useful_GFLOP" in dom else {}),
                             "traffic": pmc_traffic_kernel(dom["kernel"], in_step=bool(dom.get("in_step"))),
                             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                               "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
@@ -1087,6 +1133,12 @@ def main():
     device = torch.device("cuda", local)
     for kv in filter(None, args.tuning.split(",")):
         gfla.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    # the step forks work onto side streams (bench.HotPath.step, face_step.DualStreamAttn): gradients of shared leaves then
+    # arrive from two streams, which autograd handles and announces with a warning per backward
+    try:
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    except AttributeError:
+        pass
     if args.fc_impl == "library":  # round 1's path (rocBLAS / MIOpen FC layers), kept as a cross-check only
         torch.backends.cudnn.benchmark = True
 

@@ -220,6 +220,10 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   return GFLA_OK;
 }
 
+// (Round 4, measured and dropped: the weight gradients of both halves on a library-owned side stream, forked from and joined
+// to the caller's stream with events, concurrently with the data-gradient convolutions and their folds -- 4.75 ms per
+// step against 4.66 on one stream, profiles/r4_fc_backward_side_stream.txt.  Both chains are full-chip kernels that own a
+// CU's whole register file; side by side they only contend.)
 static int fc_backward(void *ws_, const float *flow, const float *w1, const float *g_logits, void *scratch_,
                        float *g_source, float *g_target, float *g_flow, float *g_w0, float *g_b0, float *g_w1,
                        float *g_b1, int64_t B, int C, int H, int W, int k, float slope, int mode_, int flags,

@@ -155,17 +155,21 @@ def main():
         for kind in ("zero", "smooth", "wild"):
             flow = flow_of(kind, B, H, W)
             case = "%s B%d C%d %dx%d k%d flow=%s" % (tag, B, C, H, W, k, kind)
+            # the entry points the PRODUCT runs: coefficient-table forward / matrix-core scatter backward, both with
+            # caller-owned scratch (the plain entry points select round 1's kernels)
+            fws = torch.empty(max(int(L.gfla_aggregate_fwd_workspace_bytes(B, H, W, k)), 16), dtype=torch.uint8, device=DEV)
+            bws = torch.empty(max(int(L.gfla_scatter_workspace_bytes(B, H, W, (k + 1) ** 2)), 16), dtype=torch.uint8, device=DEV)
             if want("agg_fwd"):
                 pa = ("ptr",) * 5 + (B, C, H, W, H, W, k, 1)
-                fn = lambda: _lib.call("gfla_local_attn_aggregate_fwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(lg), _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
-                emit("agg_fwd " + case, "gfla_local_attn_aggregate_fwd_f32", pa, time_fn(fn, args.iters))
+                fn = lambda: _lib.call("gfla_local_attn_aggregate_fwd_ws_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(lg), _lib.ptr(out), _lib.ptr(attn), _lib.ptr(fws), B, C, H, W, H, W, k, 1)
+                emit("agg_fwd " + case, "gfla_local_attn_aggregate_fwd_f32", pa, time_fn(fn, args.iters), note="_ws entry (what the product calls)")
             if want("agg_bwd") and kind == "smooth":
                 _lib.call("gfla_local_attn_aggregate_fwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(lg), _lib.ptr(out), _lib.ptr(attn), B, C, H, W, H, W, k, 1)
                 go = torch.randn_like(src)
                 gs, gf, gl = torch.zeros_like(src), torch.zeros_like(flow), torch.zeros_like(lg)
                 pb = ("ptr",) * 7 + (B, C, H, W, H, W, k, 1)
-                fn = lambda: _lib.call("gfla_local_attn_aggregate_bwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl), B, C, H, W, H, W, k, 1)
-                emit("agg_bwd " + case, "gfla_local_attn_aggregate_bwd_f32", pb, time_fn(fn, max(3, args.iters // 2)))
+                fn = lambda: _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(gs), _lib.ptr(gf), _lib.ptr(gl), _lib.ptr(bws), B, C, H, W, H, W, k, 1)
+                emit("agg_bwd " + case, "gfla_local_attn_aggregate_bwd_f32", pb, time_fn(fn, max(3, args.iters // 2)), note="_ws entry (what the product calls)")
         if want("reshape"):
             o2 = torch.empty(B, 1, k * H, k * W, device=DEV)
             fn = lambda: _lib.call("gfla_local_attn_reshape_fwd_f32", lg, _lib.ptr(lg), _lib.ptr(o2), B, H, W, k)
