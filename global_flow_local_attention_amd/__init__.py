@@ -14,6 +14,7 @@ from .losses import AffineRegularizationLoss, MultiAffineRegularizationLoss  # n
 from .correctness import CorrectnessMapFunction, MaxCosineFunction, PerceptualCorrectness, max_cosine_similarity  # noqa: F401
 from .install import install  # noqa: F401
 from .trainer import TrainerShell, load_reference_checkpoint  # noqa: F401
-from .face_step import DualStreamAttn, face_target_forward, generate_frames, patch_reference_face_target_net  # noqa: F401
+from .face_step import (DualStreamAttn, MaskBlendFunction, face_target_forward, generate_frames,  # noqa: F401
+                        patch_reference_face_target_net)
 
 __version__ = "0.1.0"

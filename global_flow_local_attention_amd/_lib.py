@@ -60,6 +60,10 @@ _SINGLE = {
     "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_resample2d_bwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _int, _ptr],
+    "gfla_mask_blend_fwd_f32": [_ptr] * 6 + [_i64] * 3 + [_ptr],
+    "gfla_mask_blend_fwd_bf16": [_ptr] * 6 + [_i64] * 3 + [_ptr],
+    "gfla_mask_blend_bwd_f32": [_ptr] * 11 + [_i64] * 3 + [_ptr],
+    "gfla_mask_blend_bwd_bf16": [_ptr] * 11 + [_i64] * 3 + [_ptr],
 }
 # bf16 storage exists for every entry point below; the backward ones return the reductions over channels (grad_flow,
 # grad_logits, grad_in2) in float32 (include/gfla_hip.h)

@@ -18,7 +18,8 @@ struct FcLayout {
   // forward workspace, kept for backward
   int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, wu_ft, wu_fs, wu_dt, wu_ds, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
-  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, bwd_total;
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, x32, bwd_total;
+  bool wgrad_f32_wino;   // mode 1, k = 5: the weight gradient runs in the float32 Winograd domain on unpacked activations
 };
 
 static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
@@ -77,12 +78,18 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
   // exact-f32 weight gradient: per-split partial sums (the two halves run one after the other and share it)
   const int64_t sp_s = fc_wgrad_splits(B, L.hs.M, L.cpad), sp_t = fc_wgrad_splits(B, L.ht.M, L.cpad);
   int64_t dwp = mode == 0 ? (sp_s > sp_t ? sp_s : sp_t) * L.KK * L.cpad * kFcHidden * 4 : 0;
-  if (wino) {  // Winograd-domain partials: 36 points per (c, n)
+  // bf16 features (mode 1) at k = 5: the one-f16-term weight-gradient kernel is this path's slowest (226 us per half at
+  // B = 8, 64x64, against ~125 for the float32 Winograd-domain kernel, profiles/r2_face_bf16_kernel_stats.txt); its operands
+  // are exact in float32, so the f32 kernel takes over (tuning key 19 = 1: keep the f16 kernel)
+  L.wgrad_f32_wino = mode_ == 1 && k == 5 && tuning(19) != 1;
+  if (wino || L.wgrad_f32_wino) {  // Winograd-domain partials: 36 points per (c, n)
     const int64_t ws_s = fc_wino_wgrad_splits(B, L.hs.Ho, L.hs.Wo, L.cpad, k), ws_t = fc_wino_wgrad_splits(B, L.ht.Ho, L.ht.Wo, L.cpad, k);
     const int64_t w = (ws_s > ws_t ? ws_s : ws_t) * 36 * L.cpad * kFcHidden * 4;
     if (w > dwp) dwp = w;
   }
   L.dwp = take(dwp);
+  const int64_t x32_s = fc_packed_bytes(B, L.nch_c, L.hs.Sx, 0), x32_t = fc_packed_bytes(B, L.nch_c, L.ht.Sx, 0);
+  L.x32 = take(L.wgrad_f32_wino ? (x32_s > x32_t ? x32_s : x32_t) : 0);
   L.bwd_total = o;
   return L;
 }
@@ -175,7 +182,6 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   unsigned char *zpk = sc + (source ? L.zs_pk : L.zt_pk);
   uint32_t *a_z = mode ? amax + (source ? kAmaxZs : kAmaxZt) : nullptr;
   const uint32_t *a_x = mode ? amax + (source ? kAmaxSrc : kAmaxTgt) : nullptr;
-  (void)a_x;
   const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
   PackedDesc Z;
   if (mode) {
@@ -203,7 +209,15 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
     // mode 4: the Winograd-domain weight gradient for k = 5; for k = 3 the 4 x 4 tiling leaves 1-2 k steps per tile row and
     // the direct kernel measured faster in the step (135 vs 172 us at C256 32x22) -- tuning key 19: 1 = always direct,
     // 2 = always Winograd
-    if (wino && tuning(19) != 1 && (k == 5 || tuning(19) == 2)) {
+    if (L.wgrad_f32_wino) {
+      float *x32 = reinterpret_cast<float *>(sc + L.x32);
+      GFLA_TRY(fc_unpack_act(ws + (source ? L.xs : L.xt), a_x, x32, B, L.nch_c, g.Sx, stream));
+      const PackedDesc X32 = fc_desc_packed(x32, B, L.nch_c, g.Sx, 0);
+      float *part = reinterpret_cast<float *>(sc + L.dwp);
+      GFLA_TRY(fc_wino_wgrad(X32, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+      GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
+                                    stream));
+    } else if (wino && tuning(19) != 1 && (k == 5 || tuning(19) == 2)) {
       float *part = reinterpret_cast<float *>(sc + L.dwp);
       GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
       GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
@@ -276,7 +290,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
                               (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads));
   if (need_t)
     GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream, 0, both_dgrads));
-  if (g_w0 && mode != 0) {
+  if (g_w0 && mode != 0 && !L.wgrad_f32_wino) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),
                              a ? a + kAmaxTgt : nullptr, a ? a + kAmaxSrc : nullptr, a ? a + kAmaxZt : nullptr,

@@ -129,6 +129,7 @@ int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, in
                 int mode, hipStream_t stream);
 int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
               hipStream_t stream);
+int fc_unpack_act(const void *x16, const uint32_t *amax, float *x32, int64_t B, int nch, int64_t S, hipStream_t stream);
 int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
                     int k, int mode, hipStream_t stream);
 int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,

@@ -216,6 +216,31 @@ int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_
   return launch_status();
 }
 
+// ------------------------------------------------------------------- unpack: one-f16-term records -> f32 records
+// The packed activation layout is the same for every arithmetic mode up to the element type (records of 16 channels,
+// pixel-linear, chunk-major): out32[i] = (float)in16[i] / scale.  Exact: a mode-1 operand IS the (scaled) input value
+// whenever that value has <= 11 significant bits -- a bf16 feature has 8.  Lets the float32 Winograd-domain weight
+// gradient (fc_wino.hip) read the activations the mode-1 forward packed (fc_block.hip: bf16 features, k = 5).
+__global__ __launch_bounds__(256) void fc_unpack_act_kernel(const _Float16 *__restrict__ x16, const uint32_t *__restrict__ amax,
+                                                           float *__restrict__ x32, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float inv = fc_inv_scale(amax);
+  const f16x8 v = reinterpret_cast<const f16x8 *>(x16)[i];
+  float4 a, b;
+  a.x = (float)v[0] * inv; a.y = (float)v[1] * inv; a.z = (float)v[2] * inv; a.w = (float)v[3] * inv;
+  b.x = (float)v[4] * inv; b.y = (float)v[5] * inv; b.z = (float)v[6] * inv; b.w = (float)v[7] * inv;
+  reinterpret_cast<float4 *>(x32)[2 * i] = a;
+  reinterpret_cast<float4 *>(x32)[2 * i + 1] = b;
+}
+int fc_unpack_act(const void *x16, const uint32_t *amax, float *x32, int64_t B, int nch, int64_t S, hipStream_t stream) {
+  const int64_t n8 = B * nch * S * kFcChunk / 8;
+  if (n8 <= 0) return GFLA_OK;
+  if (ceil_div(n8, 256) > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  fc_unpack_act_kernel<<<dim3((unsigned)ceil_div(n8, 256)), 256, 0, stream>>>(static_cast<const _Float16 *>(x16), amax, x32, n8);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------ pack: weights
 // conv0.weight (128, 2C, k, k), channel order (target, source) (base_function.py:805: cat((block_target, block_source))).
 // Forward tiles   wf[term][0][chunk][tap][n = 0..127][16 c]      = W[n][off + 16*chunk + c][i][j]

@@ -400,6 +400,11 @@ class FusedAttnFunction(Function):
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
 
 
+# bf16 features: the aggregation's backward in float32 on up-cast operands (matrix-core scatter) instead of the _bf16 entry
+# point (LDS-atomic scatter); False = round 3's evaluation, kept for A/B and for the parity tests of the _bf16 entry points
+BF16_BACKWARD_F32_AGGREGATE = True
+
+
 class FusedAttnBf16Function(Function):
     """ExtractorAttn.forward (softmax=True) for bfloat16 FEATURES (BASELINE config 5: mixed-precision face model).
     Storage is bf16 -- source, target, flow in; result, attention and the feature-map gradients out -- and nothing is
@@ -445,24 +450,47 @@ class FusedAttnBf16Function(Function):
         w0_shape, w1_shape, has_b0, has_b1, flow_dtype, target_dtype, pdt = ctx.meta
         need = ctx.needs_input_grad
         dev = source.device
-        g_out = g_out.contiguous().to(torch.bfloat16)
         new32 = lambda shape, wanted: torch.empty(shape, dtype=torch.float32, device=dev) if wanted else None
-        gs = torch.zeros_like(source) if need[0] else None                       # bf16, accumulated into
-        gf32 = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev) if need[2] else None
-        gl32 = torch.zeros((B, k * k, H, W), dtype=torch.float32, device=dev)
-        _lib.call("gfla_local_attn_aggregate_bwd_bf16", source, _lib.ptr(source), _lib.ptr(flow_b), _lib.ptr(attn),
-                  _lib.ptr(g_out), _lib.ptr(gs), _lib.ptr(gf32), _lib.ptr(gl32), B, C, H, W, H, W, k, 1)
-        g_s32, g_t32 = new32((B, C, H, W), need[0]), new32((B, C, H, W), need[1])
+        zeros32 = lambda shape, wanted: torch.zeros(shape, dtype=torch.float32, device=dev) if wanted else None
+        f32_aggregate = BF16_BACKWARD_F32_AGGREGATE
+        if f32_aggregate:
+            # The aggregation's backward in float32 on up-cast operands (round 4): its d/d source then runs as the
+            # block-sparse product on the matrix cores (csrc/patch_mfma.hip; the bf16 entry point only has the LDS-atomic
+            # scatter, the slowest kernel of the bf16 step), and the FC backward ACCUMULATES its own source / flow
+            # gradients on top in the same float32 buffers -- one rounding to bf16 at the very end instead of two.
+            s32 = source.float()
+            g_s32, gf32 = zeros32((B, C, H, W), need[0]), zeros32((B, 2, H, W), need[2])
+            gl32 = torch.zeros((B, k * k, H, W), dtype=torch.float32, device=dev)
+            attn32, go32 = attn.float(), g_out.contiguous().float()
+            table = _lib.scatter_workspace(s32, B, H, W, (k + 1) ** 2) if need[0] else None
+            _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", s32, _lib.ptr(s32), _lib.ptr(fl32), _lib.ptr(attn32),
+                      _lib.ptr(go32), _lib.ptr(g_s32), _lib.ptr(gf32), _lib.ptr(gl32), _lib.ptr(table), B, C, H, W, H, W, k, 1)
+            gs = None
+        else:
+            g_out = g_out.contiguous().to(torch.bfloat16)
+            gs = torch.zeros_like(source) if need[0] else None                   # bf16, accumulated into
+            gf32 = zeros32((B, 2, H, W), need[2])
+            gl32 = torch.zeros((B, k * k, H, W), dtype=torch.float32, device=dev)
+            _lib.call("gfla_local_attn_aggregate_bwd_bf16", source, _lib.ptr(source), _lib.ptr(flow_b), _lib.ptr(attn),
+                      _lib.ptr(g_out), _lib.ptr(gs), _lib.ptr(gf32), _lib.ptr(gl32), B, C, H, W, H, W, k, 1)
+            g_s32 = new32((B, C, H, W), need[0])
+        g_t32 = new32((B, C, H, W), need[1])
         g_w0 = new32(w0_shape, need[3])
         g_b0 = new32((128,), need[4] and has_b0)
         g_w1 = new32(w1_shape, need[5])
         g_b1 = new32((k * k,), need[6] and has_b1)
         scratch = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=dev)
+        flags = (2 if need[2] else 0) | (1 if (f32_aggregate and need[0]) else 0)   # += grad_flow [| += grad_source]
         _lib.call("gfla_fc_backward_f32", fl32, _lib.ptr(ws), _lib.ptr(fl32), _lib.ptr(w1c), _lib.ptr(gl32),
                   _lib.ptr(scratch), _lib.ptr(g_s32), _lib.ptr(g_t32), _lib.ptr(gf32), _lib.ptr(g_w0), _lib.ptr(g_b0),
-                  _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode, 2 if need[2] else 0)  # += grad_flow
+                  _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode, flags)
         cast = lambda t, dt: None if t is None else t.to(dt)
-        g_source = None if not need[0] else (gs.float() + g_s32).to(torch.bfloat16)
+        if not need[0]:
+            g_source = None
+        elif f32_aggregate:
+            g_source = g_s32.to(torch.bfloat16)
+        else:
+            g_source = (gs.float() + g_s32).to(torch.bfloat16)
         return (g_source, cast(g_t32, target_dtype), cast(gf32, flow_dtype), cast(g_w0, pdt[0]), cast(g_b0, pdt[1]),
                 cast(g_w1, pdt[2]), cast(g_b1, pdt[3]), None, None)
 

@@ -8,15 +8,63 @@ each other (both read `out`, neither reads the other's result until `out_p + out
 6 frames, a handful of clips per GPU) an ExtractorAttn call is ~100 short launches, so the two chains are issued on two
 HIP streams and interleave on the chip:
 
-    cur:  ... out ─┬─ attn_p(prev, out, flow_p) ─ blend_p ─┬─ out_p + out_r ─ decoder ...
-                   └─ (side) attn_r(ref, out, flow_r) ─ blend_r ─┘
+    cur:  ... out ─┬─ attn_p(prev, out, flow_p) ──────────┬─ blend (one kernel) ─ decoder ...
+                   └─ (side) attn_r(ref, out, flow_r) ────┘
 
 `DualStreamAttn` is that fork / join with the event dependencies spelled out (forward; autograd replays each node on
-the stream it ran on and inserts the reverse dependencies itself).  `face_target_forward` is FaceTargetNet.forward with
+the stream it ran on and inserts the reverse dependencies itself).  The blend behind the pair -- nine launch-sized
+elementwise kernels forward, ~14 backward in the op-by-op evaluation -- is one kernel each way (`MaskBlendFunction`,
+csrc/mask_blend.hip), bit-identical in the forward.  `face_target_forward` is FaceTargetNet.forward with
 the pair routed through it; `install(..., dual_stream_face=True)` patches it into the reference's class, leaving
 __init__, attribute names and state_dict keys alone.  Frames stay sequential, as in the reference.
 """
 import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+class MaskBlendFunction(Function):
+    """(out*(1-mask_p) + attn_p*mask_p) + (out*(1-mask_r) + attn_r*mask_r)  -- generator.py:496-499 -- as one kernel each way
+    (csrc/mask_blend.hip) instead of nine elementwise kernels forward and ~14 backward.  Forward: the op-by-op result bit for
+    bit (intermediates rounded to the storage type where torch rounds them); mask gradients are sums over the channels,
+    accumulated in float32."""
+
+    @staticmethod
+    def forward(ctx, out, attn_p, attn_r, mask_p, mask_r):
+        _lib.require_gpu(out, attn_p, attn_r, mask_p, mask_r)
+        out, attn_p, attn_r = out.contiguous(), attn_p.contiguous(), attn_r.contiguous()
+        mask_p, mask_r = mask_p.contiguous(), mask_r.contiguous()
+        B, C, H, W = out.shape
+        sfx = _lib.suffix(out, "mask_blend")
+        y = torch.empty_like(out)
+        _lib.call("gfla_mask_blend_fwd_" + sfx, out, _lib.ptr(out), _lib.ptr(attn_p), _lib.ptr(attn_r), _lib.ptr(mask_p),
+                  _lib.ptr(mask_r), _lib.ptr(y), B, C, H * W)
+        ctx.save_for_backward(out, attn_p, attn_r, mask_p, mask_r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        out, attn_p, attn_r, mask_p, mask_r = ctx.saved_tensors
+        B, C, H, W = out.shape
+        need = ctx.needs_input_grad
+        g = g.contiguous()
+        new = lambda t, wanted: torch.empty_like(t) if wanted else None
+        g_out, g_ap, g_ar = new(out, need[0]), new(attn_p, need[1]), new(attn_r, need[2])
+        zeros32 = lambda t, wanted: torch.zeros(t.shape, dtype=torch.float32, device=t.device) if wanted else None
+        g_mp, g_mr = zeros32(mask_p, need[3]), zeros32(mask_r, need[4])
+        _lib.call("gfla_mask_blend_bwd_" + _lib.suffix(out, "mask_blend"), out, _lib.ptr(out), _lib.ptr(attn_p),
+                  _lib.ptr(attn_r), _lib.ptr(mask_p), _lib.ptr(mask_r), _lib.ptr(g), _lib.ptr(g_out), _lib.ptr(g_ap),
+                  _lib.ptr(g_ar), _lib.ptr(g_mp), _lib.ptr(g_mr), B, C, H * W)
+        cast = lambda t, like: None if t is None else t.to(like.dtype)
+        return g_out, g_ap, g_ar, cast(g_mp, mask_p), cast(g_mr, mask_r)
+
+
+def _blend_fusable(out, attn_p, attn_r, mask_p, mask_r):
+    return (out.is_cuda and out.dtype in (torch.float32, torch.bfloat16) and out.dim() == 4
+            and attn_p.shape == out.shape == attn_r.shape and attn_p.dtype == out.dtype == attn_r.dtype
+            and mask_p.dtype == out.dtype == mask_r.dtype
+            and tuple(mask_p.shape) == (out.size(0), 1, out.size(2), out.size(3)) == tuple(mask_r.shape))
 
 
 class DualStreamAttn(object):
@@ -24,8 +72,8 @@ class DualStreamAttn(object):
     with the reference-frame half on a side stream.  enabled=False (or CPU tensors) evaluates the same expression
     sequentially on the current stream -- the parity tests compare the two."""
 
-    def __init__(self, attn_p, attn_r, enabled=True):
-        self.attn_p, self.attn_r, self.enabled = attn_p, attn_r, enabled
+    def __init__(self, attn_p, attn_r, enabled=True, fused_blend=True):
+        self.attn_p, self.attn_r, self.enabled, self.fused_blend = attn_p, attn_r, enabled, fused_blend
         self._side = None
 
     def side_stream(self, device):
@@ -39,23 +87,26 @@ class DualStreamAttn(object):
 
     def __call__(self, out, prev_feature, ref_feature, flow_p, flow_r, mask_p, mask_r):
         if not (self.enabled and out.is_cuda):
-            out_p = self._blend(out, self.attn_p(prev_feature, out, flow_p), mask_p)
-            out_r = self._blend(out, self.attn_r(ref_feature, out, flow_r), mask_r)
-            return out_p + out_r
+            a_p, a_r = self.attn_p(prev_feature, out, flow_p), self.attn_r(ref_feature, out, flow_r)
+            if self.fused_blend and _blend_fusable(out, a_p, a_r, mask_p, mask_r):
+                return MaskBlendFunction.apply(out, a_p, a_r, mask_p, mask_r)
+            return self._blend(out, a_p, mask_p) + self._blend(out, a_r, mask_r)
         cur = torch.cuda.current_stream(out.device)
         side = self.side_stream(out.device)
         ready = cur.record_event()                 # everything the side chain reads has been enqueued on `cur`
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            out_r = self._blend(out, self.attn_r(ref_feature, out, flow_r), mask_r)
+            a_r = self.attn_r(ref_feature, out, flow_r)
             done = side.record_event()
         # tensors that cross streams: tell the caching allocator who else uses them
-        for t in (out, ref_feature, flow_r, mask_r):
+        for t in (out, ref_feature, flow_r):
             t.record_stream(side)
-        out_p = self._blend(out, self.attn_p(prev_feature, out, flow_p), mask_p)
+        a_p = self.attn_p(prev_feature, out, flow_p)
         cur.wait_event(done)
-        out_r.record_stream(cur)
-        return out_p + out_r
+        a_r.record_stream(cur)
+        if self.fused_blend and _blend_fusable(out, a_p, a_r, mask_p, mask_r):
+            return MaskBlendFunction.apply(out, a_p, a_r, mask_p, mask_r)
+        return self._blend(out, a_p, mask_p) + self._blend(out, a_r, mask_r)
 
 
 def face_target_forward(self, BP, previous_feature_list, reference_feature_list, flow_fields, masks):

@@ -52,7 +52,7 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   1: round 1 (the three ops + aggregate)   2: round 2 (fc_*, *_ws, bf16 backward, max_cosine, correctness_map)
  *   3: round 3 (gfla_path_count, process-global tuning, arithmetic mode 4)
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
- *   5: round 4 (gfla_aggregate_bwd_supported; tuning keys 24-26; path id GFLA_PATH_BE_FWD_PIX) */
+ *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX) */
 #define GFLA_ABI_VERSION 5
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
@@ -456,6 +456,23 @@ int gfla_correctness_map_bwd_f32(const float *warped, const float *target, const
                                  const float *stats, const float *loss_map, const float *grad_map,
                                  float *grad_warped, float *grad_target, float *grad_best, int64_t B,
                                  int64_t C, int64_t N, double eps_cos, double eps, gfla_stream_t stream);
+
+/* ---- mask blend of the face model's attention pair (generator.py:496-499; csrc/mask_blend.hip, round 4) ----
+ *   y = (out*(1-mask_p) + attn_p*mask_p) + (out*(1-mask_r) + attn_r*mask_r)
+ * out, attn_p, attn_r, y: (B,C,HW) contiguous; mask_p, mask_r: (B,1,HW).  Forward: the op-by-op result bit for bit (every
+ * intermediate rounded to the storage type).  Backward: any gradient pointer may be NULL; g_mask_p / g_mask_r are FLOAT32
+ * (B,1,HW), ACCUMULATED into (pass zeroed buffers) whatever the storage type. */
+int gfla_mask_blend_fwd_f32(const float *out, const float *attn_p, const float *attn_r, const float *mask_p,
+                            const float *mask_r, float *y, int64_t B, int64_t C, int64_t HW, gfla_stream_t stream);
+int gfla_mask_blend_fwd_bf16(const uint16_t *out, const uint16_t *attn_p, const uint16_t *attn_r, const uint16_t *mask_p,
+                             const uint16_t *mask_r, uint16_t *y, int64_t B, int64_t C, int64_t HW, gfla_stream_t stream);
+int gfla_mask_blend_bwd_f32(const float *out, const float *attn_p, const float *attn_r, const float *mask_p,
+                            const float *mask_r, const float *grad_y, float *g_out, float *g_attn_p, float *g_attn_r,
+                            float *g_mask_p, float *g_mask_r, int64_t B, int64_t C, int64_t HW, gfla_stream_t stream);
+int gfla_mask_blend_bwd_bf16(const uint16_t *out, const uint16_t *attn_p, const uint16_t *attn_r, const uint16_t *mask_p,
+                             const uint16_t *mask_r, const uint16_t *grad_y, uint16_t *g_out, uint16_t *g_attn_p,
+                             uint16_t *g_attn_r, float *g_mask_p, float *g_mask_r, int64_t B, int64_t C, int64_t HW,
+                             gfla_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -83,3 +83,30 @@ def test_generate_frames_recurrence(gfla):
     images = gfla.generate_frames(frame_fn, 3, None, "ref")
     assert images == ["img0", "img1", "img2"]
     assert seen == [(0, "ref", "ref"), (1, "img0", "ref"), (2, "img1", "ref")]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 20, 9, 7), (3, 16, 16, 12), (1, 130, 5, 33)])
+def test_mask_blend_kernel_equals_op_by_op(gfla, dtype, shape):
+    """csrc/mask_blend.hip against the reference's expression (generator.py:496-499) evaluated op by op in torch: forward
+    bit for bit (f32 and bf16: every intermediate is rounded where torch rounds it), all five gradients incl. the masks'
+    (sums over the channels)."""
+    B, C, H, W = shape
+    mk = lambda s, seed: randn(s, seed=seed).to(dtype).to(DEV).requires_grad_()
+    out, a_p, a_r = mk(shape, 1), mk(shape, 2), mk(shape, 3)
+    m_p = rand((B, 1, H, W), seed=4).to(dtype).to(DEV).requires_grad_()
+    m_r = rand((B, 1, H, W), seed=5).to(dtype).to(DEV).requires_grad_()
+    up = randn(shape, seed=6).to(dtype).to(DEV)
+    leaves = (out, a_p, a_r, m_p, m_r)
+    y = gfla.MaskBlendFunction.apply(*leaves)
+    y.backward(up)
+    got = [t.grad.float().clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    want = (out * (1 - m_p) + a_p * m_p) + (out * (1 - m_r) + a_r * m_r)
+    want.backward(up)
+    assert torch.equal(y, want)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -6
+    for g, t, name in zip(got, leaves, ("out", "attn_p", "attn_r", "mask_p", "mask_r")):
+        w = t.grad.float()
+        assert (g - w).abs().max().item() <= tol * max(1e-30, w.abs().max().item()), name
