@@ -287,24 +287,11 @@ inline PixGeo pix_geometry(int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t
   else if (G > CH && nblk >= 8) G = CH;
   g.G = (int)G;
   g.ngroups = (int)ceil_div(C, G);
-  // waves: one pixel block of 64 per wave and pass
+  // waves: one pixel block of 64 per wave and pass.  Eight waves unless there are fewer items: four workgroups then share
+  // a CU, and one stages its planes while the others stream -- measured at (32,256,32,22) k=3, 11 pixel blocks: 8 waves
+  // 40.6 us, 11 waves (one block each) 46.4, 16 waves 46.3 (profiles/r4_be_fwd_pix_threads.txt)
   const int64_t items = nblk * ceil_div(G, CH);
-  int waves = 8;
-  if (items < 8) waves = (int)items;
-  else if (items <= 16) waves = (int)items;
-  else {
-    // the wave count (4..16) that leaves the fewest idle wave-passes
-    int best = 8;
-    int64_t best_cost = -1;
-    for (int w = 16; w >= 4; --w) {
-      const int64_t cost = ceil_div(items, w) * w;
-      if (best_cost < 0 || cost < best_cost || (cost == best_cost && w == 8)) {
-        best = w;
-        best_cost = cost;
-      }
-    }
-    waves = best;
-  }
+  int waves = items < 8 ? (int)items : 8;
   if (tuning(24) >= 64) waves = tuning(24) / 64;
   if (waves < 1) waves = 1;
   if (waves > 16) waves = 16;

@@ -223,7 +223,10 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
   // TB/s), wider ones to the lane-per-pixel kernel (5.2 TB/s when its output rows are whole 128-byte lines, 3.8-4.7
   // otherwise), planes beyond the LDS budget to round 1's windowed kernel
   if constexpr (sizeof(T) >= 4) {
-    if ((variant == 4 || variant == 0) && k >= 2 && k <= 5) {
+    // small output planes (<= 32 KB: a whole plane is a few hundred lines that one workgroup writes within microseconds)
+    // stream slightly faster from the lane-per-pixel kernel: (32,256,32,22) k=3 40 us against 41-45
+    const bool small_plane = (int64_t)k * k * Hf * Wf * (int64_t)sizeof(T) <= 32 * 1024 && Wf <= 64;
+    if ((variant == 4 || (variant == 0 && !small_plane)) && k >= 2 && k <= 5) {
       bool done = false;
       int st = GFLA_OK;
       switch (k) {

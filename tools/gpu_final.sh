@@ -1,7 +1,8 @@
 #!/usr/bin/env bash
-# Round-end evidence in one GPU call: HBM traffic counters of the bench step (-> profiles/pmc_traffic.json), MFMA-pipe
-# utilisation of the FC kernels, LDS counters of the aggregation forward before / after, kernel trace of the default
-# bench (steady-state per-step table); the default bench itself runs first (its roofline.traffic reads the committed json).
+# Round-end evidence in one GPU call: the default bench; HBM traffic counters of the bench step (-> profiles/pmc_traffic.json,
+# which bench.py's roofline.traffic reads) and of the north star's two forward ops; MFMA-pipe utilisation of the FC kernels;
+# LDS counters of the block_extractor forward and aggregation forward kernels; kernel trace of the default bench
+# (steady-state per-step table).  Counter passes are separate rocprofv3 runs with --kernel-trace only.
 # usage: gpurun --timeout 2400 -- 'bash tools/gpu_final.sh <tag>'
 set -uo pipefail
 TAG="${1:-final}"
@@ -9,18 +10,21 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # the default bench FIRST: after rocprofv3 --pmc passes in the same job the f32-MFMA kernels run ~10 % slower for a while
-( time timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
+( time timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
 BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-legs"
+NS="python $PWD/tools/bench_north_star.py --sweep none --iters 3"
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_$C -o pmc -- $BENCH > $OUT/pmc_$C.log 2>&1); echo "$C rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_ns_$C -o pmc -- $NS > $OUT/pmc_ns_$C.log 2>&1); echo "north star $C rc=$?"
 done
 F=$(find /tmp/fin_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
 grep -E "fc_conv|fc_wgrad|fc_wino|agg_|be_bwd|rs_lds|patch_" $OUT/pmc_traffic.txt | cut -c1-160 | head -40
+F=$(find /tmp/fin_ns_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_ns_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/pmc_summary.py "$F" "$W" $OUT/north_star_pmc_traffic.json > $OUT/north_star_pmc_traffic.txt 2>&1; cat $OUT/north_star_pmc_traffic.txt | cut -c1-170
 bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants --no-legs > $OUT/mfma.log 2>&1; grep -E "fc_conv|fc_wgrad|fc_wino" $OUT/mfma/pmc_set1.txt 2>/dev/null | cut -c1-250 | head -12
-# round 1's kernel (agg_fwd_lds_kernel, tuning key 8 = 1) and the table path (agg_coef + agg_fwd_stream) in one run
-bash tools/gpu_pmc_lds.sh $TAG/agg_lds agg_ -- python $PWD/tools/bench_agg_fwd.py --flows smooth --iters 3 > /dev/null 2>&1
-cat $OUT/agg_lds/pmc_summary.txt | cut -c1-330
+bash tools/gpu_pmc_lds.sh $TAG/ns_lds "_kernel" -- $NS > /dev/null 2>&1
+grep -E "be_fwd|agg_" $OUT/ns_lds/pmc_summary.txt | cut -c1-330
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_trace -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-legs > $OUT/rocprof_bench.log 2>&1); echo "trace rc=$?"
 cp /tmp/fin_trace/bench_kernel_stats.csv $OUT/ 2>/dev/null
-python tools/trace_steps.py /tmp/fin_trace/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -48 $OUT/steady_state_steps.txt
+python tools/trace_steps.py /tmp/fin_trace/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -50 $OUT/steady_state_steps.txt
