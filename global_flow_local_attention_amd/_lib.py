@@ -11,7 +11,8 @@ import subprocess
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgfla_hip.so")
+# GFLA_HIP_LIBRARY: a differently built library (tools/ubench/build_agg_abl.sh timing variants); default = the in-tree build
+LIB_PATH = os.environ.get("GFLA_HIP_LIBRARY") or os.path.join(_PKG, "libgfla_hip.so")
 _lib = None
 
 _i64, _int, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
     const int yf = p / Wf, xf = p - yf * Wf;
     const A fx0 = Num<T>::ld(flow_x + p);
     const A fy0 = Num<T>::ld(flow_y + p);
-    A ax[K];
+    A ax[K], ay[K];
     int x0 = 0, y0 = 0;
     bool dense = true;
 #pragma unroll
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
       }
       dense &= ((int)fdx == x0 + t) & ((int)fdy == y0 + t);   // (no short circuit: a branch per tap otherwise)
       ax[t] = dx - fdx;
+      ay[t] = dy - fdy;
     }
     const int cbase = ch * CH;
     const int ncc = min(CH, gc - cbase);
@@ -174,48 +175,29 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
       // padded column of tap 0 and the row bases (clamped rows; replicated columns are in the plane)
       const int x0c = clampi(x0, -PAD, Ws - 1) + PAD;
       const int y0c = clampi(y0, -(K + 1), Hs);
-      A vA[CH][K + 1];
-      {
-        const int rowx = clampi(y0c, 0, Hs - 1) * Wp + x0c;
+      // the bilinear form separated (be_fwd_wrow.h has the derivation and the operation count): patch rows interpolated
+      // along x once, output row i = the blend of interpolated rows i and i + 1; identical expressions in both kernels
+      auto hrow = [&](int cc, int r, A (&h)[K]) {
+        const A *pc = plc + min(cc, ncc - 1) * plane_p + clampi(y0c + r, 0, Hs - 1) * Wp + x0c;
+        A v[K + 1];
 #pragma unroll
-        for (int cc = 0; cc < CH; ++cc) {
-          const A *pc = plc + min(cc, ncc - 1) * plane_p + rowx;
+        for (int q = 0; q <= K; ++q) v[q] = (ABL & 1) ? (A)(lane + q + r + cc) : pc[q];
 #pragma unroll
-          for (int q = 0; q <= K; ++q) vA[cc][q] = (ABL & 1) ? (A)(lane + q) : pc[q];
-        }
-      }
+        for (int j = 0; j < K; ++j) h[j] = fma_t(ax[j], v[j + 1], (1 - ax[j]) * v[j]);
+      };
+      A hA[CH][K];
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) hrow(cc, 0, hA[cc]);
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;   // as in the setup loop: the same bits
-        const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
-        const int rowx = clampi(y0c + i + 1, 0, Hs - 1) * Wp + x0c;
-        // the four weights of an output (:73-76) as the reference forms them, kept for the CH channels of the chunk
-        A w[K][4];
-        {
-#pragma unroll
-          for (int j = 0; j < K; ++j) {
-            const A xR_P = ax[j], xL_P = 1 - xR_P;
-            w[j][0] = xL_P * yT_P;
-            w[j][1] = xR_P * yT_P;
-            w[j][2] = xL_P * yB_P;
-            w[j][3] = xR_P * yB_P;
-          }
-        }
+        const A yB_P = ay[i], yT_P = 1 - yB_P;
 #pragma unroll
         for (int cc = 0; cc < CH; ++cc) {
-          const A *pc = plc + min(cc, ncc - 1) * plane_p + rowx;
-          A vB[K + 1];
-#pragma unroll
-          for (int q = 0; q <= K; ++q) vB[q] = (ABL & 1) ? (A)(lane + q + i + cc) : pc[q];
+          A hB[K];
+          hrow(cc, i + 1, hB);
           T o[K];
 #pragma unroll
-          for (int j = 0; j < K; ++j) {
-            A s = w[j][0] * vA[cc][j];  // :78-84, same order of accumulation (contracted to fma as nvcc does)
-            s = fma_t(w[j][1], vA[cc][j + 1], s);
-            s = fma_t(w[j][2], vB[j], s);
-            s = fma_t(w[j][3], vB[j + 1], s);
-            o[j] = Num<T>::from(s);
-          }
+          for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[j], yT_P * hA[cc][j]));
           T *oc = oplane0 + cc * oplane + (int64_t)i * Wo;
           if constexpr (ABL & 2) {   // timing ablation: no stores (one impossible store keeps the arithmetic alive)
             A sum = 0;
@@ -226,7 +208,7 @@ __global__ __launch_bounds__(1024) void be_fwd_pix_kernel(
             if (active && cc < ncc) store_row<T, K, NT>(oc + ooff, o);
           }
 #pragma unroll
-          for (int q = 0; q <= K; ++q) vA[cc][q] = vB[q];
+          for (int j = 0; j < K; ++j) hA[cc][j] = hB[j];
         }
       }
     }

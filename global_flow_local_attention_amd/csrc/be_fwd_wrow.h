@@ -100,7 +100,7 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
     const int yf = active ? y0 + yl : y0;
     const A fx0 = Num<T>::ld(flow_x + yf * Wf + xf);
     const A fy0 = Num<T>::ld(flow_y + yf * Wf + xf);
-    A ax[K];
+    A ax[K], ay[K];
     int x0 = 0, yy0 = 0;
     bool dense = true;
 #pragma unroll
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
       }
       dense &= ((int)fdx == x0 + t) & ((int)fdy == yy0 + t);
       ax[t] = dx - fdx;
+      ay[t] = dy - fdy;
     }
     const int x0c = clampi(x0, -PAD, Ws - 1) + PAD;       // padded column of tap 0 (dense pixels)
     const int y0c = clampi(yy0, -(K + 1), Hs);
@@ -126,36 +127,35 @@ __global__ __launch_bounds__(1024) void be_fwd_wrow_kernel(
       const A *pc = planes + cc * plane_p;
       if (active) {
         if (dense) {
-          A vA[K + 1];
-          {
-            const A *pr = pc + clampi(y0c, 0, Hs - 1) * Wp + x0c;
+          // Dense patch: the bilinear form separated -- every patch row interpolated ALONG x once (K values), then output
+          // row i = the blend of interpolated rows i and i + 1:
+          //     h_r[j] = xL_j v[r][j] + xR_j v[r][j+1]          out[i][j] = yT_i h_i[j] + yB_i h_{i+1}[j]
+          // (K+1)*K*2 + K*K*2 = 110 operations per pixel and channel for K = 5 against the 200 of the reference's
+          // four-term sum with its four weight products per output (:73-84) -- at this kernel's shape the vector ALUs
+          // were what kept it from the write stream's rate (profiles/r4_be_fwd_wrow_ablations.jsonl).  Same value up to
+          // rounding (three roundings per output either way); zero weights still reproduce the source bit for bit, and
+          // the tap-by-tap branch below is the reference's expression unchanged.  be_fwd_pix.h uses the same expressions:
+          // the two kernels agree bit for bit.
+          auto hrow = [&](int r, A (&h)[K]) {
+            const A *pr = pc + clampi(y0c + r, 0, Hs - 1) * Wp + x0c;
+            A v[K + 1];
 #pragma unroll
-            for (int s = 0; s <= K; ++s) vA[s] = (ABL & 1) ? (A)(lane + s) : pr[s];
-          }
+            for (int s = 0; s <= K; ++s) v[s] = (ABL & 1) ? (A)(lane + s + r) : pr[s];
+#pragma unroll
+            for (int j = 0; j < K; ++j) h[j] = fma_t(ax[j], v[j + 1], (1 - ax[j]) * v[j]);
+          };
+          A hA[K];
+          hrow(0, hA);
 #pragma unroll
           for (int i = 0; i < K; ++i) {
-            const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;  // as in the setup loop: the same bits
-            A yB_P = dy - floor_t<A>(dy);
-            // The K*K*4 weight products below do not depend on the channel: left alone, the compiler hoists all of them
-            // out of the channel loop (100 registers for K = 5, spilled).  Opaque per (channel, row): re-formed instead.
-            asm volatile("" : "+v"(yB_P));
-            const A yT_P = 1 - yB_P;
-            const A *pr = pc + clampi(y0c + i + 1, 0, Hs - 1) * Wp + x0c;
-            A vB[K + 1];
-#pragma unroll
-            for (int s = 0; s <= K; ++s) vB[s] = (ABL & 1) ? (A)(lane + s + i) : pr[s];
+            A hB[K];
+            hrow(i + 1, hB);
+            const A yB_P = ay[i], yT_P = 1 - yB_P;
             T *to = tl + trow + i * Wo;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {  // :73-84
-              const A xR_P = ax[j], xL_P = 1 - xR_P;
-              A s = (xL_P * yT_P) * vA[j];
-              s = fma_t(xR_P * yT_P, vA[j + 1], s);
-              s = fma_t(xL_P * yB_P, vB[j], s);
-              s = fma_t(xR_P * yB_P, vB[j + 1], s);
-              to[j] = Num<T>::from(s);
-            }
+            for (int j = 0; j < K; ++j) to[j] = Num<T>::from(fma_t(yB_P, hB[j], yT_P * hA[j]));
 #pragma unroll
-            for (int s = 0; s <= K; ++s) vA[s] = vB[s];
+            for (int j = 0; j < K; ++j) hA[j] = hB[j];
           }
         } else {  // a coordinate within rounding of an integer: tap by tap, as the reference does
           int xL[K], xR[K];

@@ -137,19 +137,19 @@ static int fc_forward(const float *source, const float *target, const float *flo
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const uint32_t *a_src = mode ? amax + kAmaxSrc : nullptr, *a_tgt = mode ? amax + kAmaxTgt : nullptr;
   const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
-  if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  if (mode) {
+  if (mode) {   // the f16-split modes scale by max |x|; the float32 modes never read the slots
+    if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
     GFLA_TRY(fc_maxabs(source, B * (int64_t)C * H * W, amax + kAmaxSrc, stream));
     GFLA_TRY(fc_maxabs(target, B * (int64_t)C * H * W, amax + kAmaxTgt, stream));
     GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
   }
+  if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
   GFLA_TRY(fc_pack_act(source, a_src, ws + L.xs, B, C, H, W, L.hs, mode, stream));
   GFLA_TRY(fc_pack_act(target, a_tgt, ws + L.xt, B, C, H, W, L.ht, mode, stream));
   float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
   if (wino) {
-    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
     const WnConvJob jobs[2] = {   // both halves in one launch (fc_wino.hip: they share the half-empty last round)
         {xs, reinterpret_cast<const float *>(ws + L.wu_fs), gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, L.hs.Mv, L.hs.Wo,
          L.hs.Wp, L.hs.Sx},
@@ -250,10 +250,11 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
-  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  if (hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  const float *gs = reinterpret_cast<const float *>(ws + L.gs);
   const float *hid = reinterpret_cast<const float *>(ws + L.hid);
+  float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
+  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if (mode && hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  const float *gs = reinterpret_cast<const float *>(ws + L.gs);
   const bool need_s = g_source || g_w0, need_t = g_target || g_w0;
   float *dzs = need_s ? reinterpret_cast<float *>(sc + L.dzs) : nullptr;
   float *dzt = need_t ? reinterpret_cast<float *>(sc + L.dzt) : nullptr;
@@ -262,18 +263,16 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
                               L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
                               flags & GFLA_FC_ACCUMULATE_FLOW, stream));
-  float *red = reinterpret_cast<float *>(sc + L.red);
-  float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
-  if (g_b0) GFLA_TRY(fc_reduce_rows(b0p, g_b0, B * tiles, kFcHidden, 1.f, red_tmp, stream));
+  const float *dw1p = nullptr;
   if (g_w1 || g_b1) {
     float *part = reinterpret_cast<float *>(sc + L.dw1p);
     GFLA_TRY(fc_dw1(hid, g_logits, part, B, H * W, L.KK, L.dw1_tiles, slope, stream));
-    GFLA_TRY(fc_reduce_rows(part, red, B * L.dw1_tiles, 32 * kFcHidden + 32, 1.f, red_tmp, stream));
-    if (g_w1 && hipMemcpyAsync(g_w1, red, (size_t)L.KK * kFcHidden * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-      return GFLA_ERR_LAUNCH;
-    if (g_b1 && hipMemcpyAsync(g_b1, red + 32 * kFcHidden, (size_t)L.KK * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-      return GFLA_ERR_LAUNCH;
+    dw1p = part;
   }
+  // d b0, d W1, d b1: one two-pass reduction that writes all three in place (8 reduce launches + 4 device copies before).
+  // (Round 4, measured and dropped: this chain and the forward's weight transform forked onto a library-owned second
+  // stream -- 4.449 ms per step against 4.460 on the caller's stream alone, profiles/r4_fc_small_kernels_side_stream.txt.)
+  GFLA_TRY(fc_reduce_bias_w1(b0p, B * tiles, g_b0, dw1p, B * L.dw1_tiles, g_w1, g_b1, L.KK, red_tmp, stream));
   // mode 4: the data-gradient convolutions of both halves in one launch (fc_wino.hip)
   const bool both_dgrads = mode_ == 4 && g_source && g_target;
   if (both_dgrads) {

@@ -185,8 +185,10 @@ int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, 
            float slope, hipStream_t stream);
 int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
             int accumulate, hipStream_t stream);
-constexpr int kFcRedTmpFloats = 32 * (32 * kFcHidden + 32);  // scratch of fc_reduce_rows' first pass (32 splits x widest row)
+constexpr int kFcRedTmpFloats = 32 * (32 * kFcHidden + 32 + kFcHidden);  // first-pass scratch: 32 splits x (d W1 | d b1 row + d b0 row)
 int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, float *tmp,
                    hipStream_t stream);
+int fc_reduce_bias_w1(const float *b0_partials, int64_t rows_b0, float *g_b0, const float *dw1_partials, int64_t rows_w1,
+                      float *g_w1, float *g_b1, int KK, float *tmp, hipStream_t stream);
 
 }  // namespace gfla

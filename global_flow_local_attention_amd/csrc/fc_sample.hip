@@ -427,6 +427,63 @@ int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, fl
   return launch_status();
 }
 
+// Both row reductions of a backward pass -- d b0 (rows of 128) and d W1 | d b1 (rows of 32*128 + 32) -- as ONE two-pass
+// launch pair that writes the three gradients in place: the step spent 8 reduce launches + 4 device copies of ~5 us (+ a
+// ~4 us dependent-launch gap) each on them (profiles/r4_final_steady_state_steps.txt).
+// job j: out segment A = columns [0, nA) -> dstA, segment B = columns [offB, offB + nB) -> dstB (other columns dropped).
+struct RedJob {
+  const float *partials;
+  float *dstA, *dstB;
+  int64_t rows;
+  int cols, nA, offB, nB, gx;   // gx = column blocks of 64
+};
+struct RedJobs {
+  RedJob j[2];
+};
+__global__ __launch_bounds__(256) void fc_reduce_jobs_kernel(RedJobs jobs, float *__restrict__ tmp, int pass) {
+  __shared__ float red[4][64];
+  const bool second = blockIdx.x >= (unsigned)jobs.j[0].gx;
+  const RedJob &J = jobs.j[second ? 1 : 0];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = (int)(blockIdx.x - (second ? jobs.j[0].gx : 0)) * 64 + lane;
+  float *t = tmp + (second ? (int64_t)kRedSplits * jobs.j[0].cols : 0);   // [split][cols] of this job
+  const float *src = pass == 0 ? J.partials : t;
+  const int64_t rows = pass == 0 ? J.rows : kRedSplits;
+  const int64_t r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
+  float s = 0.f;
+  if (c < J.cols)
+    for (int64_t r = r0 + slice; r < r1; r += 4) s += src[r * J.cols + c];
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice != 0 || c >= J.cols) return;
+  const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (pass == 0) {
+    t[(int64_t)blockIdx.y * J.cols + c] = v;
+  } else {
+    if (J.dstA && c < J.nA) J.dstA[c] = v;
+    if (J.dstB && c >= J.offB && c < J.offB + J.nB) J.dstB[c - J.offB] = v;
+  }
+}
+
+// g_b0[128] from b0_partials (rows_b0 x 128), g_w1[KK*128] and g_b1[KK] from dw1 partials (rows_w1 x (32*128 + 32)); a
+// job with no destination is skipped.  tmp: kFcRedTmpFloats floats.
+int fc_reduce_bias_w1(const float *b0_partials, int64_t rows_b0, float *g_b0, const float *dw1_partials, int64_t rows_w1,
+                      float *g_w1, float *g_b1, int KK, float *tmp, hipStream_t stream) {
+  RedJobs jobs;
+  int n = 0;
+  if (g_b0 && b0_partials && rows_b0 > 0)
+    jobs.j[n++] = RedJob{b0_partials, g_b0, nullptr, rows_b0, kFcHidden, kFcHidden, 0, 0, kFcHidden / 64};
+  if ((g_w1 || g_b1) && dw1_partials && rows_w1 > 0)
+    jobs.j[n++] = RedJob{dw1_partials, g_w1, g_b1, rows_w1, kDw1Row, KK * kFcHidden, 32 * kFcHidden, KK, (kDw1Row + 63) / 64};
+  if (n == 0) return GFLA_OK;
+  if (!tmp) return GFLA_ERR_NULL_POINTER;
+  if (n == 1) jobs.j[1] = RedJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  const unsigned gx = (unsigned)(jobs.j[0].gx + jobs.j[1].gx);
+  fc_reduce_jobs_kernel<<<dim3(gx, kRedSplits), 256, 0, stream>>>(jobs, tmp, 0);
+  fc_reduce_jobs_kernel<<<dim3(gx, 1), 256, 0, stream>>>(jobs, tmp, 1);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------ replicate-pad gradient + (pixel, C) -> NCHW
 // grad[b,c,y,x] (+)= sum of dxpad[b, (yy, xx), c] over the padded positions that clamp onto (y, x).
 __global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ dxpad, float *__restrict__ grad, int C,

@@ -567,8 +567,26 @@ __device__ __forceinline__ void agg_chunk_store(float *lds, int n, const f32x2 (
 // The lane's record is fetched ONCE and stays in registers while the channels of the range stream through LDS in
 // chunks of CH planes, double buffered.
 // <= 12 waves per workgroup: 170 VGPRs per lane (record 43 + two channels x two rows in flight 28 + next chunk 16 + ...)
+//
+// Two things the ISA of the first version showed (round 4; each cost an exposed round trip per step):
+//   * a result store inside the channel loop: its address / data registers are overwritten by the next channel pair, so
+//     hipcc waits for the store -- and the memory counter is in order: waiting for the YOUNGEST store waits for the next
+//     chunk's prefetch loads as well (s_waitcnt vmcnt(0) at the top of the pair loop: the double buffering was synchronous).
+//     Now the CHT results of a chunk stay in registers (CHT = planes per chunk, compile time) and are stored once per chunk,
+//     behind the wait the staging needs anyway, from a uniform base + a per-lane offset (scalar-base store form);
+//   * the last word of a row window is the low half of a 64-bit read whose high half is dead: hipcc reused that register
+//     for the next address and had to wait for the read to land first (s_waitcnt lgkmcnt(0) in the middle of every burst of
+//     reads).  The pair is kept alive until the row has been consumed.
 constexpr int kAggStreamWaves = 12;
-template <typename T, int K>
+// timing ablations of agg_fwd_stream_kernel (tools/ubench/build_agg_abl.sh builds variant libraries with
+// -DGFLA_AGG_ABL=bits; results are garbage): 1 = no LDS reads in the row loop, 2 = no prefetch / staging of the next chunk,
+// 4 = no workgroup barrier in the chunk loop, 8 = no arithmetic on the rows
+#ifndef GFLA_AGG_ABL
+#define GFLA_AGG_ABL 0
+#endif
+constexpr int kAggAbl = GFLA_AGG_ABL;
+constexpr int kAggMaxChunk = 8;   // planes per chunk the forward kernel is instantiated for (2, 4, 6, 8)
+template <typename T, int K, int CHT>
 __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ logits,
     const float *__restrict__ table, T *__restrict__ out, int C, int Hs, int Ws, int H, int W, int apply_softmax,
@@ -652,69 +670,74 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
       ro[r] = (yc >> 1) * pitch + ((yc & 1) << 1) + (xa << 1);  // word pairs of a row sit 4 words apart
     }
   }
-  T *o = out + ((int64_t)b * C + c_begin) * HW + p;
+  T *ob = out + ((int64_t)b * C + c_begin) * HW;   // uniform: the stores take a scalar base + the lane's pixel offset
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // (record and first chunk: all landed; see the end of the loop body)
   int cur = 0;
   for (int cb = c_begin; cb < c_end; cb += CH) {
     const int gn = min(CH, c_end - cb - CH);  // planes of the next chunk (<= 0: none): in flight during this one
-    if (gn > 0) agg_chunk_load<T>(s0 + (int64_t)(cb + CH - c_begin) * Hs * Ws, gn * per_plane, pre);
+    // UNCONDITIONAL (the last chunk re-requests one word pair of its own first plane): with the loads under a branch hipcc
+    // cannot count them, and every later wait for an older store becomes vmcnt(0) -- a wait for these loads
+    if constexpr (!(kAggAbl & 2))
+      agg_chunk_load<T>(s0 + (int64_t)(gn > 0 ? cb + CH - c_begin : 0) * Hs * Ws, gn > 0 ? gn * per_plane : 1, pre);
     gc = min(CH, c_end - cb);
     const float *pl = lds + cur * buf_sz;
+    float res[CHT];
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) res[c] = 0.f;
     if (m < kAggSkip) {
       // One patch row of one channel: NP + 1 ds_read_b64 (word K+1 as the first half of a 64-bit read: a ds_read_b32 is
       // banked mod 32 and conflicts on this layout).  The empty asm statements keep the reads apart: merged into
       // ds_read2_b64 they would run at half the LDS rate (MI355X_MICROARCH.md, LDS table).
-      auto load_row = [&](const float *rp, f32x2(&v)[NP], float &u) {
+      auto load_row = [&](const float *rp, f32x2(&v)[NP], f32x2 &u) {
+        if constexpr (kAggAbl & 1) {
+#pragma unroll
+          for (int i = 0; i < NP; ++i) v[i] = f32x2{(float)lane, (float)(size_t)rp};
+          u = f32x2{(float)lane, 1.f};
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
           v[i] = *reinterpret_cast<const f32x2 *>(rp + 4 * i);
           asm volatile("" ::: "memory");
         }
-        u = (*reinterpret_cast<const f32x2 *>(rp + 4 * NP)).x;
+        u = *reinterpret_cast<const f32x2 *>(rp + 4 * NP);
         asm volatile("" ::: "memory");
       };
-      int c = 0;
-      for (; c + 2 <= gc; c += 2) {  // two channels at a time: independent accumulation chains
+#pragma unroll
+      for (int c = 0; c < CHT; c += 2) {  // two channels at a time: independent accumulation chains
+        // (a chunk shorter than CHT re-reads its last plane: finite values, results never stored)
+        const float *p0_ = pl + min(c, gc - 1) * plane_sz, *p1_ = pl + min(c + 1, gc - 1) * plane_sz;
         f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
         float s0_ = 0.f, s1_ = 0.f;
         f32x2 v0[2][NP], v1[2][NP];
-        float u0[2], u1[2];
-        load_row(pl + ro[0], v0[0], u0[0]);
-        load_row(pl + plane_sz + ro[0], v1[0], u1[0]);
+        f32x2 u0[2], u1[2];
+        load_row(p0_ + ro[0], v0[0], u0[0]);
+        load_row(p1_ + ro[0], v1[0], u1[0]);
 #pragma unroll
         for (int r = 0; r <= K; ++r) {
           if (r < K) {  // next row in flight while this one is consumed
-            load_row(pl + ro[r + 1], v0[(r + 1) & 1], u0[(r + 1) & 1]);
-            load_row(pl + plane_sz + ro[r + 1], v1[(r + 1) & 1], u1[(r + 1) & 1]);
+            load_row(p0_ + ro[r + 1], v0[(r + 1) & 1], u0[(r + 1) & 1]);
+            load_row(p1_ + ro[r + 1], v1[(r + 1) & 1], u1[(r + 1) & 1]);
           }
           __builtin_amdgcn_sched_barrier(0);  // the next row's reads are issued before this row's arithmetic
+          if constexpr (kAggAbl & 8) {
 #pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            acc0 = __builtin_elementwise_fma(w2[r][i], v0[r & 1][i], acc0);
-            acc1 = __builtin_elementwise_fma(w2[r][i], v1[r & 1][i], acc1);
+            for (int i = 0; i < NP; ++i) asm volatile("" ::"v"(v0[r & 1][i]), "v"(v1[r & 1][i]));
+          } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+              acc0 = __builtin_elementwise_fma(w2[r][i], v0[r & 1][i], acc0);
+              acc1 = __builtin_elementwise_fma(w2[r][i], v1[r & 1][i], acc1);
+            }
+            s0_ = fmaf(w1[r], u0[r & 1].x, s0_);
+            s1_ = fmaf(w1[r], u1[r & 1].x, s1_);
           }
-          s0_ = fmaf(w1[r], u0[r & 1], s0_);
-          s1_ = fmaf(w1[r], u1[r & 1], s1_);
+          // both halves of the last read stay allocated until here (see the note above the kernel)
+          asm volatile("" ::"v"(u0[r & 1]), "v"(u1[r & 1]));
           __builtin_amdgcn_sched_barrier(0);
         }
-        o[0] = Num<T>::from((acc0.x + acc0.y + s0_) * inv_kk);
-        o[HW] = Num<T>::from((acc1.x + acc1.y + s1_) * inv_kk);
-        o += 2 * (int64_t)HW;
-        pl += 2 * plane_sz;
-      }
-      if (c < gc) {
-        f32x2 acc0 = {0.f, 0.f};
-        float s0_ = 0.f;
-#pragma unroll
-        for (int r = 0; r <= K; ++r) {
-          f32x2 v[NP];
-          float u;
-          load_row(pl + ro[r], v, u);
-#pragma unroll
-          for (int i = 0; i < NP; ++i) acc0 = __builtin_elementwise_fma(w2[r][i], v[i], acc0);
-          s0_ = fmaf(w1[r], u, s0_);
-        }
-        o[0] = Num<T>::from((acc0.x + acc0.y + s0_) * inv_kk);
-        o += HW;
+        res[c] = (acc0.x + acc0.y + s0_) * inv_kk;
+        if (c + 1 < CHT) res[c + 1] = (acc1.x + acc1.y + s1_) * inv_kk;
       }
     } else if (m == kAggNotDense) {
       // tap by tap exactly as block_extractor does; rolled loops that re-derive a_ij from the logits
@@ -732,7 +755,10 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
         for (int tt = 0; tt < KK; ++tt) ssum += exp_t<float>(Num<T>::ld(lg + (int64_t)tt * HW) - sm_max);
         sm_inv = 1.f / ssum;
       }
-      for (int c = 0; c < gc; ++c) {
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) {
+        if (c >= gc) break;
+        const float *plc = pl + c * plane_sz;
         float acc = 0;
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
@@ -750,21 +776,35 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_fwd_stream_kernel(
             const float xR_P = dx - fdx, xL_P = 1 - xR_P;
             float aij = Num<T>::ld(lg + (int64_t)(i * K + j) * HW);
             if (apply_softmax) aij = exp_t<float>(aij - sm_max) * sm_inv;
-            float v = (xL_P * yT_P) * pl[yT + xL];
-            v += (xR_P * yT_P) * pl[yT + xR];
-            v += (xL_P * yB_P) * pl[yB + xL];
-            v += (xR_P * yB_P) * pl[yB + xR];
+            float v = (xL_P * yT_P) * plc[yT + xL];
+            v += (xR_P * yT_P) * plc[yT + xR];
+            v += (xL_P * yB_P) * plc[yB + xL];
+            v += (xR_P * yB_P) * plc[yB + xR];
             acc += aij * v;
           }
         }
-        *o = Num<T>::from(acc * inv_kk);
-        pl += plane_sz;
-        o += HW;
+        res[c] = acc * inv_kk;
       }
+      // (rare branch, taken by a wave with a flow within rounding of an integer.)  Its loads have all been consumed; saying
+      // so on every path out of it keeps them from turning the dense path's register reuse into waits for the prefetch
+      __builtin_amdgcn_s_waitcnt(0x0F70);
     }
-    cur ^= 1;
-    if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, off);
-    __syncthreads();  // the next chunk has landed, and nobody still reads the buffer the one after it will overwrite
+    if constexpr (!(kAggAbl & 2)) cur ^= 1;
+    if constexpr (!(kAggAbl & 2))
+      if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, off);
+    // every memory load so far has landed (the staging above needed the prefetch; the tap-by-tap branch its own): said
+    // unconditionally, so that nothing but the result stores below is pending when the loop comes round
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("" ::: "memory");
+    // the chunk's results, behind the wait the staging needed anyway; they fly during the next chunk
+    if (m != kAggSkip) {
+      T *oc = ob + (int64_t)(cb - c_begin) * HW;
+#pragma unroll
+      for (int c = 0; c < CHT; ++c)
+        if (c < gc) oc[(int64_t)c * HW + p] = Num<T>::from(res[c]);
+    }
+    if constexpr (!(kAggAbl & 4))
+      __syncthreads();  // the next chunk has landed, and nobody still reads the buffer the one after it will overwrite
   }
 }
 
@@ -799,6 +839,7 @@ inline AggStreamGeo agg_stream_geometry(int64_t B, int64_t C, int64_t Hs, int64_
   // chunk: as many planes as two buffers fit and kAggPre word pairs per thread cover
   int64_t CH = std::min<int64_t>((budget / 2 - 16) / per_plane, kAggPre * threads / (Hs * (Ws / 2)));
   if (CH > C) CH = C;
+  if (CH > kAggMaxChunk) CH = kAggMaxChunk;   // the forward kernel keeps a chunk's results in registers
   if (tuning(4) > 0 && tuning(4) < CH) CH = tuning(4);
   if (CH >= 2) CH &= ~1LL;  // channel pairs
   if (CH < 1) return g;
@@ -966,7 +1007,10 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
 // EPI = 1: the same accumulation for resample2d's d/d input2 (kernel_size 4, dilation 1: a K = 3 patch around
 // floor(p + flow) - 1): `flow` is input2 (dx, dy, sigma), `gflow` its (B, 3, H, W) gradient, the epilogue is
 // rs_bwd2_finish on the row / column sums of the patch sums (resample2d_kernel.cu:273-328); glogits / attn unused.
-template <typename T, int K, int EPI = 0>
+// CHT = planes per chunk (compile time, as in agg_fwd_stream_kernel): the chunk's CHT upstream-gradient values are
+// requested one chunk AHEAD, in front of the plane prefetch -- the first version loaded them inside the channel-pair loop
+// and waited for them at once (s_waitcnt vmcnt(0) per pair: a global round trip per pair, and the prefetch with it).
+template <typename T, int K, int EPI, int CHT>
 __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
     const T *__restrict__ src, const T *__restrict__ flow, const T *__restrict__ gout, float *__restrict__ glogits,
     const T *__restrict__ attn, float *__restrict__ gflow, int C, int Hs, int Ws, int H, int W, int CH, int CS,
@@ -1055,11 +1099,21 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
   agg_chunk_store(lds, gc * per_plane, pre, off);
   __syncthreads();
 
-  const T *go_p = gout + ((int64_t)b * C + c_begin) * HW + p;
+  const T *go_b = gout + ((int64_t)b * C + c_begin) * HW;   // uniform base; the lane's pixel is the offset
+  // raw upstream gradients of the chunk about to be computed (gcur) and of the one after it (gnxt); channels beyond the
+  // range re-read the last one and are masked where they are used (a select behind a load would make it synchronous)
+  float gcur[CHT], gnxt[CHT];
+  const int cs_n = c_end - c_begin;
+#pragma unroll
+  for (int c = 0; c < CHT; ++c) gcur[c] = Num<T>::ld(go_b + (int64_t)min(c, cs_n - 1) * HW + p);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing pending when the loop is entered (see agg_fwd_stream_kernel)
   int cur = 0;
   for (int cb = c_begin; cb < c_end; cb += CH) {
     const int gn = min(CH, c_end - cb - CH);
-    if (gn > 0) agg_chunk_load<T>(s0 + (int64_t)(cb + CH - c_begin) * Hs * Ws, gn * per_plane, pre);
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) gnxt[c] = Num<T>::ld(go_b + (int64_t)min(cb + CH - c_begin + c, cs_n - 1) * HW + p);
+    // unconditional, as in agg_fwd_stream_kernel (the last chunk re-requests one word pair)
+    agg_chunk_load<T>(s0 + (int64_t)(gn > 0 ? cb + CH - c_begin : 0) * Hs * Ws, gn > 0 ? gn * per_plane : 1, pre);
     gc = min(CH, c_end - cb);
     const float *pl = lds + cur * buf_sz;
     if (dense) {
@@ -1070,18 +1124,20 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
           asm volatile("" ::: "memory");
         }
       };
-      int c = 0;
-      for (; c + 2 <= gc; c += 2) {
-        const float g0 = Num<T>::ld(go_p) * inv_kk, g1 = Num<T>::ld(go_p + HW) * inv_kk;
+#pragma unroll
+      for (int c = 0; c < CHT; c += 2) {
+        // a chunk shorter than CHT: weight 0 on a re-read of its last plane
+        const float g0 = c < gc ? gcur[c] * inv_kk : 0.f, g1 = c + 1 < gc ? gcur[c + 1 < CHT ? c + 1 : c] * inv_kk : 0.f;
+        const float *p0_ = pl + min(c, gc - 1) * plane_sz, *p1_ = pl + min(c + 1, gc - 1) * plane_sz;
         const f32x2 gg0 = {g0, g0}, gg1 = {g1, g1};
         f32x2 v0[2][NP + 1], v1[2][NP + 1];
-        load_row(pl + ro[0], v0[0]);
-        load_row(pl + plane_sz + ro[0], v1[0]);
+        load_row(p0_ + ro[0], v0[0]);
+        load_row(p1_ + ro[0], v1[0]);
 #pragma unroll
         for (int r = 0; r <= K; ++r) {
           if (r < K) {
-            load_row(pl + ro[r + 1], v0[(r + 1) & 1]);
-            load_row(pl + plane_sz + ro[r + 1], v1[(r + 1) & 1]);
+            load_row(p0_ + ro[r + 1], v0[(r + 1) & 1]);
+            load_row(p1_ + ro[r + 1], v1[(r + 1) & 1]);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1091,25 +1147,11 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        go_p += 2 * (int64_t)HW;
-        pl += 2 * plane_sz;
-      }
-      if (c < gc) {
-        const float g0 = Num<T>::ld(go_p) * inv_kk;
-        const f32x2 gg0 = {g0, g0};
-#pragma unroll
-        for (int r = 0; r <= K; ++r) {
-          f32x2 v[NP + 1];
-          load_row(pl + ro[r], v);
-#pragma unroll
-          for (int i = 0; i <= NP; ++i) Pw[r][i] = __builtin_elementwise_fma(gg0, v[i], Pw[r][i]);
-        }
-        go_p += HW;
       }
     } else if (active) {
       // rare (a tap within rounding of an integer): tap by tap, published directly
       for (int c = 0; c < gc; ++c) {
-        const float go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
+        const float go = Num<T>::ld(go_b + (int64_t)(cb - c_begin + c) * HW + p) * inv_kk;
         const float *plc = pl + (size_t)c * plane_sz;
 #pragma unroll 1
         for (int i = 0; i < K; ++i) {
@@ -1139,10 +1181,13 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
           }
         }
       }
-      go_p += (int64_t)gc * HW;
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // (as in agg_fwd_stream_kernel: nothing of this branch stays pending)
     }
     cur ^= 1;
     if (gn > 0) agg_chunk_store(lds + cur * buf_sz, gn * per_plane, pre, off);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // the prefetch and the next chunk's gradients have landed
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) gcur[c] = gnxt[c];
     __syncthreads();
   }
 
@@ -1218,9 +1263,15 @@ int rs_bwd2_stream(const T *in1, const T *in2, const T *gout, float *gin2, int64
   const int64_t total = B * pg.nsuper * pg.tgroups;
   const int64_t padded = ceil_div(total, kNumXCD) * kNumXCD;
   if (pg.CH <= 0 || padded > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  launch_lds(agg_ga_stream_kernel<T, 3, 1>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, in1, in2, gout,
-             (float *)nullptr, (const T *)nullptr, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, pg.CH, pg.CS, pg.nsuper,
-             pg.tgroups, pg.pitch, (int)total, pg.tw_log2, pg.ntile);
+#define GFLA_RS2_LAUNCH(CV)                                                                                              \
+  launch_lds(agg_ga_stream_kernel<T, 3, 1, CV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, in1, in2, gout, \
+             (float *)nullptr, (const T *)nullptr, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, pg.CH, pg.CS, pg.nsuper, \
+             pg.tgroups, pg.pitch, (int)total, pg.tw_log2, pg.ntile)
+  if (pg.CH <= 2) GFLA_RS2_LAUNCH(2);
+  else if (pg.CH <= 4) GFLA_RS2_LAUNCH(4);
+  else if (pg.CH <= 6) GFLA_RS2_LAUNCH(6);
+  else GFLA_RS2_LAUNCH(8);
+#undef GFLA_RS2_LAUNCH
   return launch_status();
 }
 template int rs_bwd2_stream<float>(const float *, const float *, const float *, float *, int64_t, int64_t, int64_t, int64_t,
@@ -1309,15 +1360,24 @@ static int aggregate_fwd(const T *src, const T *flow, const T *logits, T *out, T
 #define GFLA_AGG_TAB(KV)                                                                                                  \
   agg_coef_kernel<T, KV><<<cgrid, dim3(kAggCoefThreads), 0, stream>>>(flow, logits, attn_out, table, (int)Hs, (int)Ws,        \
                                                                       (int)H, (int)W, sm, pg.tw_log2, pg.ntile);           \
-  launch_lds(agg_fwd_stream_kernel<T, KV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, logits,    \
+  GFLA_AGG_MAIN(KV)
+#define GFLA_AGG_LAUNCH(KV, CV)                                                                                           \
+  launch_lds(agg_fwd_stream_kernel<T, KV, CV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, logits, \
              (const float *)table, out, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, sm, pg.CH, pg.CS, pg.nsuper, pg.tgroups, \
              pg.pitch, (int)total, pg.tw_log2, pg.ntile)
+#define GFLA_AGG_MAIN(KV)                                          \
+  if (pg.CH <= 2) GFLA_AGG_LAUNCH(KV, 2);                          \
+  else if (pg.CH <= 4) GFLA_AGG_LAUNCH(KV, 4);                     \
+  else if (pg.CH <= 6) GFLA_AGG_LAUNCH(KV, 6);                     \
+  else GFLA_AGG_LAUNCH(KV, 8)
         switch (k) {
           case 1: GFLA_AGG_TAB(1); break;
           case 3: GFLA_AGG_TAB(3); break;
           default: GFLA_AGG_TAB(5); break;
         }
 #undef GFLA_AGG_TAB
+#undef GFLA_AGG_MAIN
+#undef GFLA_AGG_LAUNCH
         return launch_status();
       }
     }
@@ -1351,16 +1411,22 @@ static int launch_agg_ga(const T *src, const T *flow, const T *attn, const T *go
       const int64_t total = B * pg.nsuper * pg.tgroups;
       const int64_t padded = ceil_div(total, kNumXCD) * kNumXCD;
       if (pg.CH > 0 && padded <= 0x7fffffffLL) {
-#define GFLA_AGG_GA(KV)                                                                                                  \
-  launch_lds(agg_ga_stream_kernel<T, KV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, gout,     \
+#define GFLA_AGG_GA_LAUNCH(KV, CV)                                                                                       \
+  launch_lds(agg_ga_stream_kernel<T, KV, 0, CV>, dim3((unsigned)padded), dim3(pg.threads), pg.lds, stream, src, flow, gout, \
              (float *)glogits, gflow ? attn : (const T *)nullptr, (float *)gflow, (int)C, (int)Hs, (int)Ws, (int)H, (int)W, \
              pg.CH, pg.CS, pg.nsuper, pg.tgroups, pg.pitch, (int)total, pg.tw_log2, pg.ntile)
+#define GFLA_AGG_GA(KV)                                 \
+  if (pg.CH <= 2) GFLA_AGG_GA_LAUNCH(KV, 2);            \
+  else if (pg.CH <= 4) GFLA_AGG_GA_LAUNCH(KV, 4);       \
+  else if (pg.CH <= 6) GFLA_AGG_GA_LAUNCH(KV, 6);       \
+  else GFLA_AGG_GA_LAUNCH(KV, 8)
         switch (k) {
           case 1: GFLA_AGG_GA(1); break;
           case 3: GFLA_AGG_GA(3); break;
           default: GFLA_AGG_GA(5); break;
         }
 #undef GFLA_AGG_GA
+#undef GFLA_AGG_GA_LAUNCH
         int st = launch_status();
         if (st == GFLA_OK && sm && glogits) {
           const int64_t n = B * H * W;

@@ -380,9 +380,7 @@ class FusedAttnFunction(Function):
 
         # the aggregation's own gradients first (d/d logits feeds the FC backward; source / flow are accumulated into by
         # its kernels, so they start at zero), then the FC layers' backward ADDS its source / flow gradients on top
-        zeros = lambda shape, wanted: torch.zeros(shape, dtype=torch.float32, device=dev) if wanted else None
-        g_source, g_flow = zeros((B, C, H, W), need[0]), zeros((B, 2, H, W), need[2])
-        g_logits = torch.zeros_like(attn)
+        g_source, g_flow, g_logits = _zeros_f32(dev, ((B, C, H, W), need[0]), ((B, 2, H, W), need[2]), (attn.shape, True))
         table = _lib.scatter_workspace(source, B, H, W, (k + 1) ** 2) if need[0] else None
         _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", source, _lib.ptr(source), _lib.ptr(flow), _lib.ptr(attn),
                   _lib.ptr(g_out), _lib.ptr(g_source), _lib.ptr(g_flow), _lib.ptr(g_logits), _lib.ptr(table),
@@ -398,6 +396,18 @@ class FusedAttnFunction(Function):
                   _lib.ptr(g_b0), _lib.ptr(g_w1), _lib.ptr(g_b1), B, C, H, W, k, slope, mode,
                   3)  # GFLA_FC_ACCUMULATE_SOURCE | GFLA_FC_ACCUMULATE_FLOW
         return g_source, g_target, g_flow, g_w0, g_b0, g_w1, g_b1, None, None, None
+
+
+def _zeros_f32(dev, *wanted_shapes):
+    """Zero-initialised float32 tensors of the given (shape, wanted) pairs carved out of ONE allocation: one fill launch per
+    backward instead of one per accumulator (a dependent ~5 us launch each; segments start on 256-byte boundaries)."""
+    sizes = [(-(-int(torch.Size(shape).numel()) // 64) * 64 if wanted else 0) for shape, wanted in wanted_shapes]
+    arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, at = [], 0
+    for (shape, wanted), n in zip(wanted_shapes, sizes):
+        out.append(arena[at:at + torch.Size(shape).numel()].view(shape) if wanted else None)
+        at += n
+    return out
 
 
 # bf16 features: the aggregation's backward in float32 on up-cast operands (matrix-core scatter) instead of the _bf16 entry
@@ -459,8 +469,7 @@ class FusedAttnBf16Function(Function):
             # scatter, the slowest kernel of the bf16 step), and the FC backward ACCUMULATES its own source / flow
             # gradients on top in the same float32 buffers -- one rounding to bf16 at the very end instead of two.
             s32 = source.float()
-            g_s32, gf32 = zeros32((B, C, H, W), need[0]), zeros32((B, 2, H, W), need[2])
-            gl32 = torch.zeros((B, k * k, H, W), dtype=torch.float32, device=dev)
+            g_s32, gf32, gl32 = _zeros_f32(dev, ((B, C, H, W), need[0]), ((B, 2, H, W), need[2]), ((B, k * k, H, W), True))
             attn32, go32 = attn.float(), g_out.contiguous().float()
             table = _lib.scatter_workspace(s32, B, H, W, (k + 1) ** 2) if need[0] else None
             _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", s32, _lib.ptr(s32), _lib.ptr(fl32), _lib.ptr(attn32),

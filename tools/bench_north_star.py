@@ -2,7 +2,7 @@
 """Sweep of the two forward ops the north star prices against the HBM roofline (bench.py: op_roofline) over the
 library's tuning keys -- one JSON line per configuration.
 
-    python tools/bench_north_star.py [--iters 20] [--sweep be|agg|none] [--face] [--flow smooth|zero]
+    python tools/bench_north_star.py [--iters 20] [--sweep be|agg|abl|none] [--face] [--flow smooth|zero]
 
 --sweep be : block_extractor forward variants (key 0 kernel, key 4 planes per workgroup, key 24 threads, key 25
              non-temporal stores, key 5 split), each checked against round 1's kernel (max abs difference)
@@ -80,6 +80,17 @@ def main():
         for kb in (52, 64, 100, 150):
             run("wrow LDS budget %d KB" % kb, {0: 4, 10: kb})
             run("wrow LDS budget %d KB threads=1024" % kb, {0: 4, 10: kb, 24: 1024})
+    if args.sweep == "agg":   # softmax + aggregate forward: workgroup size, planes per chunk, channel ranges, tile width
+        for thr in (768, 704, 512, 384, 256):
+            for ch in (0, 2):
+                for ns in (0, 1, 2, 4, 8):
+                    run("agg threads=%d CH=%d ranges=%d" % (thr, ch, ns), {9: thr, 4: ch, 5: ns})
+        for tw in (8, 16, 32):
+            run("agg tile width %d" % tw, {16: tw})
+            run("agg tile width %d threads=384" % tw, {16: tw, 9: 384})
+        run("agg k=3 on the record/stream path (key 8 = 2)", {8: 2})
+        for thr in (384, 512, 704):
+            run("agg k=3 stream path threads=%d" % thr, {8: 2, 9: thr})
     if args.sweep == "abl":   # needs a `make PROBES=1` library
         for abl in (0, 1, 2, 3):
             run("wave-per-flow-row, ablation %d (1 = no patch reads, 2 = no stores)" % abl, {0: 4, 27: abl})
