@@ -929,8 +929,12 @@ __global__ __launch_bounds__(512) void agg_ga_lds_kernel(
     if (!active) continue;
     const T *go_p = gout + ((int64_t)b * C + cb) * HW + p;
     if (tp.dense) {
+      // the next channel's upstream gradient is requested a channel ahead (raw: scaled where it is used), so the loop
+      // never waits for a global round trip per channel
+      A go_next = Num<T>::ld(go_p);
       for (int c = 0; c < gc; ++c) {
-        const A go = Num<T>::ld(go_p + (int64_t)c * HW) * inv_kk;
+        const A go = go_next * inv_kk;
+        if (c + 1 < gc) go_next = Num<T>::ld(go_p + (int64_t)(c + 1) * HW);
         const A *pl = planes + (size_t)c * plane_sz;
 #pragma unroll
         for (int r = 0; r <= K; ++r)
