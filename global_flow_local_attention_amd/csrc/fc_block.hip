@@ -18,7 +18,7 @@ struct FcLayout {
   // forward workspace, kept for backward
   int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, wu_ft, wu_fs, wu_dt, wu_ds, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
-  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, x32, bwd_total;
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, dwp2, x32, bwd_total;
   bool wgrad_f32_wino;   // mode 1, k = 5: the weight gradient runs in the float32 Winograd domain on unpacked activations
 };
 
@@ -88,6 +88,7 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
     if (w > dwp) dwp = w;
   }
   L.dwp = take(dwp);
+  L.dwp2 = take(dwp);   // the target half's partials: both halves are reduced by one launch pair
   const int64_t x32_s = fc_packed_bytes(B, L.nch_c, L.hs.Sx, 0), x32_t = fc_packed_bytes(B, L.nch_c, L.ht.Sx, 0);
   L.x32 = take(L.wgrad_f32_wino ? (x32_s > x32_t ? x32_s : x32_t) : 0);
   L.bwd_total = o;
@@ -144,8 +145,7 @@ static int fc_forward(const float *source, const float *target, const float *flo
     GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
   }
   if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
-  GFLA_TRY(fc_pack_act(source, a_src, ws + L.xs, B, C, H, W, L.hs, mode, stream));
-  GFLA_TRY(fc_pack_act(target, a_tgt, ws + L.xt, B, C, H, W, L.ht, mode, stream));
+  GFLA_TRY(fc_pack_act2(source, a_src, ws + L.xs, L.hs, target, a_tgt, ws + L.xt, L.ht, B, C, H, W, mode, stream));
   float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
@@ -168,11 +168,17 @@ static int fc_forward(const float *source, const float *target, const float *flo
                             L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wo, L.ht.Wo, slope, stream);
 }
 
+// mode 4: the Winograd-domain weight gradient for k = 5 (tuning key 19: 1 = always direct, 2 = always Winograd)
+static bool fc_wgrad_in_wino_domain(int mode_, int k) { return mode_ == 4 && tuning(19) != 1 && (k == 5 || tuning(19) == 2); }
+
 // data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
 // Z-layout gradient map
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
                             float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode_,
-                            hipStream_t stream, int acc_x = 0, bool dgrad_done = false) {
+                            hipStream_t stream, int acc_x = 0, bool dgrad_done = false, bool reduce_now = true,
+                            bool wgrad_done = false) {
+  // dgrad_done: convolution AND fold already enqueued; reduce_now = false: the weight-gradient partials stay in this half's
+  // buffer (source: dwp, target: dwp2) and fc_backward reduces both halves together
   const bool wino = mode_ == 4;
   const int mode = fc_base_mode(mode_);
   const bool want_w = g_w0 != nullptr;
@@ -202,30 +208,31 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
       GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
                        g.Wp, k, mode, a_z, a_w, stream));
     }
-    GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
+    if (!dgrad_done) GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
     // mode 4: the Winograd-domain weight gradient for k = 5; for k = 3 the 4 x 4 tiling leaves 1-2 k steps per tile row and
     // the direct kernel measured faster in the step (135 vs 172 us at C256 32x22) -- tuning key 19: 1 = always direct,
     // 2 = always Winograd
+    float *part = reinterpret_cast<float *>(sc + (source ? L.dwp : L.dwp2));
     if (L.wgrad_f32_wino) {
       float *x32 = reinterpret_cast<float *>(sc + L.x32);
       GFLA_TRY(fc_unpack_act(ws + (source ? L.xs : L.xt), a_x, x32, B, L.nch_c, g.Sx, stream));
       const PackedDesc X32 = fc_desc_packed(x32, B, L.nch_c, g.Sx, 0);
-      float *part = reinterpret_cast<float *>(sc + L.dwp);
       GFLA_TRY(fc_wino_wgrad(X32, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
-      GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
-                                    stream));
-    } else if (wino && tuning(19) != 1 && (k == 5 || tuning(19) == 2)) {
-      float *part = reinterpret_cast<float *>(sc + L.dwp);
-      GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
-      GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
-                                    stream));
+      if (reduce_now)
+        GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
+                                      stream));
+    } else if (fc_wgrad_in_wino_domain(mode_, k)) {
+      if (!wgrad_done)   // (fc_backward launches both halves' kernels as one grid)
+        GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+      if (reduce_now)
+        GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
+                                      stream));
     } else if (mode == 0) {
-      float *part = reinterpret_cast<float *>(sc + L.dwp);
       GFLA_TRY(fc_wgrad_f32(X, Z, g.lead, part, L.cpad, B, g.M, g.Wp, k, stream));
-      GFLA_TRY(fc_wgrad_reduce(part, fc_wgrad_splits(B, g.M, L.cpad), g_w0, C, source ? C : 0, L.cpad, k, stream));
+      if (reduce_now) GFLA_TRY(fc_wgrad_reduce(part, fc_wgrad_splits(B, g.M, L.cpad), g_w0, C, source ? C : 0, L.cpad, k, stream));
     } else {
       GFLA_TRY(fc_wgrad(X, Z, g.lead, reinterpret_cast<float *>(sc + (source ? L.dw_s : L.dw_t)), L.cpad, B, g.M, g.Wp,
                         k, mode, stream));
@@ -283,12 +290,39 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
         {fc_desc_nhwc(dzt, L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
     GFLA_TRY(fc_wino_conv_jobs(jobs, 2, B, nch_h, k, stream));
+    // ... and their replicate-pad folds in one launch (fc_sample.hip)
+    GFLA_TRY(fc_fold2(reinterpret_cast<const float *>(sc + L.dxs), g_source, L.hs, L.hs.Mdg * (int64_t)C,
+                      (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, reinterpret_cast<const float *>(sc + L.dxt), g_target, L.ht,
+                      L.ht.Mdg * (int64_t)C, 0, B, C, H, W, stream));
   }
+  // weight-gradient partials of both halves: summed (and, in the Winograd domain, transformed back) by ONE launch (pair)
+  const bool wino_w = L.wgrad_f32_wino || fc_wgrad_in_wino_domain(mode_, k);
+  const bool defer = g_w0 && need_s && need_t && (wino_w || mode == 0);
+  // mode 4, k = 5: the two Winograd-domain weight-gradient kernels as ONE grid (each is one round of workgroups)
+  const bool both_wgrads = defer && both_dgrads && !L.wgrad_f32_wino && fc_wgrad_in_wino_domain(mode_, k) && tuning(21) != 2;
   if (need_s)
     GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode_, stream,
-                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads));
+                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads, !defer, both_wgrads));
   if (need_t)
-    GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream, 0, both_dgrads));
+    GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream, 0, both_dgrads, !defer,
+                              both_wgrads));
+  if (both_wgrads) {
+    const WwJob jobs[2] = {
+        {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode), dzs, reinterpret_cast<float *>(sc + L.dwp), L.hs.Sz * kFcHidden,
+         L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
+        {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode), dzt, reinterpret_cast<float *>(sc + L.dwp2), L.ht.Sz * kFcHidden,
+         L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
+    GFLA_TRY(fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream));
+  }
+  if (defer) {
+    float *part_s = reinterpret_cast<float *>(sc + L.dwp), *part_t = reinterpret_cast<float *>(sc + L.dwp2);
+    if (wino_w)
+      GFLA_TRY(fc_wino_wgrad_reduce2(part_s, fc_wino_wgrad_splits(B, L.hs.Ho, L.hs.Wo, L.cpad, k), part_t,
+                                     fc_wino_wgrad_splits(B, L.ht.Ho, L.ht.Wo, L.cpad, k), g_w0, C, L.cpad, k, stream));
+    else
+      GFLA_TRY(fc_wgrad_reduce2(part_s, fc_wgrad_splits(B, L.hs.M, L.cpad), part_t, fc_wgrad_splits(B, L.ht.M, L.cpad), g_w0, C,
+                                L.cpad, k, stream));
+  }
   if (g_w0 && mode != 0 && !L.wgrad_f32_wino) {
     const uint32_t *a = mode ? amax : nullptr;
     GFLA_TRY(fc_unpack_wgrad(reinterpret_cast<float *>(sc + L.dw_t), reinterpret_cast<float *>(sc + L.dw_s),

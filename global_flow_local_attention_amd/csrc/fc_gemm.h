@@ -127,6 +127,9 @@ inline FcHalf fc_half(int H, int W, int k, bool source) {
 int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream);
 int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
                 int mode, hipStream_t stream);
+int fc_pack_act2(const float *src_s, const uint32_t *amax_s, void *out_s, const FcHalf &gs, const float *src_t,
+                 const uint32_t *amax_t, void *out_t, const FcHalf &gt, int64_t B, int C, int H, int W, int mode,
+                 hipStream_t stream);
 int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
               hipStream_t stream);
 int fc_unpack_act(const void *x16, const uint32_t *amax, float *x32, int64_t B, int nch, int64_t S, hipStream_t stream);
@@ -143,6 +146,8 @@ int fc_wgrad_f32(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float
                  int Wp, int k, hipStream_t stream);
 int fc_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
                     hipStream_t stream);
+int fc_wgrad_reduce2(const float *part_s, int nsplit_s, const float *part_t, int nsplit_t, float *grad_w0, int C, int cpad,
+                     int k, hipStream_t stream);
 int fc_unpack_wgrad(const float *dw_t, const float *dw_s, const uint32_t *amax_xt, const uint32_t *amax_xs,
                     const uint32_t *amax_zt, const uint32_t *amax_zs, float *grad_w0, int C, int cpad, int k,
                     hipStream_t stream);
@@ -169,9 +174,19 @@ int fc_wino_conv_jobs(const WnConvJob *jobs, int njobs, int64_t B, int nch, int 
 int fc_wino_conv(const PackedDesc &X, const float *U, float *out, int64_t out_bs, int ldo, int n_valid, int64_t B, int nch,
                  int M, int Wv, int Wp, int64_t S, int k, hipStream_t stream);
 int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k);
+struct WwJob {   // one Winograd-domain weight gradient (fc_wino_wgrad's arguments)
+  PackedDesc X;
+  const float *Z;
+  float *part;
+  int64_t z_bs, z_lead, SX;
+  int Ho, Wo, Wp;
+};
+int fc_wino_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, hipStream_t stream);
 int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
                   int Wo, int Wp, int64_t SX, int k, hipStream_t stream);
 int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream);
+int fc_wino_wgrad_reduce2(float *part_s, int nsplit_s, float *part_t, int nsplit_t, float *grad_w0, int C, int cpad, int k,
+                          hipStream_t stream);
 
 // fc_sample.hip
 int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,
@@ -185,6 +200,8 @@ int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, 
            float slope, hipStream_t stream);
 int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
             int accumulate, hipStream_t stream);
+int fc_fold2(const float *dx_s, float *grad_s, const FcHalf &gs, int64_t dxs_bs, int acc_s, const float *dx_t, float *grad_t,
+             const FcHalf &gt, int64_t dxt_bs, int acc_t, int64_t B, int C, int H, int W, hipStream_t stream);
 constexpr int kFcRedTmpFloats = 32 * (32 * kFcHidden + 32 + kFcHidden);  // first-pass scratch: 32 splits x (d W1 | d b1 row + d b0 row)
 int fc_reduce_rows(const float *partials, float *out, int64_t rows, int cols, float scale, float *tmp,
                    hipStream_t stream);

@@ -128,19 +128,31 @@ int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream) {
 // out[term][b][chunk][m = yp*Wp + xp][16] = src[b][16*chunk + ch][clamp(yp - pad_t)][clamp(xp - pad_l)] * scale for
 // m < Hp*Wp, zero for the read slack behind it (m < S) and for channels >= C (C not a multiple of 16).
 // A thread produces one 8-channel piece: its 8 reads are coalesced along x across the lanes, the stores contiguous.
+// One launch carries up to TWO packs (the source and the target half of a layer): blockIdx.z < nb0 is job 0.
+struct PackJob {
+  const float *src;
+  const uint32_t *amax;
+  unsigned char *out;
+  int Hp, Wp, pad_t, pad_l;
+  int64_t S, split_stride;
+};
+struct PackJobs {
+  PackJob j[2];
+};
 template <int MODE>
-__global__ __launch_bounds__(256) void fc_pack_act_kernel(const float *__restrict__ src,
-                                                         const uint32_t *__restrict__ amax,
-                                                         unsigned char *__restrict__ out, int C, int H, int W, int Hp,
-                                                         int Wp, int pad_t, int pad_l, int64_t S, int nch,
-                                                         int64_t split_stride) {
+__global__ __launch_bounds__(256) void fc_pack_act_kernel(PackJobs jobs, int nb0, int C, int H, int W, int nch) {
   using F = Fc<MODE>;
+  const bool second = (int)blockIdx.z >= nb0;
+  const PackJob &J = jobs.j[second ? 1 : 0];
+  const float *__restrict__ src = J.src;
+  const int Hp = J.Hp, Wp = J.Wp, pad_t = J.pad_t, pad_l = J.pad_l;
+  const int64_t S = J.S;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (m, half)
   const int64_t m = idx >> 1;
   const int half = (int)(idx & 1);
   if (m >= S) return;
   const int cc = blockIdx.y;
-  const int64_t b = blockIdx.z;
+  const int64_t b = (int)blockIdx.z - (second ? nb0 : 0);
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -153,27 +165,49 @@ __global__ __launch_bounds__(256) void fc_pack_act_kernel(const float *__restric
       if (c < C) v[e] = src[((b * C + c) * H + y) * (int64_t)W + x];
     }
   }
-  const float s = MODE == 0 ? 1.f : fc_scale(amax);
-  unsigned char *dst = out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
-  store_pieces<MODE>(v, s, dst, split_stride);
+  const float s = MODE == 0 ? 1.f : fc_scale(J.amax);
+  unsigned char *dst = J.out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
+  store_pieces<MODE>(v, s, dst, J.split_stride);
 }
 
-int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
-                int mode, hipStream_t stream) {
+static int fc_pack_act_launch(const PackJobs &jobs, int njobs, int64_t B, int C, int H, int W, int mode, hipStream_t stream) {
+  if (B <= 0 || njobs <= 0) return GFLA_OK;
   const int nch = (int)ceil_div(C, kFcChunk);
-  if (nch > 65535 || B > 65535) return GFLA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)ceil_div(2 * g.Sx, 256), (unsigned)nch, (unsigned)B);
-  const PackedDesc d = fc_desc_packed(out, B, nch, g.Sx, mode);
-  unsigned char *o = static_cast<unsigned char *>(out);
-#define GFLA_LAUNCH(M_)                                                                                             \
-  fc_pack_act_kernel<M_><<<grid, 256, 0, stream>>>(src, amax, o, C, H, W, g.Hp, g.Wp, g.pad_t, g.pad_l, g.Sx, nch, \
-                                                   d.split_stride)
+  if (nch > 65535 || njobs * B > 65535) return GFLA_ERR_UNSUPPORTED;
+  int64_t smax = jobs.j[0].S;
+  if (njobs > 1 && jobs.j[1].S > smax) smax = jobs.j[1].S;
+  const dim3 grid((unsigned)ceil_div(2 * smax, 256), (unsigned)nch, (unsigned)(njobs * B));
+#define GFLA_LAUNCH(M_) fc_pack_act_kernel<M_><<<grid, 256, 0, stream>>>(jobs, (int)B, C, H, W, nch)
   if (mode == 0) GFLA_LAUNCH(0);
   else if (mode == 1) GFLA_LAUNCH(1);
   else if (mode == 2) GFLA_LAUNCH(2);
   else GFLA_LAUNCH(3);
 #undef GFLA_LAUNCH
   return launch_status();
+}
+
+static PackJob pack_job(const float *src, const uint32_t *amax, void *out, int64_t B, int C, const FcHalf &g, int mode) {
+  const int nch = (int)ceil_div(C, kFcChunk);
+  const PackedDesc d = fc_desc_packed(out, B, nch, g.Sx, mode);
+  return PackJob{src, amax, static_cast<unsigned char *>(out), g.Hp, g.Wp, g.pad_t, g.pad_l, g.Sx, d.split_stride};
+}
+
+int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
+                int mode, hipStream_t stream) {
+  PackJobs jobs;
+  jobs.j[0] = pack_job(src, amax, out, B, C, g, mode);
+  jobs.j[1] = jobs.j[0];
+  return fc_pack_act_launch(jobs, 1, B, C, H, W, mode, stream);
+}
+
+// both halves of a layer in one launch
+int fc_pack_act2(const float *src_s, const uint32_t *amax_s, void *out_s, const FcHalf &gs, const float *src_t,
+                 const uint32_t *amax_t, void *out_t, const FcHalf &gt, int64_t B, int C, int H, int W, int mode,
+                 hipStream_t stream) {
+  PackJobs jobs;
+  jobs.j[0] = pack_job(src_s, amax_s, out_s, B, C, gs, mode);
+  jobs.j[1] = pack_job(src_t, amax_t, out_t, B, C, gt, mode);
+  return fc_pack_act_launch(jobs, 2, B, C, H, W, mode, stream);
 }
 
 // ------------------------------------------------------------- pack: f32 (B, S, Cz) pixel-major -> f16 records
@@ -659,10 +693,19 @@ int fc_wgrad_f32(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float
   return launch_status();
 }
 
-// conv0.weight.grad[n][c_off + c][i][j] = sum_s part[s][tap][c][n]  (one half of the 2C input channels)
-__global__ __launch_bounds__(256) void fc_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit,
-                                                             float *__restrict__ gw, int C, int c_off, int cpad,
-                                                             int KK) {
+// conv0.weight.grad[n][c_off + c][i][j] = sum_s part[s][tap][c][n]  (one half of the 2C input channels).
+// blockIdx.y = job: both halves of a layer in one launch (fc_wgrad_reduce2).
+struct WgRedJob {
+  const float *part;
+  int nsplit, c_off;
+};
+struct WgRedJobs {
+  WgRedJob j[2];
+};
+__global__ __launch_bounds__(256) void fc_wgrad_reduce_kernel(WgRedJobs jobs, float *__restrict__ gw, int C, int cpad, int KK) {
+  const WgRedJob &J = jobs.j[blockIdx.y];
+  const float *__restrict__ part = J.part;
+  const int nsplit = J.nsplit, c_off = J.c_off;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (tap, c, n), n fastest: coalesced reads
   const int64_t per = (int64_t)KK * cpad * kFcHidden;
   if (idx >= per) return;
@@ -685,8 +728,20 @@ __global__ __launch_bounds__(256) void fc_wgrad_reduce_kernel(const float *__res
 int fc_wgrad_reduce(const float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k,
                     hipStream_t stream) {
   const int64_t per = (int64_t)k * k * cpad * kFcHidden;
-  fc_wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per, 256)), 256, 0, stream>>>(part, nsplit, grad_w0, C, c_off, cpad,
-                                                                               k * k);
+  WgRedJobs jobs;
+  jobs.j[0] = jobs.j[1] = WgRedJob{part, nsplit, c_off};
+  fc_wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per, 256), 1), 256, 0, stream>>>(jobs, grad_w0, C, cpad, k * k);
+  return launch_status();
+}
+
+// source half (channels C..2C-1) and target half (0..C-1) in one launch
+int fc_wgrad_reduce2(const float *part_s, int nsplit_s, const float *part_t, int nsplit_t, float *grad_w0, int C, int cpad,
+                     int k, hipStream_t stream) {
+  const int64_t per = (int64_t)k * k * cpad * kFcHidden;
+  WgRedJobs jobs;
+  jobs.j[0] = WgRedJob{part_s, nsplit_s, C};
+  jobs.j[1] = WgRedJob{part_t, nsplit_t, 0};
+  fc_wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per, 256), 2), 256, 0, stream>>>(jobs, grad_w0, C, cpad, k * k);
   return launch_status();
 }
 

@@ -486,16 +486,46 @@ int fc_reduce_bias_w1(const float *b0_partials, int64_t rows_b0, float *g_b0, co
 
 // ------------------------------------------------------------------ replicate-pad gradient + (pixel, C) -> NCHW
 // grad[b,c,y,x] (+)= sum of dxpad[b, (yy, xx), c] over the padded positions that clamp onto (y, x).
-__global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ dxpad, float *__restrict__ grad, int C,
-                                                     int H, int W, int Hp, int Wp, int pad_t, int pad_l,
-                                                     int64_t dx_bs, int accumulate) {
+// One launch carries up to TWO folds (the source and the target half of a layer: same B, C, H, W, different padding):
+// blockIdx.z < B is job 0, the rest job 1 -- one dependent launch less per backward pass, and the second half's workgroups
+// fill the first one's tail.  When accumulating, the old values are requested together with the gradient rows (one global
+// round trip per workgroup instead of two).
+struct FoldJob {
+  const float *dxpad;
+  float *grad;
+  int64_t dx_bs;
+  int Hp, Wp, pad_t, pad_l, accumulate;
+};
+struct FoldJobs {
+  FoldJob j[2];
+};
+constexpr int kFoldOld = 16;   // old values a thread keeps in flight (maps up to 64 columns); wider maps load them late
+
+__global__ __launch_bounds__(256) void fc_fold_kernel(FoldJobs jobs, int nb0, int C, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][W + 1]
+  const bool second = (int)blockIdx.z >= nb0;
+  const FoldJob &J = jobs.j[second ? 1 : 0];
+  const float *__restrict__ dxpad = J.dxpad;
+  float *__restrict__ grad = J.grad;
+  const int Hp = J.Hp, Wp = J.Wp, pad_t = J.pad_t, pad_l = J.pad_l, accumulate = J.accumulate;
   const int y = blockIdx.x, c0 = blockIdx.y * 64;
-  const int64_t b = blockIdx.z;
+  const int64_t b = (int)blockIdx.z - (second ? nb0 : 0);
   const int c = threadIdx.x & 63, xq = threadIdx.x >> 6;
   const int y0 = y == 0 ? 0 : y + pad_t, y1 = y == H - 1 ? Hp - 1 : y + pad_t;
-  const float *src = dxpad + b * dx_bs + c0 + c;
+  const float *src = dxpad + b * J.dx_bs + c0 + c;
+  // the values this workgroup will add to (element i of its 64 x W block <-> thread i % 256): requested first
+  const int n = min(64, C - c0) * W;
+  const bool early = accumulate && n <= kFoldOld * 256;
+  float old[kFoldOld];
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < kFoldOld; ++u) {
+      const int i = min((int)threadIdx.x + 256 * u, n - 1);
+      const int cl = i / W, x = i - cl * W;
+      old[u] = grad[((b * C + c0 + cl) * H + y) * (int64_t)W + x];
+    }
+  }
   if (c0 + c < C) {
     constexpr int XU = 8;  // positions per thread and batch: their centre loads are issued together (one round trip)
     for (int xb = xq; xb < W; xb += 4 * XU) {
@@ -522,34 +552,66 @@ __global__ __launch_bounds__(256) void fc_fold_kernel(const float *__restrict__ 
     }
   }
   __syncthreads();
-  // four elements per thread and pass: when accumulating, their four loads are one round trip instead of four
-  const int n = min(64, C - c0) * W;
+  if (early || !accumulate) {
+#pragma unroll
+    for (int u = 0; u < kFoldOld; ++u) {
+      const int i = (int)threadIdx.x + 256 * u;
+      if (i >= n) break;
+      const int cl = i / W, x = i - cl * W;
+      const float v = tile[cl * (W + 1) + x];
+      grad[((b * C + c0 + cl) * H + y) * (int64_t)W + x] = early ? old[u] + v : v;
+    }
+    for (int i = (int)threadIdx.x + 256 * kFoldOld; i < n; i += 256) {   // (not accumulating, wide maps)
+      const int cl = i / W, x = i - cl * W;
+      grad[((b * C + c0 + cl) * H + y) * (int64_t)W + x] = tile[cl * (W + 1) + x];
+    }
+    return;
+  }
+  // accumulating into a wide map: four elements per thread and pass, their four loads one round trip
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
     float *g[4];
-    float v[4], old[4];
+    float v[4], o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = min(i0 + 256 * u, n - 1);
       const int cl = i / W, x = i - cl * W;
       g[u] = grad + ((b * C + c0 + cl) * H + y) * (int64_t)W + x;
       v[u] = tile[cl * (W + 1) + x];
-      old[u] = accumulate ? *g[u] : 0.f;
+      o[u] = *g[u];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (i0 + 256 * u < n) *g[u] = old[u] + v[u];
+      if (i0 + 256 * u < n) *g[u] = o[u] + v[u];
   }
+}
+
+static int fc_fold_launch(const FoldJobs &jobs, int njobs, int64_t B, int C, int H, int W, hipStream_t stream) {
+  if (B <= 0 || njobs <= 0) return GFLA_OK;
+  if (njobs * B > 65535 || ceil_div(C, 64) > 65535 || (int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)H, (unsigned)ceil_div(C, 64), (unsigned)(njobs * B));
+  fc_fold_kernel<<<grid, 256, (unsigned)(64 * (W + 1) * sizeof(float)), stream>>>(jobs, (int)B, C, H, W);
+  return launch_status();
 }
 
 int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,
             int accumulate, hipStream_t stream) {
   if (!dxpad || !grad) return GFLA_ERR_NULL_POINTER;
-  if (B <= 0) return GFLA_OK;
-  if (B > 65535 || ceil_div(C, 64) > 65535 || (int64_t)64 * (W + 1) * 4 > 64 * 1024) return GFLA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)H, (unsigned)ceil_div(C, 64), (unsigned)B);
-  fc_fold_kernel<<<grid, 256, (unsigned)(64 * (W + 1) * sizeof(float)), stream>>>(dxpad, grad, C, H, W, g.Hp, g.Wp, g.pad_t,
-                                                                                g.pad_l, dx_bs, accumulate);
-  return launch_status();
+  FoldJobs jobs;
+  jobs.j[0] = FoldJob{dxpad, grad, dx_bs, g.Hp, g.Wp, g.pad_t, g.pad_l, accumulate};
+  jobs.j[1] = jobs.j[0];
+  return fc_fold_launch(jobs, 1, B, C, H, W, stream);
+}
+
+// both halves of a layer in one launch (either may be absent: dxpad == NULL)
+int fc_fold2(const float *dx_s, float *grad_s, const FcHalf &gs, int64_t dxs_bs, int acc_s, const float *dx_t, float *grad_t,
+             const FcHalf &gt, int64_t dxt_bs, int acc_t, int64_t B, int C, int H, int W, hipStream_t stream) {
+  FoldJobs jobs;
+  int n = 0;
+  if (dx_s && grad_s) jobs.j[n++] = FoldJob{dx_s, grad_s, dxs_bs, gs.Hp, gs.Wp, gs.pad_t, gs.pad_l, acc_s};
+  if (dx_t && grad_t) jobs.j[n++] = FoldJob{dx_t, grad_t, dxt_bs, gt.Hp, gt.Wp, gt.pad_t, gt.pad_l, acc_t};
+  if (n == 0) return GFLA_OK;
+  if (n == 1) jobs.j[1] = jobs.j[0];
+  return fc_fold_launch(jobs, n, B, C, H, W, stream);
 }
 
 }  // namespace gfla

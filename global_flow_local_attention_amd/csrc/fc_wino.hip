@@ -712,19 +712,38 @@ struct WwUnit {
 
 // DBG (timing ablations, tools only; results are garbage): 1 no input transform, 2 no MFMAs / A reads, 4 no dY loads,
 // 8 no lift of dY to the 36 points, 16 no raw staging
+struct WwKArgs {
+  PackedDesc X;
+  const float *Z;
+  float *part;
+  int64_t z_bs, z_lead, total_units, SX;
+  int Wp, Wo, nsplit;
+  WwGeo geo;
+};
 template <int KS, int DBG = 0>
-__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc X, const float *__restrict__ Z,
-                                                                     int64_t z_bs, int64_t z_lead,
-                                                                     float *__restrict__ part, int cpad, int Wp,
-                                                                     int Wo, WwGeo geo, int64_t total_units, int nsplit,
-                                                                     int64_t SX) {
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad) {
+  // One launch carries up to TWO weight gradients (the source and the target half of a layer): split indices
+  // [0, nsplit0) belong to job 0, the rest to job 1 -- each job is one round of workgroups, and in one grid the second
+  // round starts on a CU the moment the first one's workgroup there retires.  Workgroup-uniform selects (scalar registers).
+  const bool second = (int)blockIdx.y >= nsplit0;
+#define GFLA_PICK(f) (second ? a1.f : a0.f)
+  PackedDesc X;
+  X.base = GFLA_PICK(X.base), X.split_stride = 0, X.batch_stride = GFLA_PICK(X.batch_stride);
+  X.chunk_stride = GFLA_PICK(X.chunk_stride), X.pix_stride = GFLA_PICK(X.pix_stride);
+  const float *__restrict__ Z = GFLA_PICK(Z);
+  float *__restrict__ part = GFLA_PICK(part);
+  const int64_t z_bs = GFLA_PICK(z_bs), z_lead = GFLA_PICK(z_lead), total_units = GFLA_PICK(total_units), SX = GFLA_PICK(SX);
+  const int Wp = GFLA_PICK(Wp), Wo = GFLA_PICK(Wo), nsplit = GFLA_PICK(nsplit);
+  WwGeo geo;
+  geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.nseg = GFLA_PICK(geo.nseg);
+#undef GFLA_PICK
   constexpr int M = Ww<KS>::M, SEG = Ww<KS>::SEG, L = Ww<KS>::L, RAW = Ww<KS>::RAW, PITCH = kWwPitch;
   constexpr int PF = (6 * L * 4 + kWnThreads - 1) / kWnThreads;  // 16-byte pieces of a unit's raw rows per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *vbuf = reinterpret_cast<float *>(gfla_smem);            // [2][kWwVFloats]
   unsigned char *raw = gfla_smem + 2 * kWwVFloats * 4;           // [2][6][L][PITCH]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xh = wave >> 2;
-  const int cc = blockIdx.x, sp = blockIdx.y;
+  const int cc = blockIdx.x, sp = (int)blockIdx.y - (second ? nsplit0 : 0);
   const int64_t u0 = total_units * sp / nsplit, u1 = total_units * (sp + 1) / nsplit;
   const int per_sample = geo.TH * geo.nseg;
 
@@ -936,11 +955,21 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(PackedDesc
 //   (1) dU[point][c][n] = sum over the splits (one thread per element: 36 * cpad * 128 threads, coalesced along n; a single
 //       pass with one thread per (c, n) doing 36 * nsplit dependent loads took 170 us for 75 MB);
 //   (2) one thread per (c, n): 36 values -> G^T dU G -> k*k outputs in conv0.weight.grad's layout.
-__global__ __launch_bounds__(256) void fc_wino_wgrad_sum_kernel(const float *part, int nsplit, float *dusum, int64_t per) {
+// blockIdx.y = job (the source / target half of a layer: fc_wino_wgrad_reduce2)
+struct WwRedJob {
+  float *part;
+  int nsplit, c_off;
+};
+struct WwRedJobs {
+  WwRedJob j[2];
+};
+__global__ __launch_bounds__(256) void fc_wino_wgrad_sum_kernel(WwRedJobs jobs, int64_t per) {
+  const WwRedJob &J = jobs.j[blockIdx.y];
+  const int nsplit = J.nsplit;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= per) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const float *p = part + idx;
+  const float *p = J.part + idx;
   int s = 0;
   for (; s + 4 <= nsplit; s += 4) {
     s0 += p[(int64_t)s * per];
@@ -949,12 +978,13 @@ __global__ __launch_bounds__(256) void fc_wino_wgrad_sum_kernel(const float *par
     s3 += p[(int64_t)(s + 3) * per];
   }
   for (; s < nsplit; ++s) s0 += p[(int64_t)s * per];
-  dusum[idx] = (s0 + s1) + (s2 + s3);
+  J.part[idx] = (s0 + s1) + (s2 + s3);   // slab 0 <- the sum (element idx is read and written by this thread only)
 }
 
 template <int KS>
-__global__ __launch_bounds__(256) void fc_wino_wgrad_finish_kernel(const float *__restrict__ dusum, float *__restrict__ gw,
-                                                                  int C, int c_off, int cpad) {
+__global__ __launch_bounds__(256) void fc_wino_wgrad_finish_kernel(WwRedJobs jobs, float *__restrict__ gw, int C, int cpad) {
+  const float *__restrict__ dusum = jobs.j[blockIdx.y].part;
+  const int c_off = jobs.j[blockIdx.y].c_off;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (c, n), n fastest: coalesced reads
   if (idx >= (int64_t)cpad * kFcHidden) return;
   const int n = (int)(idx & (kFcHidden - 1)), c = (int)(idx >> 7);
@@ -1018,20 +1048,26 @@ int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k) {
 }
 
 // part: fc_wino_wgrad_splits(...) * 36 * cpad * 128 floats.  X: packed f32 records; Z: the f32 (B, Sz, 128) Z-layout map.
-int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
-                  int Wo, int Wp, int64_t SX, int k, hipStream_t stream) {
+static int ww_launch(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, hipStream_t stream) {
   if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
-  if (X.pix_stride != 64) return GFLA_ERR_UNSUPPORTED;
-  if (B <= 0) return GFLA_OK;
-  const WwGeo g = ww_geometry(Ho, Wo, k);
-  const int nsplit = fc_wino_wgrad_splits(B, Ho, Wo, cpad, k);
-  const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)nsplit);
+  if (B <= 0 || njobs <= 0) return GFLA_OK;
+  WwKArgs a[2];
+  int ns[2] = {0, 0};
+  for (int j = 0; j < 2; ++j) {
+    const WwJob &J = jobs[j < njobs ? j : 0];
+    if (J.X.pix_stride != 64) return GFLA_ERR_UNSUPPORTED;
+    const WwGeo g = ww_geometry(J.Ho, J.Wo, k);
+    const int nsplit = fc_wino_wgrad_splits(B, J.Ho, J.Wo, cpad, k);
+    a[j] = WwKArgs{J.X, J.Z, J.part, J.z_bs, J.z_lead, B * g.TH * g.nseg, J.SX, J.Wp, J.Wo, nsplit, g};
+    if (j < njobs) ns[j] = nsplit;
+  }
+  const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)(ns[0] + ns[1]));
 #define GFLA_WW(K_, D_)                                                                                                \
   {                                                                                                                    \
     const unsigned lds = (unsigned)(2 * kWwVFloats * 4 + 2 * Ww<K_>::RAW);                                             \
     auto kern = fc_wino_wgrad_kernel<K_, D_>;                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    kern<<<grid, kWnThreads, lds, stream>>>(X, Z, z_bs, z_lead, part, cpad, Wp, Wo, g, B * g.TH * g.nseg, nsplit, SX);   \
+    kern<<<grid, kWnThreads, lds, stream>>>(a[0], a[1], ns[0], cpad);                                                   \
   }
   if (k == 5) {
 #ifdef GFLA_PROBES  // timing ablations (tuning key 20 = 32 + bits; results are garbage): `make PROBES=1` builds only
@@ -1055,18 +1091,44 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
   return launch_status();
 }
 
+int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
+                  int Wo, int Wp, int64_t SX, int k, hipStream_t stream) {
+  const WwJob job{X, Z, part, z_bs, z_lead, SX, Ho, Wo, Wp};
+  return ww_launch(&job, 1, cpad, B, k, stream);
+}
+
+// two weight gradients (same B, cpad, k) in one launch
+int fc_wino_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, hipStream_t stream) {
+  if (njobs > 2) return GFLA_ERR_UNSUPPORTED;
+  return ww_launch(jobs, njobs, cpad, B, k, stream);
+}
+
 // `part` holds nsplit slabs of 36 * cpad * 128 floats; slab 0 is overwritten with their sum
-int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream) {
+static int ww_reduce_launch(const WwRedJobs &jobs, int njobs, float *grad_w0, int C, int cpad, int k, hipStream_t stream) {
   if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
   const int64_t per = (int64_t)kWnXi * cpad * kFcHidden;
-  // in place: element idx of slab 0 is read and written by the same thread only
-  fc_wino_wgrad_sum_kernel<<<dim3((unsigned)ceil_div(per, 256)), 256, 0, stream>>>(part, nsplit, part, per);
-  const dim3 grid((unsigned)ceil_div((int64_t)cpad * kFcHidden, 256));
+  fc_wino_wgrad_sum_kernel<<<dim3((unsigned)ceil_div(per, 256), (unsigned)njobs), 256, 0, stream>>>(jobs, per);
+  const dim3 grid((unsigned)ceil_div((int64_t)cpad * kFcHidden, 256), (unsigned)njobs);
   if (k == 5)
-    fc_wino_wgrad_finish_kernel<5><<<grid, 256, 0, stream>>>(part, grad_w0, C, c_off, cpad);
+    fc_wino_wgrad_finish_kernel<5><<<grid, 256, 0, stream>>>(jobs, grad_w0, C, cpad);
   else
-    fc_wino_wgrad_finish_kernel<3><<<grid, 256, 0, stream>>>(part, grad_w0, C, c_off, cpad);
+    fc_wino_wgrad_finish_kernel<3><<<grid, 256, 0, stream>>>(jobs, grad_w0, C, cpad);
   return launch_status();
+}
+
+int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream) {
+  WwRedJobs jobs;
+  jobs.j[0] = jobs.j[1] = WwRedJob{part, nsplit, c_off};
+  return ww_reduce_launch(jobs, 1, grad_w0, C, cpad, k, stream);
+}
+
+// source half (conv0 input channels C..2C-1) and target half (0..C-1): two launches for both instead of four
+int fc_wino_wgrad_reduce2(float *part_s, int nsplit_s, float *part_t, int nsplit_t, float *grad_w0, int C, int cpad, int k,
+                          hipStream_t stream) {
+  WwRedJobs jobs;
+  jobs.j[0] = WwRedJob{part_s, nsplit_s, C};
+  jobs.j[1] = WwRedJob{part_t, nsplit_t, 0};
+  return ww_reduce_launch(jobs, 2, grad_w0, C, cpad, k, stream);
 }
 
 }  // namespace gfla

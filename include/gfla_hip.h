@@ -73,7 +73,8 @@ const char *gfla_status_string(int status);
  *   key 19: FC weight gradient in arithmetic mode 4   0 auto (Winograd domain for k = 5), 1 direct, 2 Winograd
  *   key 20: timing ablations of the Winograd kernels -- only in `make PROBES=1` builds (results are garbage;
  *           tools/probe_wino.py); a default build ignores the key
- *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one
+ *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one (also
+ *           separates the two weight-gradient kernels of a layer again)
  *   key 23: resample2d d/d input1 LDS planes   0 fixed point + tap records (with scratch), 1 double planes (round 1)
  *   key 24: be_fwd_pix_kernel / be_fwd_wrow_kernel: threads per workgroup (0 auto; multiples of 64 up to 1024)
  *   key 25: be_fwd_pix_kernel: 1 = non-temporal output stores (A/B only: half the rate)
