@@ -61,6 +61,7 @@ _SINGLE = {
     "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_resample2d_bwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _int, _ptr],
+    "gfla_convert_multi": [_ptr, _ptr, _i64] * 4 + [_int, _ptr],
     "gfla_mask_blend_fwd_f32": [_ptr] * 6 + [_i64] * 3 + [_ptr],
     "gfla_mask_blend_fwd_bf16": [_ptr] * 6 + [_i64] * 3 + [_ptr],
     "gfla_mask_blend_bwd_f32": [_ptr] * 11 + [_i64] * 3 + [_ptr],
@@ -185,6 +186,27 @@ def call(name, ref_tensor, *args):
         raise RuntimeError("%s failed: %s (status %d)" % (name, lib().gfla_status_string(status).decode(), status))
 
 
+def convert_many(tensors, dtype):
+    """[t.to(dtype) for t in tensors] for bfloat16 <-> float32 CUDA tensors, up to four per launch (gfla_convert_multi);
+    None entries pass through.  Anything else (other dtypes, CPU tensors, nothing to convert) goes to torch."""
+    out = list(tensors)
+    todo = [i for i, t in enumerate(out) if t is not None and t.dtype != dtype]
+    pair_ok = all(out[i].is_cuda and {out[i].dtype, dtype} == {torch.bfloat16, torch.float32} for i in todo)
+    if not todo or not pair_ok or len({out[i].dtype for i in todo}) != 1:
+        return [None if t is None else t.to(dtype) for t in out]
+    for at in range(0, len(todo), 4):
+        grp = todo[at:at + 4]
+        srcs = [out[i].contiguous() for i in grp]
+        dsts = [torch.empty(t.shape, dtype=dtype, device=t.device) for t in srcs]
+        args = []
+        for j in range(4):
+            args += [ptr(srcs[j]), ptr(dsts[j]), srcs[j].numel()] if j < len(grp) else [None, None, 0]
+        call("gfla_convert_multi", srcs[0], *args, 1 if dtype == torch.bfloat16 else 0)
+        for i, d in zip(grp, dsts):
+            out[i] = d
+    return out
+
+
 def unfold_supported(Hs, Ws, k, elem_size):
     return bool(lib().gfla_unfold_supported(int(Hs), int(Ws), int(k), int(elem_size)))
 
@@ -194,7 +216,7 @@ def set_tuning(key, value):
     return lib().gfla_set_tuning(int(key), int(value))
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
 PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_BE_FWD_PIX, PATH_COUNT = 0, 1, 2, 7, 12, 13
 

@@ -18,7 +18,7 @@ struct FcLayout {
   // forward workspace, kept for backward
   int64_t amax, xs, xt, gs, hid, wd_t, wd_s, gt, wf_t, wf_s, wu_ft, wu_fs, wu_dt, wu_ds, fwd_total;
   // backward scratch: [dzs, dzt, dw_s, dw_t] are zeroed by one memset
-  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, dwp2, x32, bwd_total;
+  int64_t dzs, dzt, dw_s, dw_t, zero_bytes, zs_pk, zt_pk, dxs, dxt, b0p, dw1p, red, red_tmp, dwp, dwp2, x32, x32b, bwd_total;
   bool wgrad_f32_wino;   // mode 1, k = 5: the weight gradient runs in the float32 Winograd domain on unpacked activations
 };
 
@@ -91,6 +91,7 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
   L.dwp2 = take(dwp);   // the target half's partials: both halves are reduced by one launch pair
   const int64_t x32_s = fc_packed_bytes(B, L.nch_c, L.hs.Sx, 0), x32_t = fc_packed_bytes(B, L.nch_c, L.ht.Sx, 0);
   L.x32 = take(L.wgrad_f32_wino ? (x32_s > x32_t ? x32_s : x32_t) : 0);
+  L.x32b = take(L.wgrad_f32_wino ? x32_t : 0);   // the target half's copy: both weight gradients run as one grid
   L.bwd_total = o;
   return L;
 }
@@ -140,9 +141,8 @@ static int fc_forward(const float *source, const float *target, const float *flo
   const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
   if (mode) {   // the f16-split modes scale by max |x|; the float32 modes never read the slots
     if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-    GFLA_TRY(fc_maxabs(source, B * (int64_t)C * H * W, amax + kAmaxSrc, stream));
-    GFLA_TRY(fc_maxabs(target, B * (int64_t)C * H * W, amax + kAmaxTgt, stream));
-    GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
+    GFLA_TRY(fc_maxabs_multi(source, B * (int64_t)C * H * W, amax + kAmaxSrc, target, B * (int64_t)C * H * W, amax + kAmaxTgt,
+                             w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
   }
   if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
   GFLA_TRY(fc_pack_act2(source, a_src, ws + L.xs, L.hs, target, a_tgt, ws + L.xt, L.ht, B, C, H, W, mode, stream));
@@ -176,7 +176,8 @@ static bool fc_wgrad_in_wino_domain(int mode_, int k) { return mode_ == 4 && tun
 static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, unsigned char *ws, unsigned char *sc,
                             float *g_x, float *g_w0, int64_t B, int C, int H, int W, int k, int mode_,
                             hipStream_t stream, int acc_x = 0, bool dgrad_done = false, bool reduce_now = true,
-                            bool wgrad_done = false) {
+                            bool wgrad_done = false, bool z_ready = false, bool defer_fold = false) {
+  // z_ready: max |dz| and the packed gradient map already exist; defer_fold: fc_backward folds both halves in one launch
   // dgrad_done: convolution AND fold already enqueued; reduce_now = false: the weight-gradient partials stay in this half's
   // buffer (source: dwp, target: dwp2) and fc_backward reduces both halves together
   const bool wino = mode_ == 4;
@@ -191,8 +192,10 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
   PackedDesc Z;
   if (mode) {
-    GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z, stream));
-    GFLA_TRY(fc_pack_z(dz, a_z, zpk, B, g.Sz, kFcHidden, mode, stream));
+    if (!z_ready) {
+      GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z, stream));
+      GFLA_TRY(fc_pack_z(dz, a_z, zpk, B, g.Sz, kFcHidden, mode, stream));
+    }
     Z = fc_desc_packed(zpk, B, nch_h, g.Sz, mode);
   } else {
     Z = fc_desc_nhwc(dz, g.Sz, kFcHidden);
@@ -208,7 +211,7 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
       GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
                        g.Wp, k, mode, a_z, a_w, stream));
     }
-    if (!dgrad_done) GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
+    if (!dgrad_done && !defer_fold) GFLA_TRY(fc_fold(dx, g_x, B, C, H, W, g, g.Mdg * (int64_t)C, acc_x, stream));
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
@@ -217,10 +220,11 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
     // 2 = always Winograd
     float *part = reinterpret_cast<float *>(sc + (source ? L.dwp : L.dwp2));
     if (L.wgrad_f32_wino) {
-      float *x32 = reinterpret_cast<float *>(sc + L.x32);
+      float *x32 = reinterpret_cast<float *>(sc + (source ? L.x32 : L.x32b));
       GFLA_TRY(fc_unpack_act(ws + (source ? L.xs : L.xt), a_x, x32, B, L.nch_c, g.Sx, stream));
       const PackedDesc X32 = fc_desc_packed(x32, B, L.nch_c, g.Sx, 0);
-      GFLA_TRY(fc_wino_wgrad(X32, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+      if (!wgrad_done)
+        GFLA_TRY(fc_wino_wgrad(X32, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
       if (reduce_now)
         GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
                                       stream));
@@ -299,19 +303,36 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const bool wino_w = L.wgrad_f32_wino || fc_wgrad_in_wino_domain(mode_, k);
   const bool defer = g_w0 && need_s && need_t && (wino_w || mode == 0);
   // mode 4, k = 5: the two Winograd-domain weight-gradient kernels as ONE grid (each is one round of workgroups)
-  const bool both_wgrads = defer && both_dgrads && !L.wgrad_f32_wino && fc_wgrad_in_wino_domain(mode_, k) && tuning(21) != 2;
+  // (bf16 features, k = 5: the same kernel on the unpacked activations of both halves)
+  const bool both_wgrads = defer && wino_w && g_source && g_target && tuning(21) != 2;
+  // f16-split modes: max |dz| and the packed gradient maps of both halves by one launch each, and (any mode without the
+  // joint Winograd launch above) both replicate-pad folds by one launch behind the two data-gradient convolutions
+  const bool z_both = mode != 0 && need_s && need_t;
+  if (z_both) {
+    GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
+                             0, nullptr, stream));
+    GFLA_TRY(fc_pack_z2(dzs, amax + kAmaxZs, sc + L.zs_pk, L.hs.Sz, dzt, amax + kAmaxZt, sc + L.zt_pk, L.ht.Sz, B, kFcHidden,
+                        mode, stream));
+  }
+  const bool fold_both = !both_dgrads && g_source && g_target;
   if (need_s)
     GFLA_TRY(fc_half_backward(L, L.hs, true, ws, sc, g_source, g_w0, B, C, H, W, k, mode_, stream,
-                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads, !defer, both_wgrads));
+                              (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, both_dgrads, !defer, both_wgrads, z_both, fold_both));
   if (need_t)
     GFLA_TRY(fc_half_backward(L, L.ht, false, ws, sc, g_target, g_w0, B, C, H, W, k, mode_, stream, 0, both_dgrads, !defer,
-                              both_wgrads));
+                              both_wgrads, z_both, fold_both));
+  if (fold_both)
+    GFLA_TRY(fc_fold2(reinterpret_cast<const float *>(sc + L.dxs), g_source, L.hs, L.hs.Mdg * (int64_t)C,
+                      (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, reinterpret_cast<const float *>(sc + L.dxt), g_target, L.ht,
+                      L.ht.Mdg * (int64_t)C, 0, B, C, H, W, stream));
   if (both_wgrads) {
+    const PackedDesc Xs = L.wgrad_f32_wino ? fc_desc_packed(sc + L.x32, B, L.nch_c, L.hs.Sx, 0)
+                                           : fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
+    const PackedDesc Xt = L.wgrad_f32_wino ? fc_desc_packed(sc + L.x32b, B, L.nch_c, L.ht.Sx, 0)
+                                           : fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
     const WwJob jobs[2] = {
-        {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode), dzs, reinterpret_cast<float *>(sc + L.dwp), L.hs.Sz * kFcHidden,
-         L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
-        {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode), dzt, reinterpret_cast<float *>(sc + L.dwp2), L.ht.Sz * kFcHidden,
-         L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
+        {Xs, dzs, reinterpret_cast<float *>(sc + L.dwp), L.hs.Sz * kFcHidden, L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
+        {Xt, dzt, reinterpret_cast<float *>(sc + L.dwp2), L.ht.Sz * kFcHidden, L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
     GFLA_TRY(fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream));
   }
   if (defer) {

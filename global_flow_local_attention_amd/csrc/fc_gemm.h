@@ -125,6 +125,8 @@ inline FcHalf fc_half(int H, int W, int k, bool source) {
 
 // kernels / launchers defined in fc_gemm.hip
 int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream);
+int fc_maxabs_multi(const float *x0, int64_t n0, uint32_t *slot0, const float *x1, int64_t n1, uint32_t *slot1,
+                    const float *x2, int64_t n2, uint32_t *slot2, hipStream_t stream);
 int fc_pack_act(const float *src, const uint32_t *amax, void *out, int64_t B, int C, int H, int W, const FcHalf &g,
                 int mode, hipStream_t stream);
 int fc_pack_act2(const float *src_s, const uint32_t *amax_s, void *out_s, const FcHalf &gs, const float *src_t,
@@ -132,6 +134,8 @@ int fc_pack_act2(const float *src_s, const uint32_t *amax_s, void *out_s, const 
                  hipStream_t stream);
 int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
               hipStream_t stream);
+int fc_pack_z2(const float *z_s, const uint32_t *amax_s, void *out_s, int64_t S_s, const float *z_t, const uint32_t *amax_t,
+               void *out_t, int64_t S_t, int64_t B, int Cz, int mode, hipStream_t stream);
 int fc_unpack_act(const void *x16, const uint32_t *amax, float *x32, int64_t B, int nch, int64_t S, hipStream_t stream);
 int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_s, void *wd_t, void *wd_s, int C,
                     int k, int mode, hipStream_t stream);

@@ -92,7 +92,20 @@ int64_t fc_wpack_bytes(int ntiles, int nch, int k, int mode) {
 }
 
 // ------------------------------------------------------------------------------------------ max |x|
-__global__ __launch_bounds__(256) void fc_maxabs_kernel(const float *__restrict__ x, int64_t n, uint32_t *slot) {
+// blockIdx.y = job: up to three tensors per launch (the f16-split modes need max |x| of both activations and the weights
+// before anything else can start, and of both gradient maps in the backward pass)
+struct MaxAbsJob {
+  const float *x;
+  int64_t n;
+  uint32_t *slot;
+};
+struct MaxAbsJobs {
+  MaxAbsJob j[3];
+};
+__global__ __launch_bounds__(256) void fc_maxabs_kernel(MaxAbsJobs jobs) {
+  const MaxAbsJob &J = jobs.j[blockIdx.y];
+  const float *__restrict__ x = J.x;
+  const int64_t n = J.n;
   uint32_t m = 0;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
@@ -112,16 +125,33 @@ __global__ __launch_bounds__(256) void fc_maxabs_kernel(const float *__restrict_
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
-    if (m) atomicMax(slot, m);
+    if (m) atomicMax(J.slot, m);
   }
 }
 
-int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream) {
-  if (n <= 0) return GFLA_OK;
-  int64_t blocks = ceil_div(n, 256 * 16);
+int fc_maxabs_multi(const float *x0, int64_t n0, uint32_t *slot0, const float *x1, int64_t n1, uint32_t *slot1,
+                    const float *x2, int64_t n2, uint32_t *slot2, hipStream_t stream) {
+  MaxAbsJobs jobs;
+  int nj = 0;
+  int64_t most = 0;
+  const float *x[3] = {x0, x1, x2};
+  const int64_t n[3] = {n0, n1, n2};
+  uint32_t *slot[3] = {slot0, slot1, slot2};
+  for (int i = 0; i < 3; ++i)
+    if (x[i] && n[i] > 0) {
+      jobs.j[nj++] = MaxAbsJob{x[i], n[i], slot[i]};
+      if (n[i] > most) most = n[i];
+    }
+  if (nj == 0) return GFLA_OK;
+  for (int i = nj; i < 3; ++i) jobs.j[i] = jobs.j[0];
+  int64_t blocks = ceil_div(most, 256 * 16);
   if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
-  fc_maxabs_kernel<<<dim3((unsigned)blocks), 256, 0, stream>>>(x, n, slot);
+  fc_maxabs_kernel<<<dim3((unsigned)blocks, (unsigned)nj), 256, 0, stream>>>(jobs);
   return launch_status();
+}
+
+int fc_maxabs(const float *x, int64_t n, uint32_t *slot, hipStream_t stream) {
+  return fc_maxabs_multi(x, n, slot, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------ pack: NCHW f32 -> records
@@ -213,41 +243,72 @@ int fc_pack_act2(const float *src_s, const uint32_t *amax_s, void *out_s, const 
 // ------------------------------------------------------------- pack: f32 (B, S, Cz) pixel-major -> f16 records
 // (mode 2/3 only; mode 0 reads the f32 map in place).  A thread owns one pixel and walks its chunks: the reads of
 // a wave hit every 64-byte line of the map exactly once (through L2), the stores are contiguous per chunk.
+struct PackZJob {
+  const float *z;
+  const uint32_t *amax;
+  unsigned char *out;
+  int64_t S, split_stride;
+};
+struct PackZJobs {
+  PackZJob j[2];
+};
 template <int MODE>
-__global__ __launch_bounds__(256) void fc_pack_z_kernel(const float *__restrict__ z, const uint32_t *__restrict__ amax,
-                                                       unsigned char *__restrict__ out, int64_t S, int Cz,
-                                                       int64_t split_stride) {
+__global__ __launch_bounds__(256) void fc_pack_z_kernel(PackZJobs jobs, int nb0, int Cz) {
   using F = Fc<MODE>;
+  const bool second = (int)blockIdx.y >= nb0;
+  const PackZJob &J = jobs.j[second ? 1 : 0];
+  const int64_t S = J.S;
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= S) return;
-  const int64_t b = blockIdx.y;
+  const int64_t b = (int)blockIdx.y - (second ? nb0 : 0);
   const int nch = Cz / kFcChunk;
-  const float s = fc_scale(amax);
-  const float4 *zp = reinterpret_cast<const float4 *>(z + (b * S + m) * Cz);
+  const float s = fc_scale(J.amax);
+  const float4 *zp = reinterpret_cast<const float4 *>(J.z + (b * S + m) * Cz);
   for (int cc = 0; cc < nch; ++cc) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const float4 a = zp[cc * 4 + half * 2], c = zp[cc * 4 + half * 2 + 1];
       const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-      unsigned char *dst = out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
-      store_pieces<MODE>(v, s, dst, split_stride);
+      unsigned char *dst = J.out + (((b * nch + cc) * S + m) * kFcChunk + half * 8) * F::ESZ;
+      store_pieces<MODE>(v, s, dst, J.split_stride);
     }
   }
+}
+
+static int fc_pack_z_launch(const PackZJobs &jobs, int njobs, int64_t B, int Cz, int mode, hipStream_t stream) {
+  if (mode == 0 || B <= 0 || njobs <= 0) return GFLA_OK;
+  int64_t smax = jobs.j[0].S;
+  if (njobs > 1 && jobs.j[1].S > smax) smax = jobs.j[1].S;
+  if (njobs * B > 65535) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)ceil_div(smax, 256), (unsigned)(njobs * B));
+  if (mode == 1)
+    fc_pack_z_kernel<1><<<grid, 256, 0, stream>>>(jobs, (int)B, Cz);
+  else if (mode == 2)
+    fc_pack_z_kernel<2><<<grid, 256, 0, stream>>>(jobs, (int)B, Cz);
+  else
+    fc_pack_z_kernel<3><<<grid, 256, 0, stream>>>(jobs, (int)B, Cz);
+  return launch_status();
 }
 
 int fc_pack_z(const float *z, const uint32_t *amax, void *out, int64_t B, int64_t S, int Cz, int mode,
               hipStream_t stream) {
   if (mode == 0) return GFLA_OK;
-  const dim3 grid((unsigned)ceil_div(S, 256), (unsigned)B);
-  const PackedDesc d = fc_desc_packed(out, B, Cz / kFcChunk, S, mode);
-  unsigned char *o = static_cast<unsigned char *>(out);
-  if (mode == 1)
-    fc_pack_z_kernel<1><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
-  else if (mode == 2)
-    fc_pack_z_kernel<2><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
-  else
-    fc_pack_z_kernel<3><<<grid, 256, 0, stream>>>(z, amax, o, S, Cz, d.split_stride);
-  return launch_status();
+  PackZJobs jobs;
+  jobs.j[0] = jobs.j[1] =
+      PackZJob{z, amax, static_cast<unsigned char *>(out), S, fc_desc_packed(out, B, Cz / kFcChunk, S, mode).split_stride};
+  return fc_pack_z_launch(jobs, 1, B, Cz, mode, stream);
+}
+
+// both gradient maps of a layer in one launch
+int fc_pack_z2(const float *z_s, const uint32_t *amax_s, void *out_s, int64_t S_s, const float *z_t, const uint32_t *amax_t,
+               void *out_t, int64_t S_t, int64_t B, int Cz, int mode, hipStream_t stream) {
+  if (mode == 0) return GFLA_OK;
+  PackZJobs jobs;
+  jobs.j[0] = PackZJob{z_s, amax_s, static_cast<unsigned char *>(out_s), S_s,
+                       fc_desc_packed(out_s, B, Cz / kFcChunk, S_s, mode).split_stride};
+  jobs.j[1] = PackZJob{z_t, amax_t, static_cast<unsigned char *>(out_t), S_t,
+                       fc_desc_packed(out_t, B, Cz / kFcChunk, S_t, mode).split_stride};
+  return fc_pack_z_launch(jobs, 2, B, Cz, mode, stream);
 }
 
 // ------------------------------------------------------------------- unpack: one-f16-term records -> f32 records

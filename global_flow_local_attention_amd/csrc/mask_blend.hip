@@ -103,11 +103,83 @@ static int mask_blend_bwd(const T *out, const T *ap, const T *ar, const T *mp, c
   return launch_status();
 }
 
+// ---- storage-type conversion of up to four tensors in ONE launch -------------------------------------------------------
+// The bf16 feature path of ExtractorAttn (extractor_attn.py: FusedAttnBf16Function) widens three operands on the way in and
+// narrows three gradients on the way out, per call; at the face model's batch each conversion is a launch-sized kernel and
+// the step is bound as much by the host's launch rate as by the GPU (tools/probe_face_host.py).  blockIdx.y = job.
+struct ConvertJob {
+  const void *src;
+  void *dst;
+  int64_t n;
+};
+struct ConvertJobs {
+  ConvertJob j[4];
+};
+template <bool TO_BF16>
+__global__ __launch_bounds__(256) void convert_multi_kernel(ConvertJobs jobs) {
+  const ConvertJob &J = jobs.j[blockIdx.y];
+  const int64_t n = J.n, stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(J.src) | reinterpret_cast<uintptr_t>(J.dst)) & 15) == 0 ? n >> 2 : 0;
+  if constexpr (TO_BF16) {   // float32 -> bfloat16, round to nearest even (torch's conversion)
+    const float4 *s4 = static_cast<const float4 *>(J.src);
+    uint2 *d4 = static_cast<uint2 *>(J.dst);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 v = s4[i];
+      d4[i] = make_uint2((uint32_t)Num<bf16_t>::pack(v.x) | (uint32_t)Num<bf16_t>::pack(v.y) << 16,
+                         (uint32_t)Num<bf16_t>::pack(v.z) | (uint32_t)Num<bf16_t>::pack(v.w) << 16);
+    }
+    const float *s = static_cast<const float *>(J.src);
+    uint16_t *d = static_cast<uint16_t *>(J.dst);
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = Num<bf16_t>::pack(s[i]);
+  } else {                   // bfloat16 -> float32 (exact)
+    const uint2 *s4 = static_cast<const uint2 *>(J.src);
+    float4 *d4 = static_cast<float4 *>(J.dst);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const uint2 v = s4[i];
+      d4[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                          __uint_as_float(v.y & 0xffff0000u));
+    }
+    const uint16_t *s = static_cast<const uint16_t *>(J.src);
+    float *d = static_cast<float *>(J.dst);
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+      d[i] = __uint_as_float((uint32_t)s[i] << 16);
+  }
+}
+
 }  // namespace gfla
 
 using gfla::bf16_t;
 
 extern "C" {
+/* dst_i[0..n_i) = convert(src_i[0..n_i)) for up to four tensors (unused jobs: n = 0); to_bf16 = 0: bfloat16 -> float32,
+ * 1: float32 -> bfloat16 (round to nearest even). */
+int gfla_convert_multi(const void *s0, void *d0, int64_t n0, const void *s1, void *d1, int64_t n1, const void *s2, void *d2,
+                       int64_t n2, const void *s3, void *d3, int64_t n3, int to_bf16, gfla_stream_t st) {
+  gfla::ConvertJobs jobs;
+  const void *s[4] = {s0, s1, s2, s3};
+  void *d[4] = {d0, d1, d2, d3};
+  const int64_t n[4] = {n0, n1, n2, n3};
+  int nj = 0;
+  int64_t most = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (n[i] < 0) return GFLA_ERR_BAD_SHAPE;
+    if (n[i] == 0) continue;
+    if (!s[i] || !d[i]) return GFLA_ERR_NULL_POINTER;
+    jobs.j[nj++] = gfla::ConvertJob{s[i], d[i], n[i]};
+    if (n[i] > most) most = n[i];
+  }
+  if (nj == 0) return GFLA_OK;
+  for (int i = nj; i < 4; ++i) jobs.j[i] = gfla::ConvertJob{nullptr, nullptr, 0};
+  int64_t blocks = gfla::ceil_div(most, 256 * 8);
+  if (blocks > 4 * gfla::kNumCU) blocks = 4 * gfla::kNumCU;
+  const dim3 grid((unsigned)blocks, (unsigned)nj);
+  if (to_bf16)
+    gfla::convert_multi_kernel<true><<<grid, 256, 0, static_cast<hipStream_t>(st)>>>(jobs);
+  else
+    gfla::convert_multi_kernel<false><<<grid, 256, 0, static_cast<hipStream_t>(st)>>>(jobs);
+  return gfla::launch_status();
+}
+
 int gfla_mask_blend_fwd_f32(const float *out, const float *ap, const float *ar, const float *mp, const float *mr, float *y,
                             int64_t B, int64_t C, int64_t HW, gfla_stream_t st) {
   return gfla::mask_blend_fwd<float>(out, ap, ar, mp, mr, y, B, C, HW, st);

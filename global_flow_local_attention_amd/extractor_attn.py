@@ -434,7 +434,8 @@ class FusedAttnBf16Function(Function):
             raise ValueError("ExtractorAttn (bf16): source, target and flow must share B, C and H, W")
         source, flow = source.contiguous(), flow.contiguous()
         f32 = lambda t: None if t is None else t.detach().float().contiguous()
-        s32, t32, fl32 = f32(source), f32(target), f32(flow)
+        # (one launch for the three widenings: the call is launch-bound at the face model's batch)
+        s32, t32, fl32 = _lib.convert_many([source.detach(), target.detach().contiguous(), flow.detach()], torch.float32)
         w0c, w1c, b0c, b1c = f32(w0), f32(w1).reshape(k * k, 128), f32(b0), f32(b1)
         mode = 1
         ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=source.device)
@@ -468,9 +469,8 @@ class FusedAttnBf16Function(Function):
             # block-sparse product on the matrix cores (csrc/patch_mfma.hip; the bf16 entry point only has the LDS-atomic
             # scatter, the slowest kernel of the bf16 step), and the FC backward ACCUMULATES its own source / flow
             # gradients on top in the same float32 buffers -- one rounding to bf16 at the very end instead of two.
-            s32 = source.float()
             g_s32, gf32, gl32 = _zeros_f32(dev, ((B, C, H, W), need[0]), ((B, 2, H, W), need[2]), ((B, k * k, H, W), True))
-            attn32, go32 = attn.float(), g_out.contiguous().float()
+            s32, attn32, go32 = _lib.convert_many([source, attn, g_out.contiguous()], torch.float32)
             table = _lib.scatter_workspace(s32, B, H, W, (k + 1) ** 2) if need[0] else None
             _lib.call("gfla_local_attn_aggregate_bwd_ws_f32", s32, _lib.ptr(s32), _lib.ptr(fl32), _lib.ptr(attn32),
                       _lib.ptr(go32), _lib.ptr(g_s32), _lib.ptr(gf32), _lib.ptr(gl32), _lib.ptr(table), B, C, H, W, H, W, k, 1)
@@ -497,11 +497,15 @@ class FusedAttnBf16Function(Function):
         if not need[0]:
             g_source = None
         elif f32_aggregate:
-            g_source = g_s32.to(torch.bfloat16)
+            g_source = g_s32
         else:
-            g_source = (gs.float() + g_s32).to(torch.bfloat16)
-        return (g_source, cast(g_t32, target_dtype), cast(gf32, flow_dtype), cast(g_w0, pdt[0]), cast(g_b0, pdt[1]),
-                cast(g_w1, pdt[2]), cast(g_b1, pdt[3]), None, None)
+            g_source = gs.float() + g_s32
+        if target_dtype == flow_dtype == torch.bfloat16:   # the three feature-map gradients narrowed by one launch
+            g_source, g_target, g_flow = _lib.convert_many([g_source, g_t32, gf32], torch.bfloat16)
+        else:
+            g_source, g_target, g_flow = cast(g_source, torch.bfloat16), cast(g_t32, target_dtype), cast(gf32, flow_dtype)
+        return (g_source, g_target, g_flow, cast(g_w0, pdt[0]), cast(g_b0, pdt[1]), cast(g_w1, pdt[2]), cast(g_b1, pdt[3]),
+                None, None)
 
 
 def _fused_attention(self, source, target, flow_field):

@@ -52,8 +52,9 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   1: round 1 (the three ops + aggregate)   2: round 2 (fc_*, *_ws, bf16 backward, max_cosine, correctness_map)
  *   3: round 3 (gfla_path_count, process-global tuning, arithmetic mode 4)
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
- *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX) */
-#define GFLA_ABI_VERSION 5
+ *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX)
+ *   6: round 4 (gfla_convert_multi) */
+#define GFLA_ABI_VERSION 6
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
@@ -457,6 +458,12 @@ int gfla_correctness_map_bwd_f32(const float *warped, const float *target, const
                                  const float *stats, const float *loss_map, const float *grad_map,
                                  float *grad_warped, float *grad_target, float *grad_best, int64_t B,
                                  int64_t C, int64_t N, double eps_cos, double eps, gfla_stream_t stream);
+
+/* Storage-type conversion of up to four contiguous tensors in one launch (unused jobs: n = 0).  to_bf16 = 0: bfloat16 ->
+ * float32 (exact); 1: float32 -> bfloat16, round to nearest even.  The bf16 feature path of ExtractorAttn widens three
+ * operands and narrows three gradients per call; at the face model's batch every one of them was a launch of its own. */
+int gfla_convert_multi(const void *src0, void *dst0, int64_t n0, const void *src1, void *dst1, int64_t n1, const void *src2,
+                       void *dst2, int64_t n2, const void *src3, void *dst3, int64_t n3, int to_bf16, gfla_stream_t stream);
 
 /* ---- mask blend of the face model's attention pair (generator.py:496-499; csrc/mask_blend.hip, round 4) ----
  *   y = (out*(1-mask_p) + attn_p*mask_p) + (out*(1-mask_r) + attn_r*mask_r)
