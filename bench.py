@@ -591,7 +591,7 @@ def fc_kernel_probes(hp, iters=10):
                                 "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
                                 "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
                                 "in_step": True})
-                elif mode == 4 and (which < 4 or k == 5):   # (k = 3 weight gradient: the direct kernel, csrc/fc_block.hip)
+                elif mode == 4:   # (the weight gradients of both layers run in the Winograd domain too: csrc/fc_block.hip)
                     # Winograd domain: the kernel EXECUTES 36 multiplies per (tile, c, n) -- F(2x2,5x5): 2x2 outputs per
                     # tile, F(4x4,3x3): 4x4.  `TFLOPs` / `frac` are these executed MFMA flops against the f32 peak (what the
                     # hardware does); `effective_TFLOPs` = the reference formulation's flops / time (what the caller gets).

@@ -168,8 +168,13 @@ static int fc_forward(const float *source, const float *target, const float *flo
                             L.hs.Mg * kFcHidden, L.ht.Mg * kFcHidden, L.hs.Wo, L.ht.Wo, slope, stream);
 }
 
-// mode 4: the Winograd-domain weight gradient for k = 5 (tuning key 19: 1 = always direct, 2 = always Winograd)
-static bool fc_wgrad_in_wino_domain(int mode_, int k) { return mode_ == 4 && tuning(19) != 1 && (k == 5 || tuning(19) == 2); }
+// mode 4: the weight gradient in the Winograd domain (tuning key 19: 1 = the direct kernel, 3 = round 3's choice: Winograd for
+// k = 5 only).  Round 3 kept the direct kernel for k = 3 (135 vs 172 us at C256 32x22: units of one tile row, 6 of 16 tiles);
+// with units of whole tile rows and both halves in one grid it is 102 / 88 us against 151 / 129
+// (profiles/r4_wino_wgrad_k3_multirow.txt).
+static bool fc_wgrad_in_wino_domain(int mode_, int k) {
+  return mode_ == 4 && tuning(19) != 1 && (k == 5 || tuning(19) != 3);
+}
 
 // data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
 // Z-layout gradient map
@@ -215,9 +220,6 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   }
   if (want_w) {
     const PackedDesc X = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, mode);
-    // mode 4: the Winograd-domain weight gradient for k = 5; for k = 3 the 4 x 4 tiling leaves 1-2 k steps per tile row and
-    // the direct kernel measured faster in the step (135 vs 172 us at C256 32x22) -- tuning key 19: 1 = always direct,
-    // 2 = always Winograd
     float *part = reinterpret_cast<float *>(sc + (source ? L.dwp : L.dwp2));
     if (L.wgrad_f32_wino) {
       float *x32 = reinterpret_cast<float *>(sc + (source ? L.x32 : L.x32b));
@@ -507,7 +509,7 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
       return fc_wino_conv(Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
                           reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, B,
                           kFcHidden / kFcChunk, g.Md, g.Wp, g.Wp, g.Sz, k, stream);
-    if (tuning(19) == 1 || (k != 5 && tuning(19) != 2))
+    if (!fc_wgrad_in_wino_domain(mode, k))
       return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
     return fc_wino_wgrad(X4, reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz * kFcHidden, g.lead,
                          reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream);

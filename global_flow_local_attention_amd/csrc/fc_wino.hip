@@ -660,12 +660,18 @@ struct Ww {
   static constexpr int SEG = KS == 5 ? 32 : 16;          // tiles per unit
   static constexpr int L = M * SEG + 6 - M;              // raw pixels per row of a unit
   static constexpr int RAW = ((6 * L * kWwPitch + 15) & ~15);
+  // multi-row units (narrow maps): up to SEGM tiles = two 16-tile steps, so that the second step's transform runs under
+  // the first one's MFMAs; the unit's raw rows (its own pitch) must fit kWwRawMax bytes and PFM pieces per thread
+  static constexpr int SEGM = 32;
+  static constexpr int PFM = KS == 5 ? 4 : 5;
 };
+constexpr int kWwRawMax = 43 * 1024;   // per raw buffer: 2 V buffers (72 KB) + 2 x 43 KB = the 160 KB of a CU
 constexpr int kWwVFloats = 4 * 4 * 16 * kWnXi;           // one V buffer: [tile >> 2][tile & 3][channel][point]: a lane's 36
                                                          // A values of a k step are contiguous (nine ds_read_b128)
 
 struct WwGeo {
   int TH, TW, nseg;
+  int R, ups;   // tile rows per unit (> 1: narrow maps, see ww_geometry), units per sample
 };
 
 // A dY A^T for one (tile, channel): dy[i][j] (m x m) -> zh[36]
@@ -707,7 +713,8 @@ __device__ __forceinline__ void ww_lift(const float (&dy)[M][M], float (&zh)[kWn
 
 struct WwUnit {
   int64_t b;
-  int ty, tx0, ntx;
+  int ty, tx0, ntx;   // first tile row, first tile column, tiles per row
+  int nt;             // tiles of the unit = ntx * rows (rows > 1 only in the multi-row instantiation)
 };
 
 // DBG (timing ablations, tools only; results are garbage): 1 no input transform, 2 no MFMAs / A reads, 4 no dY loads,
@@ -720,8 +727,14 @@ struct WwKArgs {
   int Wp, Wo, nsplit;
   WwGeo geo;
 };
-template <int KS, int DBG = 0>
-__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad) {
+// MR (multi-row units): on a map whose tile rows are at most half a unit (TW <= SEG / 2: the k = 3 layer at 32x22 has 6
+// tiles of 4x4 per row against units of 16) a unit of ONE tile row left the k steps mostly empty -- 6 of 16 tiles, one
+// exposed transform per 6 tiles -- and the direct kernel won (135 vs 172 us).  With MR a unit is R = SEG / TW whole tile
+// rows: the raw rows are staged with the map's own pitch instead of the unit's maximum, tile t of the unit is (t / TW,
+// t % TW).  The single-row instantiation keeps its compile-time pitch (every LDS offset of the transform an immediate).
+template <int KS, int DBG = 0, bool MR = false>
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad,
+                                                                     int raw_stride) {
   // One launch carries up to TWO weight gradients (the source and the target half of a layer): split indices
   // [0, nsplit0) belong to job 0, the rest to job 1 -- each job is one round of workgroups, and in one grid the second
   // round starts on a CU the moment the first one's workgroup there retires.  Workgroup-uniform selects (scalar registers).
@@ -736,16 +749,25 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   const int Wp = GFLA_PICK(Wp), Wo = GFLA_PICK(Wo), nsplit = GFLA_PICK(nsplit);
   WwGeo geo;
   geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.nseg = GFLA_PICK(geo.nseg);
+  geo.R = GFLA_PICK(geo.R), geo.ups = GFLA_PICK(geo.ups);
 #undef GFLA_PICK
-  constexpr int M = Ww<KS>::M, SEG = Ww<KS>::SEG, L = Ww<KS>::L, RAW = Ww<KS>::RAW, PITCH = kWwPitch;
-  constexpr int PF = (6 * L * 4 + kWnThreads - 1) / kWnThreads;  // 16-byte pieces of a unit's raw rows per thread
+  constexpr int M = Ww<KS>::M, SEG = Ww<KS>::SEG, L = Ww<KS>::L, PITCH = kWwPitch;
+  const int RAW = MR ? raw_stride : Ww<KS>::RAW;   // bytes between the two raw buffers
+  // 16-byte pieces of a unit's raw rows per thread
+  constexpr int PF1 = (6 * L * 4 + kWnThreads - 1) / kWnThreads;
+  constexpr int PF = MR ? (PF1 > Ww<KS>::PFM ? PF1 : Ww<KS>::PFM) : PF1;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *vbuf = reinterpret_cast<float *>(gfla_smem);            // [2][kWwVFloats]
   unsigned char *raw = gfla_smem + 2 * kWwVFloats * 4;           // [2][6][L][PITCH]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xh = wave >> 2;
   const int cc = blockIdx.x, sp = (int)blockIdx.y - (second ? nsplit0 : 0);
   const int64_t u0 = total_units * sp / nsplit, u1 = total_units * (sp + 1) / nsplit;
-  const int per_sample = geo.TH * geo.nseg;
+  const int per_sample = geo.ups;
+  // raw row pitch in pixels and raw rows of a unit: the unit's maximum (compile time) or, multi-row, the map's own
+  const int Lr = (MR && geo.R > 1) ? M * geo.TW + 6 - M : L;
+  const int raw_rows = (MR && geo.R > 1) ? M * geo.R + 6 - M : 6;
+  const int npieces = raw_rows * Lr * 4;
+  const unsigned inv_ntx = (65536u + (unsigned)geo.TW - 1u) / (unsigned)geo.TW;   // t / TW = (t * inv) >> 16 for t < 2^8
 
   f32x4v acc[kWnXi];
 #pragma unroll
@@ -755,17 +777,35 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
     WwUnit un;
     un.b = u / per_sample;
     const int r = (int)(u - un.b * per_sample);
-    un.ty = r / geo.nseg;
-    un.tx0 = (r - un.ty * geo.nseg) * SEG;
-    un.ntx = min(SEG, geo.TW - un.tx0);
+    if (MR && geo.R > 1) {   // R whole tile rows
+      un.ty = r * geo.R;
+      un.tx0 = 0;
+      un.ntx = geo.TW;
+      un.nt = geo.TW * min(geo.R, geo.TH - un.ty);
+    } else {
+      un.ty = r / geo.nseg;
+      un.tx0 = (r - un.ty * geo.nseg) * SEG;
+      un.ntx = min(SEG, geo.TW - un.tx0);
+      un.nt = un.ntx;
+    }
     return un;
+  };
+  // tile t of a unit -> (tile row inside the unit, tile column)
+  auto tile_rc = [&](int t_, int &tr, int &tcol) {
+    if (MR && geo.R > 1) {
+      tr = (int)(((unsigned)t_ * inv_ntx) >> 16);
+      tcol = t_ - tr * geo.TW;
+    } else {
+      tr = 0;
+      tcol = t_;
+    }
   };
 
   // raw rows of a unit: piece q -> (row = q / (4 L), pixel, part); global -> registers -> LDS (pitch 72: two b64 stores)
   u32x4v pf[PF];
   auto piece_addr = [&](const WwUnit &un, int q, int &ldso) -> const unsigned char * {
-    const int row = q / (4 * L), rem = q - row * (4 * L), px = rem >> 2, prt = rem & 3;
-    ldso = (row * L + px) * PITCH + prt * 16;
+    const int row = q / (4 * Lr), rem = q - row * (4 * Lr), px = rem >> 2, prt = rem & 3;
+    ldso = (row * Lr + px) * PITCH + prt * 16;
     const int64_t pix = (int64_t)(M * un.ty + row) * Wp + M * un.tx0 + px;
     return X.base + un.b * X.batch_stride + (int64_t)cc * X.chunk_stride + (pix < SX ? pix : SX - 1) * X.pix_stride + prt * 16;
   };
@@ -773,14 +813,14 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       int ldso;
-      pf[i] = *reinterpret_cast<const u32x4v *>(piece_addr(un, min(t + kWnThreads * i, 6 * L * 4 - 1), ldso));
+      pf[i] = *reinterpret_cast<const u32x4v *>(piece_addr(un, min(t + kWnThreads * i, npieces - 1), ldso));
     }
   };
   auto commit = [&](const WwUnit &un, int buf) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int q = t + kWnThreads * i;
-      if (q < 6 * L * 4) {
+      if (q < npieces) {
         int ldso;
         (void)piece_addr(un, q, ldso);
         uint2 *d = reinterpret_cast<uint2 *>(raw + buf * RAW + ldso);
@@ -796,8 +836,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   const int vpos = ((tks * 4 + tq) * 16 + tc) * kWnXi + xh * 18;   // float offset of V[ks][tq][c][first point of this half]
   auto transform = [&](auto half_tag, const WwUnit &un, int h, int rbuf, int vb) {
     constexpr int HALF = decltype(half_tag)::value;
-    const int tile = min(h * 16 + tl, un.ntx - 1);
-    const unsigned char *src = raw + rbuf * RAW + (M * tile) * PITCH + tc * 4;
+    const int tile = min(h * 16 + tl, un.nt - 1);
+    int tr, tcol;
+    tile_rc(tile, tr, tcol);
+    const unsigned char *src = raw + rbuf * RAW + ((M * tr) * Lr + M * tcol) * PITCH + tc * 4;
     float *dst = vbuf + vb * kWwVFloats + vpos;
     __builtin_amdgcn_s_setprio(3);
     float tm[3][6];
@@ -806,8 +848,8 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
       f32x2v d[6], o[3];
 #pragma unroll
       for (int i = 0; i < 6; ++i)
-        d[i] = f32x2v{*reinterpret_cast<const float *>(src + (i * L + 2 * jp) * PITCH),
-                      *reinterpret_cast<const float *>(src + (i * L + 2 * jp + 1) * PITCH)};
+        d[i] = f32x2v{*reinterpret_cast<const float *>(src + (i * Lr + 2 * jp) * PITCH),
+                      *reinterpret_cast<const float *>(src + (i * Lr + 2 * jp + 1) * PITCH)};
       wn_bt3<HALF, f32x2v>(d, o);
 #pragma unroll
       for (int r = 0; r < 3; ++r) tm[r][2 * jp] = o[r][0], tm[r][2 * jp + 1] = o[r][1];
@@ -828,9 +870,11 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   const int kq = lane >> 4, n = wave * 16 + (lane & 15);
   auto load_dy = [&](const WwUnit &un, int h, int ks, float (&dy)[M][M]) {
     const int tile = h * 16 + 4 * ks + kq;
-    const bool live = tile < un.ntx;
-    const int xo0 = M * (un.tx0 + (live ? tile : 0));
-    const float *zp = Z + un.b * z_bs + (z_lead + (int64_t)(M * un.ty) * Wp + xo0) * kFcHidden + n;
+    const bool live = tile < un.nt;
+    int tr, tcol;
+    tile_rc(live ? tile : 0, tr, tcol);
+    const int xo0 = M * (un.tx0 + tcol);
+    const float *zp = Z + un.b * z_bs + (z_lead + (int64_t)(M * (un.ty + tr)) * Wp + xo0) * kFcHidden + n;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -842,8 +886,10 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   // every load_dy wait for its own round trip -- the "two k steps ahead" never happened (80 of the kernel's 385 us).
   auto mask_dy = [&](const WwUnit &un, int h, int ks, float (&dy)[M][M]) {
     const int tile = h * 16 + 4 * ks + kq;
-    const bool live = tile < un.ntx;
-    const int xo0 = M * (un.tx0 + (live ? tile : 0));
+    const bool live = tile < un.nt;
+    int tr, tcol;
+    tile_rc(live ? tile : 0, tr, tcol);
+    const int xo0 = M * (un.tx0 + tcol);
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -854,7 +900,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
       }
   };
   auto multiply = [&](const WwUnit &un, int h, int vb) {
-    const int nks = min(4, (un.ntx - h * 16 + 3) >> 2);
+    const int nks = min(4, (un.nt - h * 16 + 3) >> 2);
     const float *va = vbuf + vb * kWwVFloats + (kq * 16 + (lane & 15)) * kWnXi;
     // the dY values run TWO k steps ahead of their use (global loads: an L2 round trip is about one k step of MFMAs)
     constexpr int AHEAD = M == 2 ? 2 : 1;
@@ -902,7 +948,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
     __syncthreads();
     int vb = 0, rbuf = 0;
     for (int64_t u = u0; u < u1; ++u) {
-      const int nh = (cur.ntx + 15) >> 4;
+      const int nh = (cur.nt + 15) >> 4;
       const bool has_next = u + 1 < u1;
       const WwUnit nxt = has_next ? unit_of(u + 1) : cur;
       for (int h = 0; h < nh; ++h) {
@@ -1035,12 +1081,25 @@ static WwGeo ww_geometry(int Ho, int Wo, int k) {
   g.TH = (Ho + m - 1) / m;
   g.TW = (Wo + m - 1) / m;
   g.nseg = (g.TW + seg - 1) / seg;
+  // narrow maps: a unit of R whole tile rows (up to 32 tiles = two steps) instead of one mostly empty row (the MR
+  // instantiation; tuning key 29 = 1: off, 2: at most 16 tiles per unit)
+  g.R = 1;
+  if (g.nseg == 1 && 2 * g.TW <= 32 && tuning(29) != 1) {
+    const int segm = tuning(29) == 2 ? 16 : 32;
+    const int pfm = (k == 5 ? 4 : 5) * kWnThreads;
+    int R = segm / g.TW;
+    if (R > g.TH) R = g.TH;
+    while (R > 1 && ((m * R + 6 - m) * (m * g.TW + 6 - m) * kWwPitch > kWwRawMax || (m * R + 6 - m) * (m * g.TW + 6 - m) * 4 > pfm))
+      --R;
+    g.R = R < 1 ? 1 : R;
+  }
+  g.ups = g.R > 1 ? (g.TH + g.R - 1) / g.R : g.TH * g.nseg;
   return g;
 }
 
 int fc_wino_wgrad_splits(int64_t B, int Ho, int Wo, int cpad, int k) {
   const WwGeo g = ww_geometry(Ho, Wo, k);
-  const int64_t units = B * g.TH * g.nseg;
+  const int64_t units = B * g.ups;
   // 8 waves per workgroup, two per SIMD: ONE workgroup per CU; one round of 256 workgroups
   int64_t s = tuning(12) > 0 ? tuning(12) : kNumCU / (cpad / kFcChunk);
   if (s < 1) s = 1;
@@ -1053,21 +1112,29 @@ static int ww_launch(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, h
   if (B <= 0 || njobs <= 0) return GFLA_OK;
   WwKArgs a[2];
   int ns[2] = {0, 0};
+  bool multirow = false;
+  int raw_stride = 0;   // bytes of one raw buffer: the larger of the jobs' needs
   for (int j = 0; j < 2; ++j) {
     const WwJob &J = jobs[j < njobs ? j : 0];
     if (J.X.pix_stride != 64) return GFLA_ERR_UNSUPPORTED;
     const WwGeo g = ww_geometry(J.Ho, J.Wo, k);
     const int nsplit = fc_wino_wgrad_splits(B, J.Ho, J.Wo, cpad, k);
-    a[j] = WwKArgs{J.X, J.Z, J.part, J.z_bs, J.z_lead, B * g.TH * g.nseg, J.SX, J.Wp, J.Wo, nsplit, g};
-    if (j < njobs) ns[j] = nsplit;
+    a[j] = WwKArgs{J.X, J.Z, J.part, J.z_bs, J.z_lead, B * g.ups, J.SX, J.Wp, J.Wo, nsplit, g};
+    if (j < njobs) {
+      ns[j] = nsplit;
+      multirow = multirow || g.R > 1;
+      const int m = k == 5 ? 2 : 4;
+      const int need = g.R > 1 ? (((m * g.R + 6 - m) * (m * g.TW + 6 - m) * kWwPitch + 15) & ~15) : (k == 5 ? Ww<5>::RAW : Ww<3>::RAW);
+      if (need > raw_stride) raw_stride = need;
+    }
   }
   const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)(ns[0] + ns[1]));
 #define GFLA_WW(K_, D_)                                                                                                \
   {                                                                                                                    \
-    const unsigned lds = (unsigned)(2 * kWwVFloats * 4 + 2 * Ww<K_>::RAW);                                             \
-    auto kern = fc_wino_wgrad_kernel<K_, D_>;                                                                          \
+    const unsigned lds = (unsigned)(2 * kWwVFloats * 4 + 2 * raw_stride);                                              \
+    auto kern = multirow ? fc_wino_wgrad_kernel<K_, D_, true> : fc_wino_wgrad_kernel<K_, D_, false>;                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    kern<<<grid, kWnThreads, lds, stream>>>(a[0], a[1], ns[0], cpad);                                                   \
+    kern<<<grid, kWnThreads, lds, stream>>>(a[0], a[1], ns[0], cpad, raw_stride);                                       \
   }
   if (k == 5) {
 #ifdef GFLA_PROBES  // timing ablations (tuning key 20 = 32 + bits; results are garbage): `make PROBES=1` builds only

@@ -71,7 +71,7 @@ const char *gfla_status_string(int status);
  *   key 6: resample2d fwd/bwd        0 auto, 1 force global kernels
  *   key 7: row windows for planes larger than the LDS budget   0 on, 1 off (use global kernels)
  *   key 10: LDS budget per workgroup in KB (0 = 64; up to 160)
- *   key 19: FC weight gradient in arithmetic mode 4   0 auto (Winograd domain for k = 5), 1 direct, 2 Winograd
+ *   key 19: FC weight gradient in arithmetic mode 4   0 auto (Winograd domain), 1 direct, 3 Winograd for k = 5 only (round 3)
  *   key 20: timing ablations of the Winograd kernels -- only in `make PROBES=1` builds (results are garbage;
  *           tools/probe_wino.py); a default build ignores the key
  *   key 21: Winograd convolutions   1 single raw buffer, 2 one launch per half instead of both halves in one (also
@@ -80,6 +80,8 @@ const char *gfla_status_string(int status);
  *   key 24: be_fwd_pix_kernel / be_fwd_wrow_kernel: threads per workgroup (0 auto; multiples of 64 up to 1024)
  *   key 25: be_fwd_pix_kernel: 1 = non-temporal output stores (A/B only: half the rate)
  *   key 27: (make PROBES=1 builds) timing ablations of the two round-4 block_extractor forward kernels
+ *   key 29: Winograd-domain weight gradient: 1 = units of one tile row everywhere (round 3); 0 = whole tile rows per unit
+ *           on maps whose tile rows fill at most half a unit (csrc/fc_wino.hip: MR)
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 

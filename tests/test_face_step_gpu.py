@@ -110,3 +110,28 @@ def test_mask_blend_kernel_equals_op_by_op(gfla, dtype, shape):
     for g, t, name in zip(got, leaves, ("out", "attn_p", "attn_r", "mask_p", "mask_r")):
         w = t.grad.float()
         assert (g - w).abs().max().item() <= tol * max(1e-30, w.abs().max().item()), name
+
+
+@pytest.mark.parametrize("sizes", [(1,), (7, 4096), (33, 1000003, 5), (2049, 16, 777, 8193), (5, 6, 7, 8, 9, 10)])
+def test_convert_many_equals_torch(gfla, sizes):
+    """gfla_convert_multi (one launch for up to four tensors, the bf16 feature path's conversions): bit-identical to
+    torch's .to() both ways -- float32 -> bfloat16 rounds to nearest even, NaN / inf / denormals included; odd sizes and
+    unaligned views take the scalar tail."""
+    from global_flow_local_attention_amd import _lib
+    gen = torch.Generator(device=DEV).manual_seed(len(sizes))
+    src32 = []
+    for i, n in enumerate(sizes):
+        t = torch.randn(n + 1, device=DEV, generator=gen) * (10.0 ** (i - 2))
+        if n >= 5:
+            t[1], t[2], t[3], t[4] = float("nan"), float("inf"), -float("inf"), 1e-40
+        src32.append(t[1:] if i % 2 else t[:n])   # every other tensor starts 4 bytes off a 16-byte boundary
+    want16 = [t.to(torch.bfloat16) for t in src32]
+    got16 = _lib.convert_many(src32 + [None], torch.bfloat16)
+    assert got16[-1] is None
+    for g, w in zip(got16, want16):
+        assert g.dtype == torch.bfloat16 and torch.equal(g.view(torch.int16), w.view(torch.int16))
+    back = _lib.convert_many(want16, torch.float32)
+    for g, w in zip(back, want16):
+        assert g.dtype == torch.float32 and torch.equal(g.view(torch.int32), w.float().view(torch.int32))
+    same = _lib.convert_many(src32[:1], torch.float32)   # nothing to convert: handed back unchanged
+    assert same[0] is src32[0] or torch.equal(same[0], src32[0])

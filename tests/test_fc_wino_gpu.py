@@ -151,3 +151,35 @@ def test_two_job_launch_equals_one_launch_per_half(gfla, k, B, C, H, W):
             assert rel_err(a, b) < 1e-5, name   # order moves the last bits from run to run (1.2e-6 seen)
         else:
             assert torch.equal(a, b), name
+
+
+WGRAD_SWEEP = SWEEP + [(3, 4, 32, 32, 22), (3, 2, 24, 12, 30), (5, 2, 16, 20, 26), (5, 3, 8, 9, 14), (3, 2, 16, 31, 7)]
+
+
+@pytest.mark.parametrize("k,B,C,H,W", WGRAD_SWEEP)
+@pytest.mark.parametrize("is_source", [0, 1])
+@pytest.mark.parametrize("form", ["winograd", "winograd_single_row_units"])
+def test_winograd_domain_weight_gradient_forms(gfla, k, B, C, H, W, is_source, form):
+    """The Winograd-domain weight gradient forced for every k (tuning key 19 = 2; the default takes it for k = 5 and wherever
+    multi-row units apply) with units of whole tile rows on narrow maps (the default) and with round 3's single-row units
+    (key 29 = 1), against float64 on the host."""
+    from global_flow_local_attention_amd import fc_mfma
+    if fc_mfma.resolve_mode(C, H, W, k, 4) != 4:
+        pytest.skip("shape falls back to the direct kernels")
+    x = (randn((B, C, H, W), seed=5) * 1.3).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=6) * 0.05).to(DEV)
+    g = fc_mfma.geometry(H, W, k, is_source)
+    dG = (randn((B, 128, g["Ho"], g["Wo"]), seed=7) * 1e-3).to(DEV)
+    old19, old29 = gfla.set_tuning(19, 2), gfla.set_tuning(29, 1 if form == "winograd_single_row_units" else 0)
+    try:
+        _, _, gw, _ = _run_half(B, C, H, W, k, is_source, 4, x, w0, dG)
+        torch.cuda.synchronize()
+    finally:
+        gfla.set_tuning(19, old19)
+        gfla.set_tuning(29, old29)
+    x64 = x.cpu().double()
+    wh = (w0[:, C:] if is_source else w0[:, :C]).cpu().double().clone().requires_grad_()
+    F.conv2d(F.pad(x64, _pads(k, is_source), mode="replicate"), wh).backward(dG.cpu().double())
+    e_w = rel_err((gw[:, C:] if is_source else gw[:, :C]).cpu(), wh.grad)
+    print("k %d B %d C %d %dx%d half %d %s: grad_w %.2e" % (k, B, C, H, W, is_source, form, e_w))
+    assert e_w <= GRAD_TOL, e_w
