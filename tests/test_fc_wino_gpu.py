@@ -158,11 +158,11 @@ WGRAD_SWEEP = SWEEP + [(3, 4, 32, 32, 22), (3, 2, 24, 12, 30), (5, 2, 16, 20, 26
 
 @pytest.mark.parametrize("k,B,C,H,W", WGRAD_SWEEP)
 @pytest.mark.parametrize("is_source", [0, 1])
-@pytest.mark.parametrize("form", ["winograd", "winograd_single_row_units"])
+@pytest.mark.parametrize("form", ["winograd", "winograd_units_of_16_tiles", "winograd_single_row_units"])
 def test_winograd_domain_weight_gradient_forms(gfla, k, B, C, H, W, is_source, form):
     """The Winograd-domain weight gradient forced for every k (tuning key 19 = 2; the default takes it for k = 5 and wherever
-    multi-row units apply) with units of whole tile rows on narrow maps (the default) and with round 3's single-row units
-    (key 29 = 1), against float64 on the host."""
+    multi-row units apply) with units of whole tile rows on narrow maps (the default: up to 32 tiles; key 29 = 2: up to 16)
+    and with round 3's single-row units (key 29 = 1), against float64 on the host."""
     from global_flow_local_attention_amd import fc_mfma
     if fc_mfma.resolve_mode(C, H, W, k, 4) != 4:
         pytest.skip("shape falls back to the direct kernels")
@@ -170,7 +170,7 @@ def test_winograd_domain_weight_gradient_forms(gfla, k, B, C, H, W, is_source, f
     w0 = (randn((128, 2 * C, k, k), seed=6) * 0.05).to(DEV)
     g = fc_mfma.geometry(H, W, k, is_source)
     dG = (randn((B, 128, g["Ho"], g["Wo"]), seed=7) * 1e-3).to(DEV)
-    old19, old29 = gfla.set_tuning(19, 2), gfla.set_tuning(29, 1 if form == "winograd_single_row_units" else 0)
+    old19, old29 = gfla.set_tuning(19, 2), gfla.set_tuning(29, {"winograd": 0, "winograd_units_of_16_tiles": 2, "winograd_single_row_units": 1}[form])
     try:
         _, _, gw, _ = _run_half(B, C, H, W, k, is_source, 4, x, w0, dG)
         torch.cuda.synchronize()

@@ -2,7 +2,7 @@
 set -uo pipefail
 TAG="${1:-r5a}"; OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 timeout 1200 python -m pytest tests/test_fc_wino_gpu.py tests/test_face_step_gpu.py -x -q -m gpu -k "weight_gradient_forms or convert_many or ragged or two_job" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
-for T in "" "19=2" "19=2,29=1"; do
+for T in "" "29=2" "29=1" "19=1"; do
 timeout 600 python bench.py --tuning "$T" --no-cpu-baseline --no-legs --no-variants > $OUT/bench_$T.json 2> $OUT/bench_$T.err; echo "bench rc=$?"
 python - <<PY
 import json
