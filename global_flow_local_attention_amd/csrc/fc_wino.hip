@@ -43,7 +43,11 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 template <int KS>
 struct Wn {
   static constexpr int M = KS == 5 ? 2 : 4;        // output tile edge
-  static constexpr int PITCH = 80;                 // LDS bytes per raw pixel (16 channels + one 16-byte pad slot)
+  // LDS bytes per raw pixel (16 channels + pad).  k = 5: tiles are 2 pixels = 40 words apart (banks 8 t + channel: two tiles
+  // per bank among the 8 a wave reads).  k = 3: tiles are 4 pixels apart -- 80 words = 16 mod 32 with an 80-byte pitch (four
+  // tiles per bank), 72 words = 8 mod 32 with 72 bytes -- and the smaller pitch is what lets the 32x22 layer's span fit TWO
+  // raw buffers next to the V buffers (the single-buffer staging costs a barrier and an exposed copy per chunk).
+  static constexpr int PITCH = KS == 5 ? 80 : 72;
 };
 
 // ---- the three transforms (points 0, 1, -1, 2, -1/2, inf) -----------------------------------------------------
@@ -214,6 +218,21 @@ static WnGeo wn_geometry(int M, int Wv, int Wp) {
   int rows = g.TW >= kWnTiles ? 2 : (kWnTiles + g.TW - 2) / g.TW + 1;
   if (rows > g.TH) rows = g.TH;
   g.span = ((rows - 1) * m + 6) * Wp + 6;
+  // ... and what the groups of THIS map actually reach: from the first pixel of a group's first tile row to the last pixel of
+  // its last tile's 6 x 6 window (groups start at multiples of 32 tiles, so few of them are the worst case)
+  const int ntiles = g.TH * g.TW;
+  int exact = 0;
+  for (int grp = 0; grp < g.ngroups; ++grp) {
+    const int t0 = grp * kWnTiles, t1 = std::min(t0 + kWnTiles, ntiles) - 1;
+    const int r0 = t0 / g.TW, r1 = t1 / g.TW;
+    int need = 0;
+    for (int r = std::max(r0, r1 - 1); r <= r1; ++r) {   // the last pixel is the last tile's, or the previous row's last tile's
+      const int c = r == r1 ? t1 - r1 * g.TW : g.TW - 1;
+      need = std::max(need, (m * r + 5) * Wp + m * c + 5 + 1 - m * r0 * Wp);
+    }
+    exact = std::max(exact, need);
+  }
+  if (exact < g.span) g.span = exact;
   return g;
 }
 
