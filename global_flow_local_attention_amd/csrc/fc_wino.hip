@@ -1100,17 +1100,23 @@ static WwGeo ww_geometry(int Ho, int Wo, int k) {
   g.TH = (Ho + m - 1) / m;
   g.TW = (Wo + m - 1) / m;
   g.nseg = (g.TW + seg - 1) / seg;
-  // narrow maps: a unit of R whole tile rows (up to 32 tiles = two steps) instead of one mostly empty row (the MR
-  // instantiation; tuning key 29 = 1: off, 2: at most 16 tiles per unit)
+  // Units of R whole tile rows (the MR instantiation) wherever that needs fewer 16-tile steps per sample than one row per
+  // unit: the k = 3 layer at 32x22 has 6 tiles per row (5 rows = 30 of 32), the k = 5 layer at 64x44 has 22 / 24 (one row:
+  // 16 + 6..8 of 32; two rows: 44..48 of 48 -- a quarter fewer steps).  Bounds: the unit's raw rows (the map's own pitch)
+  // within kWwRawMax bytes and the staging registers of the instantiation.  Tuning key 29: 1 = one row per unit (round 3),
+  // 2 = at most 16 tiles per unit.
   g.R = 1;
-  if (g.nseg == 1 && 2 * g.TW <= 32 && tuning(29) != 1) {
-    const int segm = tuning(29) == 2 ? 16 : 32;
+  if (g.nseg == 1 && tuning(29) != 1) {
     const int pfm = (k == 5 ? 4 : 5) * kWnThreads;
-    int R = segm / g.TW;
-    if (R > g.TH) R = g.TH;
-    while (R > 1 && ((m * R + 6 - m) * (m * g.TW + 6 - m) * kWwPitch > kWwRawMax || (m * R + 6 - m) * (m * g.TW + 6 - m) * 4 > pfm))
-      --R;
-    g.R = R < 1 ? 1 : R;
+    const int cap = tuning(29) == 2 ? 16 : 1 << 20;
+    auto steps = [&](int R) { return (g.TH / R) * ((R * g.TW + 15) / 16) + (g.TH % R ? ((g.TH % R) * g.TW + 15) / 16 : 0); };
+    int best = 1, best_steps = steps(1);
+    for (int R = 2; R <= g.TH && R * g.TW <= cap; ++R) {
+      const int px = (m * R + 6 - m) * (m * g.TW + 6 - m);
+      if (px * kWwPitch > kWwRawMax || px * 4 > pfm) break;
+      if (steps(R) <= best_steps) best = R, best_steps = steps(R);
+    }
+    g.R = best;
   }
   g.ups = g.R > 1 ? (g.TH + g.R - 1) / g.R : g.TH * g.nseg;
   return g;
