@@ -1008,58 +1008,14 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
     }
   }
 
-  // C/D layout of the 16x16 MFMA: column (hidden channel) = lane & 15, row (input channel) = 4*(lane >> 4) + r
-  float *o = part + (((int64_t)sp * kWnXi) * cpad + cc * kFcChunk) * kFcHidden + wave * 16 + (lane & 15);
-#pragma unroll
-  for (int q = 0; q < kWnXi; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[((int64_t)q * cpad + 4 * kq + r) * kFcHidden] = acc[q][r];
-}
-
-// conv0.weight.grad[n][c_off + c][i][j] = (G^T (sum_s part[s][.][c][n]) G)[i][j], two passes:
-//   (1) dU[point][c][n] = sum over the splits (one thread per element: 36 * cpad * 128 threads, coalesced along n; a single
-//       pass with one thread per (c, n) doing 36 * nsplit dependent loads took 170 us for 75 MB);
-//   (2) one thread per (c, n): 36 values -> G^T dU G -> k*k outputs in conv0.weight.grad's layout.
-// blockIdx.y = job (the source / target half of a layer: fc_wino_wgrad_reduce2)
-struct WwRedJob {
-  float *part;
-  int nsplit, c_off;
-};
-struct WwRedJobs {
-  WwRedJob j[2];
-};
-__global__ __launch_bounds__(256) void fc_wino_wgrad_sum_kernel(WwRedJobs jobs, int64_t per) {
-  const WwRedJob &J = jobs.j[blockIdx.y];
-  const int nsplit = J.nsplit;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= per) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const float *p = J.part + idx;
-  int s = 0;
-  for (; s + 4 <= nsplit; s += 4) {
-    s0 += p[(int64_t)s * per];
-    s1 += p[(int64_t)(s + 1) * per];
-    s2 += p[(int64_t)(s + 2) * per];
-    s3 += p[(int64_t)(s + 3) * per];
-  }
-  for (; s < nsplit; ++s) s0 += p[(int64_t)s * per];
-  J.part[idx] = (s0 + s1) + (s2 + s3);   // slab 0 <- the sum (element idx is read and written by this thread only)
-}
-
-template <int KS>
-__global__ __launch_bounds__(256) void fc_wino_wgrad_finish_kernel(WwRedJobs jobs, float *__restrict__ gw, int C, int cpad) {
-  const float *__restrict__ dusum = jobs.j[blockIdx.y].part;
-  const int c_off = jobs.j[blockIdx.y].c_off;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (c, n), n fastest: coalesced reads
-  if (idx >= (int64_t)cpad * kFcHidden) return;
-  const int n = (int)(idx & (kFcHidden - 1)), c = (int)(idx >> 7);
-  if (c >= C) return;
-  float du[6][6];
-#pragma unroll
-  for (int q = 0; q < kWnXi; ++q) du[q / 6][q % 6] = dusum[(int64_t)q * cpad * kFcHidden + idx];
+  // C/D layout of the 16x16 MFMA: column (hidden channel) = lane & 15, row (input channel) = 4*(lane >> 4) + r: a lane holds
+  // ALL 36 points of its four (c, n) pairs, so it applies dW = G^T dU G itself and the split's partial leaves as k*k values
+  // per pair instead of 36 -- in the direct kernel's [split][tap][c][n] layout, which fc_wgrad_reduce sums straight into
+  // conv0.weight.grad (k = 3: a quarter of the partial traffic, k = 5: 70 %, and no separate transform pass; the transform
+  // is linear, so doing it per split changes rounding only).
   // G (6 x k): G[a][i] = p_a^i / f_a for a < 5, G[5][k-1] = 1 (wn_g)
-  const float inv_f[5] = {1.f, -1.f / 3.f, 1.f / 3.f, 1.f / 15.f, -16.f / 15.f};
-  const float pt[5] = {0.f, 1.f, -1.f, 2.f, -0.5f};
+  constexpr float inv_f[5] = {1.f, -1.f / 3.f, 1.f / 3.f, 1.f / 15.f, -16.f / 15.f};
+  constexpr float pt[5] = {0.f, 1.f, -1.f, 2.f, -0.5f};
   float G[6][KS];
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
@@ -1072,26 +1028,29 @@ __global__ __launch_bounds__(256) void fc_wino_wgrad_finish_kernel(WwRedJobs job
   }
 #pragma unroll
   for (int i = 0; i < KS; ++i) G[5][i] = i == KS - 1 ? 1.f : 0.f;
-  float tmp[KS][6];
+  float *o = part + (((int64_t)sp * KS * KS) * cpad + cc * kFcChunk) * kFcHidden + wave * 16 + (lane & 15);
 #pragma unroll
-  for (int i = 0; i < KS; ++i)
+  for (int r = 0; r < 4; ++r) {
+    float tmp[KS][6];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      float s = 0.f;
+    for (int i = 0; i < KS; ++i)
 #pragma unroll
-      for (int a = 0; a < 6; ++a) s += G[a][i] * du[a][e];
-      tmp[i][e] = s;
-    }
-  float *g = gw + ((int64_t)n * 2 * C + c_off + c) * KS * KS;
+      for (int e = 0; e < 6; ++e) {
+        float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < KS; ++i)
+        for (int a = 0; a < 6; ++a) sum += G[a][i] * acc[a * 6 + e][r];
+        tmp[i][e] = sum;
+      }
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      float s = 0.f;
+    for (int i = 0; i < KS; ++i)
 #pragma unroll
-      for (int e = 0; e < 6; ++e) s += tmp[i][e] * G[e][j];
-      g[i * KS + j] = s;
-    }
+      for (int j = 0; j < KS; ++j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) sum += tmp[i][e] * G[e][j];
+        o[((int64_t)(i * KS + j) * cpad + 4 * kq + r) * kFcHidden] = sum;
+      }
+  }
 }
 
 static WwGeo ww_geometry(int Ho, int Wo, int k) {
@@ -1195,32 +1154,17 @@ int fc_wino_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k,
   return ww_launch(jobs, njobs, cpad, B, k, stream);
 }
 
-// `part` holds nsplit slabs of 36 * cpad * 128 floats; slab 0 is overwritten with their sum
-static int ww_reduce_launch(const WwRedJobs &jobs, int njobs, float *grad_w0, int C, int cpad, int k, hipStream_t stream) {
-  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
-  const int64_t per = (int64_t)kWnXi * cpad * kFcHidden;
-  fc_wino_wgrad_sum_kernel<<<dim3((unsigned)ceil_div(per, 256), (unsigned)njobs), 256, 0, stream>>>(jobs, per);
-  const dim3 grid((unsigned)ceil_div((int64_t)cpad * kFcHidden, 256), (unsigned)njobs);
-  if (k == 5)
-    fc_wino_wgrad_finish_kernel<5><<<grid, 256, 0, stream>>>(jobs, grad_w0, C, cpad);
-  else
-    fc_wino_wgrad_finish_kernel<3><<<grid, 256, 0, stream>>>(jobs, grad_w0, C, cpad);
-  return launch_status();
-}
-
+// `part` holds nsplit slabs of k*k * cpad * 128 floats (the kernel's epilogue has applied G^T . G): the direct kernel's layout
 int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream) {
-  WwRedJobs jobs;
-  jobs.j[0] = jobs.j[1] = WwRedJob{part, nsplit, c_off};
-  return ww_reduce_launch(jobs, 1, grad_w0, C, cpad, k, stream);
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  return fc_wgrad_reduce(part, nsplit, grad_w0, C, c_off, cpad, k, stream);
 }
 
-// source half (conv0 input channels C..2C-1) and target half (0..C-1): two launches for both instead of four
+// source half (conv0 input channels C..2C-1) and target half (0..C-1) in one launch
 int fc_wino_wgrad_reduce2(float *part_s, int nsplit_s, float *part_t, int nsplit_t, float *grad_w0, int C, int cpad, int k,
                           hipStream_t stream) {
-  WwRedJobs jobs;
-  jobs.j[0] = WwRedJob{part_s, nsplit_s, C};
-  jobs.j[1] = WwRedJob{part_t, nsplit_t, 0};
-  return ww_reduce_launch(jobs, 2, grad_w0, C, cpad, k, stream);
+  if (k != 3 && k != 5) return GFLA_ERR_UNSUPPORTED;
+  return fc_wgrad_reduce2(part_s, nsplit_s, part_t, nsplit_t, grad_w0, C, cpad, k, stream);
 }
 
 }  // namespace gfla
