@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
   float *gt = wt + kPmTile * NQ;                                      // [128][33]
   unsigned short *list = reinterpret_cast<unsigned short *>(gt + kPmChannels * kPmGPitch);  // tiles reaching the band
   __shared__ int s_nlist;
+  // which (K step, 32-column block) pairs of the current tile's W hold a non-zero: a tile's 32 pixels reach a band with a few
+  // of their patch rows only, and a pixel's six columns fall into one or two of the band's blocks -- most pairs are all zero,
+  // and their MFMAs (64 cycles each) are skipped
+  __shared__ unsigned s_mask[3];   // 16 K steps x NB <= 6 blocks = up to 96 bits
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, kh = lane >> 5;
   const int band = blockIdx.x;
   const int64_t b = blockIdx.y;
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
     __syncthreads();  // the previous tile's MFMAs are done with wt / gt
 #pragma unroll
     for (int i = 0; i < NB; ++i) reinterpret_cast<float4 *>(wt)[t + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < 3) s_mask[t] = 0u;
     {
       float *dst = gt + gc * kPmGPitch + gh * 16;
 #pragma unroll
@@ -490,13 +495,21 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
       const int q = peq[m];
       if (q >= 0) {
         const int ty = q >> 16, tx = q & 0xffff;
-        if (ty >= by0 && ty <= by1) wt[pl * NQ + (ty - by0) * Ws + tx] = pev[m];
+        if (ty >= by0 && ty <= by1) {
+          const int col = (ty - by0) * Ws + tx;
+          wt[pl * NQ + col] = pev[m];
+          const int bit = (pl >> 1) * NB + (col >> 5);   // K step of this pixel, block of this column
+          atomicOr(&s_mask[bit >> 5], 1u << (bit & 31));
+        }
       }
     }
     if (li + 1 < nlist)  // in flight during the MFMAs
       pm_fetch(gv, peq, pev, list[li + 1], g_row, g_ok, g_vec, gh, HW, tab, sub, E);
     __syncthreads();
     // D[c][q] += G[c][p] W[p][q]: A = G (rows = channels), B = W (columns = band positions), K = the 32 pixels
+    const unsigned mk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]);   // wave-uniform: scalar registers
+    const unsigned mk1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[1]);
+    const unsigned mk2 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[2]);
     const float *ga = gt + (wave * 32 + l31) * kPmGPitch + kh;
     const float *wb = wt + kh * NQ + l31;
     float a = ga[0];
@@ -515,7 +528,12 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
       for (int j = 0; j < NB; ++j) bq[j] = wb[2 * kn * NQ + 32 * j];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NB; ++j)
+      {
+        const int bit = ks * NB + j;
+        const unsigned w = bit < 32 ? mk0 : (bit < 64 ? mk1 : mk2);
+        if ((w >> (bit & 31)) & 1u) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[j], acc[j], 0, 0, 0);
+      }
     }
   }
   // C/D layout: column = lane & 31 (band position), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
