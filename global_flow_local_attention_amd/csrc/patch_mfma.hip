@@ -419,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
                                                                    int accumulate, const unsigned *__restrict__ stat,
                                                                    unsigned limit) {
   constexpr int NQ = NB * 32;
+  // all-zero (K step, block) pairs are skipped where a band has three or more blocks; with two (64-wide planes: one row per
+  // band) the bookkeeping cost more than the MFMAs it saved (aggregation backward at 64x64: 490 -> 570 us)
+  constexpr bool kSkip = NB >= 3;
   if (pm_stat_total(stat) > limit) return;  // adaptive dispatch: the flow spreads the patches too far, the LDS-atomic kernel runs
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *wt = reinterpret_cast<float *>(gfla_smem);                   // [32][NQ]
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
     __syncthreads();  // the previous tile's MFMAs are done with wt / gt
 #pragma unroll
     for (int i = 0; i < NB; ++i) reinterpret_cast<float4 *>(wt)[t + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < 3) s_mask[t] = 0u;
+    if (kSkip && t < 3) s_mask[t] = 0u;
     {
       float *dst = gt + gc * kPmGPitch + gh * 16;
 #pragma unroll
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
       }
     }
     __syncthreads();  // wt is zero everywhere before any entry lands
+    unsigned blocks = 0;   // the column blocks this thread's entries fall into
 #pragma unroll
     for (int m = 0; m < kPmMaxEntriesPerThread; ++m) {
       const int q = peq[m];
@@ -498,18 +502,32 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
         if (ty >= by0 && ty <= by1) {
           const int col = (ty - by0) * Ws + tx;
           wt[pl * NQ + col] = pev[m];
-          const int bit = (pl >> 1) * NB + (col >> 5);   // K step of this pixel, block of this column
-          atomicOr(&s_mask[bit >> 5], 1u << (bit & 31));
+          blocks |= 1u << (col >> 5);
         }
       }
+    }
+    // 16 consecutive threads hold the two pixels of ONE K step: their blocks are OR-ed across the 16 lanes and published by
+    // one lane (a thread-per-entry atomicOr put ~1000 same-address LDS atomics into every tile pass: at 64-wide planes that
+    // cost more than the skipped MFMAs saved)
+    if constexpr (kSkip) {
+      blocks |= (unsigned)__shfl_xor((int)blocks, 1);
+      blocks |= (unsigned)__shfl_xor((int)blocks, 2);
+      blocks |= (unsigned)__shfl_xor((int)blocks, 4);
+      blocks |= (unsigned)__shfl_xor((int)blocks, 8);
+    }
+    if (kSkip && (t & 15) == 0 && blocks) {
+      const int base = (t >> 4) * NB, w = base >> 5, sh = base & 31;   // bits [base, base + NB) of the mask
+      atomicOr(&s_mask[w], blocks << sh);
+      if (sh + NB > 32) atomicOr(&s_mask[w + 1], blocks >> (32 - sh));
     }
     if (li + 1 < nlist)  // in flight during the MFMAs
       pm_fetch(gv, peq, pev, list[li + 1], g_row, g_ok, g_vec, gh, HW, tab, sub, E);
     __syncthreads();
     // D[c][q] += G[c][p] W[p][q]: A = G (rows = channels), B = W (columns = band positions), K = the 32 pixels
-    const unsigned mk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]);   // wave-uniform: scalar registers
-    const unsigned mk1 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[1]);
-    const unsigned mk2 = (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[2]);
+    // wave-uniform: scalar registers
+    const unsigned mk0 = kSkip ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[0]) : 0xffffffffu;
+    const unsigned mk1 = kSkip ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[1]) : 0xffffffffu;
+    const unsigned mk2 = kSkip ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_mask[2]) : 0xffffffffu;
     const float *ga = gt + (wave * 32 + l31) * kPmGPitch + kh;
     const float *wb = wt + kh * NQ + l31;
     float a = ga[0];
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void patch_scatter_mfma_kernel(const float 
       {
         const int bit = ks * NB + j;
         const unsigned w = bit < 32 ? mk0 : (bit < 64 ? mk1 : mk2);
-        if ((w >> (bit & 31)) & 1u) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[j], acc[j], 0, 0, 0);
+        if (!kSkip || ((w >> (bit & 31)) & 1u)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[j], acc[j], 0, 0, 0);
       }
     }
   }
@@ -569,6 +587,9 @@ struct PmGeo {
 static PmGeo pm_geometry(int64_t B, int64_t C, int Hs, int Ws, int W, int patch) {
   (void)B, (void)C, (void)W, (void)patch;
   int R = tuning(13) > 0 ? tuning(13) : 96 / Ws;
+  // planes wider than 48: one row would be a band of two blocks -- too little work per tile pass, and no skipping of its zero
+  // slices; up to six blocks instead (aggregation backward at 64x64: 501 us with one row per band, 428 with two, 415 with three)
+  if (tuning(13) <= 0 && R < 2) R = (kPmMaxNB * 32) / Ws;
   if (R < 1) R = 1;
   if (R > Hs) R = Hs;
   while (R > 1 && R * Ws > kPmMaxNB * 32) --R;
@@ -579,9 +600,11 @@ static PmGeo pm_geometry(int64_t B, int64_t C, int Hs, int Ws, int W, int patch)
 // tuning key 14: 0 = where it measured faster (pm_auto), 1 = never, 2 = wherever the shape is supported
 static bool pm_auto(bool aggregate, int64_t Ws) {
   if (tuning(14) == 2) return true;
-  // bench shapes, smooth / coherent flows (profiles/r2_scatter_paths.jsonl): aggregation 64x44 378 -> 256 us,
-  // 32x22 95 -> 90..100; resample2d 32x22 178 -> 128, 64x44 328 -> 321 (coherent: 287 -> 343)
-  return aggregate ? Ws >= 32 : Ws <= 24;
+  // bench shapes, smooth / coherent flows, with the all-zero K slices skipped (profiles/r4_scatter_paths_after_zero_skip.jsonl,
+  // r4_scatter_paths_mfma_everywhere.jsonl): aggregation 64x44 376 -> 153 us, 32x22 95 -> 69 (round 3, without the skipping:
+  // 90..100, and the LDS-atomic kernel was kept there); resample2d 32x22 138 -> 91, 64x44 210 (LDS planes fed from tap
+  // records) vs 214 (coherent: 194 vs 229)
+  return aggregate ? true : Ws <= 24;
 }
 
 // dynamic LDS of patch_scatter_mfma_kernel: the W / G tiles plus 2 bytes per flow tile; plain <<<>>> launches get 64 KB

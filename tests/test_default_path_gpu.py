@@ -103,7 +103,9 @@ def test_extractor_attn_bench_shape_rough_flows(gfla, name, B, C, H, W, k, kind)
         # oob: everything behind d/d logits vanishes identically (see rel_err); absolute bounds = tolerance x the scale the
         # tensor has on ordinary flows: 1e-2 per position, 100 for the parameter gradients (sums over 22 528 positions of
         # O(1e-1) softmax gradients x activations of magnitude 8-16)
-        floors = [(1e-2 if n in ("source", "target", "flow") else 100.0) if kind == "oob" else 0.0 for n in NAMES]
+        # (d/d flow is O(1..10) per position on ordinary flows -- bench.py's oracle check sees 6-8 -- so its floor is 1e-1:
+        # the float32 sums over C channels x k*k taps that cancel to zero here leave ~2e-7 of rounding noise)
+        floors = [({"source": 1e-2, "target": 1e-2, "flow": 1e-1}.get(n, 100.0)) if kind == "oob" else 0.0 for n in NAMES]
         errs = [("out", rel_err(out, want_out))] + [(n, rel_err(g, w, fl)) for n, g, w, fl in zip(NAMES, grads, want_grads, floors)]
         print("%s %s mode %d: " % (name, kind, mode) + " ".join("%s %.2e" % e for e in errs))
         for n, e in errs:

@@ -2,7 +2,7 @@
 set -uo pipefail
 TAG="${1:-r5h}"; OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_default_path_gpu.py -x -q -m gpu -k "aggregate or attn or extractor" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest.log
-timeout 600 python tools/opbench.py --only agg_bwd --no-ref > $OUT/opbench.jsonl 2> $OUT/opbench.err
+timeout 600 python tools/opbench.py --only agg_bwd,rs_bwd --no-ref > $OUT/opbench.jsonl 2> $OUT/opbench.err
 python - <<PY
 import json
 for l in open("$OUT/opbench.jsonl"):
