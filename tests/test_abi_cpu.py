@@ -130,3 +130,25 @@ def test_aggregate_forward_table_path_geometry_invariants():
                     assert CH * H * (W // 2) <= 8 * threads                 # word pairs per thread and chunk
                     assert L.gfla_aggregate_fwd_workspace_bytes(B, H, W, k) >= B * ntile * 64 * (((k + 1) * (k + 2) + 4) // 4 * 4) * 4
     assert seen > 300
+
+
+def test_host_helpers_of_the_launch_merges(gfla):
+    """Round 4's host-side helpers, on CPU tensors: the one-allocation zero arena of the attention backward (segments on
+    256-byte boundaries, the requested shapes, None for gradients nobody wants) and convert_many's pass-through rules
+    (anything but a bf16 <-> f32 CUDA conversion goes to torch; None stays None; nothing to convert = the same tensors)."""
+    import torch
+    from global_flow_local_attention_amd import _lib, extractor_attn
+    a, b, c = extractor_attn._zeros_f32(torch.device("cpu"), ((2, 3, 5, 7), True), ((2, 2, 5, 7), False), ((2, 9, 5, 7), True))
+    assert b is None and a.shape == (2, 3, 5, 7) and c.shape == (2, 9, 5, 7)
+    assert a.dtype == c.dtype == torch.float32 and not a.any() and not c.any()
+    assert a.is_contiguous() and c.is_contiguous()
+    assert a.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()          # one allocation ...
+    assert (c.data_ptr() - a.data_ptr()) % 256 == 0 and c.data_ptr() - a.data_ptr() >= a.numel() * 4   # ... aligned segments
+    a.fill_(1.0)
+    assert not c.any()
+    x32, x16 = torch.randn(5, 3), torch.randn(4).to(torch.bfloat16)
+    out = _lib.convert_many([x32, None, x16], torch.float32)
+    assert out[0] is x32 or torch.equal(out[0], x32)
+    assert out[1] is None and out[2].dtype == torch.float32 and torch.equal(out[2], x16.float())
+    back = _lib.convert_many([x32], torch.bfloat16)
+    assert back[0].dtype == torch.bfloat16 and torch.equal(back[0], x32.to(torch.bfloat16))
