@@ -1072,6 +1072,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
     # calls of this process that left the library's own MFMA kernels for rocBLAS / MIOpen (0 unless --fc-impl library)
     from global_flow_local_attention_amd import extractor_attn as _ea
     line["vendor_fallback_calls"] = _ea.vendor_fallback_calls
+    if getattr(args, "one_stream", False):
+        line["streams"] = "--one-stream: warps issued on the attention layers' stream (trace run; the headline uses two)"
     if rank == 0:
         if world == 1 and on_gpu and not args.no_cpu_baseline and not custom:
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
@@ -1102,6 +1104,9 @@ def parse_args(argv=None):
                          "bf16 features; --batch is then clips per GPU.  trainer_step: one TrainerShell.optimize_parameters step "
                          "of the in-repo generator-shaped network (SURVEY 8f row 4 / BASELINE configs[3] per rank)")
     ap.add_argument("--frames", type=int, default=6, help="face_bf16: frames generated per clip")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="pose workload: the loss-side warps on the same stream as the attention layers (for kernel traces whose "
+                         "durations are not inflated by the second stream; the headline is the two-stream step)")
     ap.add_argument("--face-one-stream", action="store_true",
                     help="face_bf16: evaluate attn_p and attn_r of a layer one after the other on one stream (default: two streams)")
     ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4), default=4,
@@ -1147,8 +1152,11 @@ def main():
             return FacePath(args.batch, device, seed=100 + rank, frames=args.frames, dual_stream=not args.face_one_stream)
         if args.workload == "trainer_step":
             return TrainerPath(args.batch, device, seed=100 + rank, fc_mode=fc_mode)
-        return HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
-                       fc_mode=fc_mode, with_losses=args.with_losses)
+        hp_ = HotPath(args.batch, device, seed=100 + rank, vgg_grad=not args.no_vgg_grad, fc_impl=args.fc_impl,
+                      fc_mode=fc_mode, with_losses=args.with_losses)
+        if getattr(args, "one_stream", False):
+            hp_.two_streams = False
+        return hp_
 
     run(args, make_hotpath, lambda: gfla.Resample2d(4, 1, 2), rank, world, device)
     if world > 1:
