@@ -21,18 +21,24 @@ and the reference network code does not exist on the GPU box, so `value` is imag
 HOT PATH, not end-to-end generator throughput.  Inputs are resident in HBM before timing starts.
 
 The FC layers of ExtractorAttn (base_function.py:799-807) run on this library's own f32 MFMA kernels
-(csrc/fc_*.hip): no vendor GEMM / convolution is called anywhere in the step.  `--fc-mode 0` (default, the headline)
-is exact f32 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32); modes 3 / 2 (f16-split operands, f32 accumulation) are
-labelled experiments, reported under "variants".
+(csrc/fc_*.hip): no vendor GEMM / convolution is called anywhere in the step.  `--fc-mode 4` (default, the headline)
+is float32 in the Winograd domain (F(2x2,5x5) / F(4x4,3x3) on v_mfma_f32_16x16x4_f32); mode 0 is the direct f32
+convolution, modes 3 / 2 (f16-split operands, f32 accumulation) are labelled experiments, all reported under "variants".
+
+`python bench.py --gpus N` without a torchrun environment spawns its own N ranks (self_spawn); the torchrun form of
+the contract works as well.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that additionally carries
-  "roofline":     the dominant gfx950 kernel of the step -- an MFMA kernel: algorithmic FLOPs / HIP-event duration
+  "roofline":     the dominant gfx950 kernel of the step -- an MFMA kernel: executed FLOPs / HIP-event duration
                   against the 157.3 TFLOP/s f32 matrix-core peak
   "kernels":      per C-ABI entry point of the step: HIP-event time, algorithmic bytes and FLOPs; and per internal
                   kernel of the FC path (timed alone through gfla_fc_kernel_f32)
-  "oracle_check": forward + input gradients of sample 0 of the timed configuration against the CPU oracle,
-                  asserted before anything is timed (rank 0, N=1)
-  "variants":     the same step with the f16-split FC arithmetic (labelled experiments, not the headline)
+  "oracle_check": forward + input gradients of samples 0 and B-1 of the timed configuration against the CPU oracle;
+                  runs AFTER the timed region (its host threads disturb a timed region started behind it) and aborts
+                  the run on a mismatch (rank 0, N=1)
+  "north_star":   block_extractor + local-attention forward, op by op, against the HBM roofline
+  "legs":         the other BASELINE configs, compact (configs[1] ops, config-3 inference, losses, trainer step, face bf16)
+  "variants":     the same step with the other FC arithmetic modes / stream arrangements (not the headline)
   "cpu_baseline": the reference composition with the CPU oracle kernels on the host cores,
                   timed on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -904,7 +910,7 @@ def timed_steps(step, steps, warmup, barrier, world, device):
     return elapsed
 
 
-def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
+def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, data="synthetic"):
     """Everything after process-group / device setup; `make_hotpath(fc_mode)` builds the per-rank workload.  Split from
     main() so that the N>1 control flow can be exercised on CPU under gloo with a stand-in workload
     (tests/test_dist_cpu.py): a typo must not burn the one multi-GPU hardware run."""
@@ -984,7 +990,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": data,
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
                                "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. both FC layers, "
                                "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)"
@@ -1124,17 +1130,88 @@ def parse_args(argv=None):
     return args
 
 
+def self_spawn(argv):
+    """`python bench.py --gpus N` with no torchrun environment: re-launch this script as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port) and hand back its exit code.
+    The torchrun form of the contract keeps working: it sets WORLD_SIZE, so this is never reached from a rank."""
+    import socket
+    import subprocess
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, GFLA_BENCH_SELF_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print("bench.py: --gpus %d without a torch.distributed.run environment -- spawning %d ranks (port %d)" % (n, n, port),
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+class _ControlFlowStub(object):
+    """GFLA_BENCH_CPU_STUB=1 (test hook, tests/test_dist_cpu.py): a tiny torch model with the HotPath surface so that
+    the launcher, the process group, the barriers, the MAX-over-ranks clock and the rank-0 JSON line of an N>1 run can
+    be executed end to end where there is no GPU.  Its line says so in `data`; it is never a measurement."""
+
+    def __init__(self, rank):
+        torch.manual_seed(1234)
+        self.net = torch.nn.Linear(8, 4)
+        self.x = torch.full((3, 8), float(rank + 1))
+        self.reducer = None
+
+    def params(self):
+        return list(self.net.parameters())
+
+    def step(self, resample, allreduce=True):
+        for p in self.params():
+            p.grad = None
+        if allreduce and self.reducer is None:
+            self.reducer = gdist.GradBucketReducer(self.params())
+        out = resample(self.net(self.x))
+        out.sum().backward()
+        if allreduce:
+            self.reducer.finish()
+        return [out]
+
+
+def main_cpu_stub(args):
+    rank, world, _ = gdist.init_from_env("gloo")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    args.no_cpu_baseline = True
+    line = run(args, lambda mode: _ControlFlowStub(rank), lambda: (lambda t: t * 2.0), rank, world, torch.device("cpu"),
+               on_gpu=False, data="cpu-stub: control flow of the launcher only (GFLA_BENCH_CPU_STUB), not a measurement")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return line
+
+
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 \
+            and not os.environ.get("GFLA_BENCH_SELF_SPAWNED"):
+        raise SystemExit(self_spawn(argv))
+    if os.environ.get("GFLA_BENCH_CPU_STUB") == "1":
+        main_cpu_stub(args)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     # bind the device BEFORE anything touches the GPU or the process group (RCCL communicators are per device)
     local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     # GFLA_DIST_BACKEND / GFLA_DEVICE: test hooks (e.g. two gloo ranks sharing the one GPU of a test box)
     rank, world, _ = gdist.init_from_env(os.environ.get("GFLA_DIST_BACKEND"), device=local)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run, or plain `python bench.py "
+                         "--gpus N`, which spawns the ranks itself)" % (args.gpus, world))
     device = torch.device("cuda", local)
     for kv in filter(None, args.tuning.split(",")):
         gfla.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))

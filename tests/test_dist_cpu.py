@@ -202,3 +202,40 @@ def test_bench_control_flow_world2_gloo():
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
     assert abs(ret[0] - ret[1]) < 1e-6 * ret[0]        # both ranks computed the same MAX-over-ranks time
+
+
+def test_bench_self_spawn_world2_gloo():
+    """`python bench.py --gpus 2` with NO torchrun environment (the shape of the N=1 command with a different N) must not
+    exit with a usage error: it spawns its own ranks under torch.distributed.run and rank 0 prints ONE JSON line with
+    n_gpus = 2.  GFLA_BENCH_CPU_STUB swaps the GPU workload for a stand-in so the launcher runs where there is no GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GFLA_BENCH_CPU_STUB="1", OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert line["dist"]["world_size_seen_by_group"] == 2 and line["dist"]["allreduce_of_rank_ids"] == 3.0
+    assert "cpu-stub" in line["data"]
+
+
+def test_bench_torchrun_form_still_works_gloo():
+    """The contract's own launch form (python -m torch.distributed.run ... bench.py --gpus N) must not spawn again."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GFLA_BENCH_CPU_STUB="1", OMP_NUM_THREADS="1")
+    port = 29300 + os.getpid() % 190
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "spawning" not in res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
