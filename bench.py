@@ -1213,6 +1213,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run, or plain `python bench.py "
                          "--gpus N`, which spawns the ranks itself)" % (args.gpus, world))
     device = torch.device("cuda", local)
+    # a benchmark must never time rocBLAS / MIOpen by accident: configurations the library's MFMA kernels do not take raise
+    # here (the package default, also after install(), is a warning once per module)
+    from global_flow_local_attention_amd import extractor_attn as _ea
+    _ea.VENDOR_FALLBACK = "error"
     for kv in filter(None, args.tuning.split(",")):
         gfla.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     # the step forks work onto side streams (bench.HotPath.step, face_step.DualStreamAttn): gradients of shared leaves then

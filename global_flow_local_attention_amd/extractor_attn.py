@@ -30,8 +30,8 @@ _FUSED_MAX_K = 5  # kernel sizes the fused tail is instantiated for
 # What happens when a module's FC layers are NOT taken by this library's own MFMA kernels (kernel_size other than 3 / 5 --
 # the reference's constructor default is 4, base_function.py:791 --, float64 features, maps whose tiles exceed the LDS)
 # and would run through torch.mm / F.conv2d, i.e. rocBLAS / MIOpen:
-#   "warn"  (package default)  warn once per module, then run the vendor path
-#   "error" (what install() sets unless allow_vendor_fallback=True)  raise: nobody benchmarks or ships the vendor
+#   "warn"  (package default, also after install())  warn once per module, then run the vendor path
+#   "error" (install(strict_mfma=True) / GFLA_STRICT_MFMA=1 / bench.py)  raise: nobody benchmarks or ships the vendor
 #           libraries by accident
 #   "allow" run it silently
 # A module attribute `vendor_fallback` overrides the policy for that module; `module.fc_impl = "library"` is an explicit
@@ -331,7 +331,9 @@ def _bf16_path_ok(self, source, target, flow_field, conv0, act, conv1, last, k):
         return False
     needs_bwd = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or flow_field.requires_grad
                                              or conv0.weight.requires_grad or conv1.weight.requires_grad)
-    return not needs_bwd or _bf16_backward_supported(source.size(2), source.size(3))
+    # the LDS-plane limit belongs to the bf16 aggregate backward only; the default backward (BF16_BACKWARD_F32_AGGREGATE)
+    # goes through gfla_local_attn_aggregate_bwd_ws_f32, which has no such limit
+    return not needs_bwd or BF16_BACKWARD_F32_AGGREGATE or _bf16_backward_supported(source.size(2), source.size(3))
 
 
 class FusedAttnFunction(Function):
@@ -553,7 +555,7 @@ def _fused_attention(self, source, target, flow_field):
                 "(kernel_size 3 / 5, float32 or bfloat16 features, 128 hidden channels, maps whose tiles fit the LDS); its FC "
                 "layers would run through torch.mm / F.conv2d (rocBLAS / MIOpen)" % (k, source.dtype, tuple(source.shape)))
         if policy == "error":
-            raise VendorFallbackError(what + ".  Pass allow_vendor_fallback=True to install(), or set module.vendor_fallback = "
+            raise VendorFallbackError(what + ".  Strict mode is on (install(strict_mfma=True) / GFLA_STRICT_MFMA); set module.vendor_fallback = "
                                       "'allow' / module.fc_impl = 'library', to run it that way")
         if policy == "warn" and not getattr(self, "_library_warned", False):
             # nobody should benchmark the vendor libraries by accident: say once that this module left the MFMA path
@@ -582,20 +584,18 @@ def _fused_attention(self, source, target, flow_field):
     return _aggregate(source_c, flow_c, logits, last, k, link)
 
 
-def _fused_attention_f32_module(self, source, target, flow_field):
-    """_fused_attention on float32 inputs with the module's parameters viewed as float32 (bf16 modules).  The float32
-    twins of the convolutions are built ONCE, on the meta device (no initialisation: the global RNG is not consumed, no
-    host allocation) with every attribute of the original (dilation, groups, padding_mode included); each call only
-    re-derives their weights as differentiable float32 views of the bf16 parameters."""
-    fc = self.fully_connect_layer
-    if fc[0].weight.dtype == torch.float32:
-        return _fused_attention(self, source, target, flow_field)
-    import copy
-    shadow = self.__dict__.get("_f32_shadow")
-    if shadow is None:
-        shadow = copy.copy(self)              # shares nothing mutable we touch; parameters are re-derived below
-        shadow._modules = dict(self._modules)
-        layers = []
+# float32 twins of a bf16 module's convolutions, built once per module ON THE META DEVICE (no initialisation: the global RNG
+# is not consumed, nothing is allocated) and holding NO tensors between calls.  Kept outside the module (weakly keyed) so
+# that deepcopy / pickle / state_dict / DataParallel.replicate of the module never see them.
+import weakref
+_F32_TWINS = weakref.WeakKeyDictionary()
+_STICKY_FLAGS = ("_library_warned", "_attn_warned")
+
+
+def _f32_twins(fc):
+    twins = _F32_TWINS.get(fc)
+    if twins is None:
+        twins = []
         for m in fc:
             if isinstance(m, nn.Conv2d):
                 m32 = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
@@ -603,17 +603,53 @@ def _fused_attention_f32_module(self, source, target, flow_field):
                 del m32.weight
                 if m.bias is not None:
                     del m32.bias
-                layers.append(m32)
+                twins.append(m32)
             else:
+                twins.append(None)
+        _F32_TWINS[fc] = twins
+    return twins
+
+
+def _fused_attention_f32_module(self, source, target, flow_field):
+    """_fused_attention on float32 inputs with the module's parameters viewed as float32 (bf16 modules).  A shallow shadow
+    of the module is built PER CALL (so attributes set at any time -- fc_mode, vendor_fallback, fc_impl, training -- are
+    seen), around cached meta-device twins of the convolutions that carry the differentiable float32 views of the bf16
+    parameters only for the duration of the call: nothing non-leaf stays reachable from the module afterwards (deepcopy
+    for EMA copies works, the last call's autograd graph is not kept alive)."""
+    fc = self.fully_connect_layer
+    if fc[0].weight.dtype == torch.float32:
+        return _fused_attention(self, source, target, flow_field)
+    import copy
+    twins = _f32_twins(fc)
+    # twins are shared by every call on this module: calls from two threads (DataParallel replicas are distinct modules,
+    # so this is two threads driving ONE module) would swap each other's views -- give such a caller private twins
+    private = any(t is not None and "weight" in t.__dict__ for t in twins)
+    if private:
+        twins = [copy.copy(t) if t is not None else None for t in twins]
+    shadow = copy.copy(self)
+    shadow.__dict__ = dict(self.__dict__)
+    shadow._modules = dict(self._modules)
+    try:
+        layers = []
+        for m, m32 in zip(fc, twins):
+            if m32 is None:
                 layers.append(m)
-        shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
-        self.__dict__["_f32_shadow"] = shadow
-    for m, m32 in zip(fc, shadow._modules["fully_connect_layer"]):
-        if isinstance(m, nn.Conv2d):
+                continue
             m32.weight = m.weight.float()      # differentiable float32 views of the bf16 parameters
             if m.bias is not None:
                 m32.bias = m.bias.float()
-    return _fused_attention(shadow, source, target, flow_field)
+            m32.training = m.training
+            layers.append(m32)
+        shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
+        return _fused_attention(shadow, source, target, flow_field)
+    finally:
+        for m32 in twins:
+            if m32 is not None:
+                m32.__dict__.pop("weight", None)
+                m32.__dict__.pop("bias", None)
+        for flag in _STICKY_FLAGS:                # "warned once" must survive the per-call shadow
+            if shadow.__dict__.get(flag) and not self.__dict__.get(flag):
+                self.__dict__[flag] = True
 
 
 def _aggregate(source_c, flow_c, logits, last, k, link):

@@ -32,6 +32,20 @@ class MaskBlendFunction(Function):
 
     @staticmethod
     def forward(ctx, out, attn_p, attn_r, mask_p, mask_r):
+        # the kernel takes raw pointers and B, C, H*W from `out` alone: anything that is not exactly that layout would be
+        # read out of bounds or reinterpreted, so it is refused here (DualStreamAttn falls back to the op-by-op blend)
+        if out.dim() != 4:
+            raise ValueError("MaskBlendFunction: out must be (B, C, H, W), got %s" % (tuple(out.shape),))
+        for name, t in (("attn_p", attn_p), ("attn_r", attn_r)):
+            if t.shape != out.shape:
+                raise ValueError("MaskBlendFunction: %s %s must have the shape of out %s" % (name, tuple(t.shape), tuple(out.shape)))
+        want = (out.size(0), 1, out.size(2), out.size(3))
+        for name, t in (("mask_p", mask_p), ("mask_r", mask_r)):
+            if tuple(t.shape) != want:
+                raise ValueError("MaskBlendFunction: %s %s must be %s (no broadcasting here)" % (name, tuple(t.shape), want))
+        for name, t in (("attn_p", attn_p), ("attn_r", attn_r), ("mask_p", mask_p), ("mask_r", mask_r)):
+            if t.dtype != out.dtype:
+                raise TypeError("MaskBlendFunction: %s is %s, out is %s" % (name, t.dtype, out.dtype))
         _lib.require_gpu(out, attn_p, attn_r, mask_p, mask_r)
         out, attn_p, attn_r = out.contiguous(), attn_p.contiguous(), attn_r.contiguous()
         mask_p, mask_r = mask_p.contiguous(), mask_r.contiguous()
@@ -48,7 +62,7 @@ class MaskBlendFunction(Function):
         out, attn_p, attn_r, mask_p, mask_r = ctx.saved_tensors
         B, C, H, W = out.shape
         need = ctx.needs_input_grad
-        g = g.contiguous()
+        g = g.to(out.dtype).contiguous()
         new = lambda t, wanted: torch.empty_like(t) if wanted else None
         g_out, g_ap, g_ar = new(out, need[0]), new(attn_p, need[1]), new(attn_r, need[2])
         zeros32 = lambda t, wanted: torch.zeros(t.shape, dtype=torch.float32, device=t.device) if wanted else None
@@ -67,19 +81,29 @@ def _blend_fusable(out, attn_p, attn_r, mask_p, mask_r):
             and tuple(mask_p.shape) == (out.size(0), 1, out.size(2), out.size(3)) == tuple(mask_r.shape))
 
 
+_SIDE_STREAMS = {}   # one side stream per device for the whole process (replicas of a DataParallel module each find their own)
+
+
+def side_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class DualStreamAttn(object):
     """out*(1-m_p) + attn_p(prev, out, flow_p)*m_p  +  out*(1-m_r) + attn_r(ref, out, flow_r)*m_r   (generator.py:494-499)
     with the reference-frame half on a side stream.  enabled=False (or CPU tensors) evaluates the same expression
-    sequentially on the current stream -- the parity tests compare the two."""
+    sequentially on the current stream -- the parity tests compare the two.  Holds the two modules it was given and
+    nothing else; face_target_forward builds one per call from the module's CURRENT attributes."""
 
     def __init__(self, attn_p, attn_r, enabled=True, fused_blend=True):
         self.attn_p, self.attn_r, self.enabled, self.fused_blend = attn_p, attn_r, enabled, fused_blend
-        self._side = None
 
-    def side_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+    @staticmethod
+    def side_stream(device):
+        return side_stream(device)
 
     @staticmethod
     def _blend(out, attn, mask):
@@ -115,14 +139,13 @@ def face_target_forward(self, BP, previous_feature_list, reference_feature_list,
     out = self.block0(BP)
     for i in range(self.layers - 1):
         out = getattr(self, "encoder" + str(i))(out)
-    pairs = self.__dict__.setdefault("_gfla_pairs", {})
     counter = 0
     for i in range(self.layers):
         if self.layers - i in self.attn_layer:
-            pair = pairs.get(i)
-            if pair is None:
-                pair = pairs[i] = DualStreamAttn(getattr(self, "attn_p" + str(i)), getattr(self, "attn_r" + str(i)),
-                                                 getattr(self, "dual_stream", True))
+            # resolved on every call: a replica made by nn.DataParallel.replicate (a shallow copy of __dict__) must use ITS
+            # attn modules and device, a module swapped in later must be seen, and `dual_stream` can be toggled any time
+            pair = DualStreamAttn(getattr(self, "attn_p" + str(i)), getattr(self, "attn_r" + str(i)),
+                                  getattr(self, "dual_stream", True))
             out = pair(out, previous_feature_list[i], reference_feature_list[i], flow_fields[2 * counter],
                        flow_fields[2 * counter + 1], masks[2 * counter], masks[2 * counter + 1])
             counter += 1

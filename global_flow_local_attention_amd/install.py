@@ -34,23 +34,32 @@ def _namespace(name, path=None):
     return mod
 
 
-def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, allow_vendor_fallback=False,
-            dual_stream_face=False):
+def install(reference_root=None, fuse_extractor_attn=True, stub_missing=True, allow_vendor_fallback=None,
+            dual_stream_face=False, strict_mfma=None):
     """Alias the three op modules; optionally patch the reference's ExtractorAttn with the fused
     forward.  `reference_root` (a checkout of the reference) is only needed if `model` is not
     already importable.  Returns the reference's `model.networks.base_function` module when it
     could be imported, else None.
 
-    allow_vendor_fallback: an ExtractorAttn configuration this library's own MFMA kernels do not take (kernel_size other
-    than 3 / 5 -- the reference's constructor default is 4 --, float64 features, maps too large for the LDS tiles) would
-    run its FC layers through rocBLAS / MIOpen.  After install() that RAISES (extractor_attn.VendorFallbackError) unless
-    this flag is True (then it warns once per module); the production configurations (kernel_size 2=5, 3=3) never reach it.
+    strict_mfma: an ExtractorAttn configuration this library's own MFMA kernels do not take (kernel_size other than
+    3 / 5 -- the reference's constructor default is 4 --, float64 features and gradcheck, maps too large for the LDS tiles)
+    runs its FC layers through rocBLAS / MIOpen, with ONE warning per module, and every such call is counted
+    (extractor_attn.vendor_fallback_calls): a drop-in must not turn a working reference configuration into a failure.
+    strict_mfma=True (or GFLA_STRICT_MFMA=1 in the environment) makes it RAISE extractor_attn.VendorFallbackError instead
+    -- what a benchmark or a deployment that must not ship vendor kernels by accident wants (bench.py sets it).  None
+    leaves the process-wide policy as it is, so a second install() never flips it silently.  allow_vendor_fallback is the
+    round-4 spelling: True = "warn", False = "error".
 
     dual_stream_face: also patch the reference's FaceTargetNet.forward (generator.py:480-505) so that the two ExtractorAttn
     of an attention layer (previous frame / reference frame) run on two HIP streams (face_step.py).  Imports the
     reference's generator module."""
     from . import extractor_attn as _ea
-    _ea.VENDOR_FALLBACK = "warn" if allow_vendor_fallback else "error"
+    if strict_mfma is None and allow_vendor_fallback is not None:
+        strict_mfma = not allow_vendor_fallback
+    if strict_mfma is None and os.environ.get("GFLA_STRICT_MFMA"):
+        strict_mfma = os.environ["GFLA_STRICT_MFMA"] not in ("0", "")
+    if strict_mfma is not None:
+        _ea.VENDOR_FALLBACK = "error" if strict_mfma else "warn"
     if reference_root:
         # a bare namespace for `model` skips model/__init__.py (which pulls in skimage etc.)
         _namespace("model", os.path.join(reference_root, "model"))

@@ -223,8 +223,8 @@ def test_unsupported_shapes_fall_back(gfla):
 
 def test_vendor_fallback_policy(gfla):
     """A configuration the library's own MFMA kernels do not take (the reference's constructor default kernel_size=4,
-    base_function.py:791) reaches rocBLAS / MIOpen only when that is allowed: the package default warns once, install()
-    turns it into an error unless allow_vendor_fallback=True, a module attribute overrides either; every call that took
+    base_function.py:791) reaches rocBLAS / MIOpen only when that is allowed: the package default warns once,
+    install(strict_mfma=True) turns it into an error, a module attribute overrides either; every call that took
     the vendor path is counted (bench.py reports the count of its run)."""
     import warnings
     from global_flow_local_attention_amd import extractor_attn as ea
@@ -233,7 +233,7 @@ def test_vendor_fallback_policy(gfla):
     f = make_flow("coherent", 1, 6, 6, seed=3).to(DEV)
     old = ea.VENDOR_FALLBACK
     try:
-        ea.VENDOR_FALLBACK = "error"      # what install() sets by default
+        ea.VENDOR_FALLBACK = "error"      # what install(strict_mfma=True) and bench.py set
         n0 = ea.vendor_fallback_calls
         with pytest.raises(ea.VendorFallbackError):
             m(s, t, f)

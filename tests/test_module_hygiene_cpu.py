@@ -1,0 +1,167 @@
+"""Host-side behaviour a drop-in must have (round-4 advisor findings), all on CPU: nothing non-leaf stays attached to a
+module after a call, install() does not flip process-wide policy behind the caller's back, the face model's patched
+forward computes the reference's expression from the module's CURRENT attributes, the fused blend refuses layouts its
+kernel would misread."""
+import copy
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REF = os.path.isdir("/root/reference/model/networks")
+
+
+@pytest.fixture(scope="module")
+def gfla():
+    sys.path.insert(0, ROOT)
+    import global_flow_local_attention_amd as g
+    return g
+
+
+def test_bf16_module_shadow_leaves_nothing_behind(gfla, monkeypatch):
+    """_fused_attention_f32_module (bf16 parameters viewed as float32): after a grad-enabled call the module deep-copies
+    (EMA copies), pickles its state, holds no autograd graph, and attributes set AFTER the first call are seen."""
+    from global_flow_local_attention_amd import extractor_attn as ea
+    seen = []
+
+    def fake(shadow, source, target, flow):
+        fc = shadow.fully_connect_layer
+        assert fc[0].weight.dtype == torch.float32 and fc[0].weight.requires_grad and not fc[0].weight.is_leaf
+        assert fc[0].kernel_size == (3, 3) and fc[0].stride == (3, 3) and isinstance(fc[3], torch.nn.Softmax)
+        seen.append(getattr(shadow, "fc_mode", None))
+        shadow._library_warned = True              # "warned once" flags must reach the real module
+        return None, (fc[0].weight.sum() + fc[2].bias.sum()) * source.sum()
+
+    monkeypatch.setattr(ea, "_fused_attention", fake)
+    m = gfla.ExtractorAttn(4, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(torch.bfloat16)
+    x = torch.ones(1, 4, 5, 5)
+    _, r = ea._fused_attention_f32_module(m, x, x, torch.zeros(1, 2, 5, 5))
+    r.backward()
+    assert m.fully_connect_layer[0].weight.grad is not None            # gradients reach the bf16 parameters
+    assert m.__dict__.get("_library_warned") is True
+    assert "_f32_shadow" not in m.__dict__
+    twins = ea._F32_TWINS[m.fully_connect_layer]
+    assert all(t is None or ("weight" not in t.__dict__ and "bias" not in t.__dict__) for t in twins)
+    clone = copy.deepcopy(m)                                           # raised "Only Tensors created explicitly..." in round 4
+    assert torch.equal(clone.fully_connect_layer[0].weight, m.fully_connect_layer[0].weight)
+    assert list(clone.state_dict().keys()) == list(m.state_dict().keys())
+    m.fc_mode = 0                                                       # set after the first call: must be seen
+    ea._fused_attention_f32_module(m, x, x, torch.zeros(1, 2, 5, 5))
+    assert seen == [None, 0]
+    # an exception inside the call must not leave the views behind either
+    monkeypatch.setattr(ea, "_fused_attention", lambda *a: (_ for _ in ()).throw(RuntimeError("boom")))
+    with pytest.raises(RuntimeError):
+        ea._fused_attention_f32_module(m, x, x, torch.zeros(1, 2, 5, 5))
+    assert all(t is None or "weight" not in t.__dict__ for t in ea._F32_TWINS[m.fully_connect_layer])
+    copy.deepcopy(m)
+
+
+def test_install_policy_is_opt_in_and_sticky(gfla):
+    from global_flow_local_attention_amd import extractor_attn as ea
+    old, env = ea.VENDOR_FALLBACK, os.environ.pop("GFLA_STRICT_MFMA", None)
+    try:
+        ea.VENDOR_FALLBACK = "warn"
+        gfla.install()
+        assert ea.VENDOR_FALLBACK == "warn"            # a drop-in keeps working reference configurations working
+        gfla.install(strict_mfma=True)
+        assert ea.VENDOR_FALLBACK == "error"
+        gfla.install()                                  # a second install() does not flip it back silently
+        assert ea.VENDOR_FALLBACK == "error"
+        gfla.install(strict_mfma=False)
+        assert ea.VENDOR_FALLBACK == "warn"
+        gfla.install(allow_vendor_fallback=False)       # round-4 spelling
+        assert ea.VENDOR_FALLBACK == "error"
+        gfla.install(allow_vendor_fallback=True)
+        assert ea.VENDOR_FALLBACK == "warn"
+        os.environ["GFLA_STRICT_MFMA"] = "1"
+        gfla.install()
+        assert ea.VENDOR_FALLBACK == "error"
+    finally:
+        ea.VENDOR_FALLBACK = old
+        os.environ.pop("GFLA_STRICT_MFMA", None)
+        if env is not None:
+            os.environ["GFLA_STRICT_MFMA"] = env
+
+
+def test_mask_blend_refuses_what_its_kernel_would_misread(gfla):
+    from global_flow_local_attention_amd.face_step import MaskBlendFunction
+    out = torch.zeros(2, 3, 4, 4)
+    m = torch.zeros(2, 1, 4, 4)
+    with pytest.raises(ValueError):
+        MaskBlendFunction.apply(out, out[:, :2], out, m, m)
+    with pytest.raises(ValueError):
+        MaskBlendFunction.apply(out, out, out, torch.zeros(1, 1, 4, 4), m)          # broadcast-shaped mask
+    with pytest.raises(ValueError):
+        MaskBlendFunction.apply(out, out, out, torch.zeros(2, 3, 4, 4), m)
+    with pytest.raises(TypeError):
+        MaskBlendFunction.apply(out, out.double(), out, m, m)
+    with pytest.raises(TypeError):
+        MaskBlendFunction.apply(out, out, out, m.to(torch.bfloat16), m)
+    with pytest.raises(NotImplementedError):                                         # valid layout, but a CPU tensor
+        MaskBlendFunction.apply(out, out, out, m, m)
+
+
+_FACE_CODE = r"""
+import sys, types, copy
+sys.path.insert(0, %r)
+import torch
+import global_flow_local_attention_amd as g
+sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+bf = g.install('/root/reference')
+import model.networks.generator as gen
+reference_forward = gen.FaceTargetNet.forward
+g.install('/root/reference', dual_stream_face=True)
+assert gen.FaceTargetNet.forward.__module__ == 'global_flow_local_attention_amd.face_step'
+# the reference's own constructor, unmodified (the face model's production hyper-parameters, face_model.py)
+net = gen.FaceGenerator(image_nc=3, structure_nc=16, ngf=16, img_f=64, layers=3, num_blocks=2, norm='instance',
+                        activation='LeakyReLU', attn_layer=[2, 3], extractor_kz={'2': 5, '3': 3}, use_spect=False)
+t = net.target
+assert type(t.attn_p0.extractor) is g.BlockExtractor and type(t.attn_r1.reshape) is g.LocalAttnReshape
+
+
+class Stub(torch.nn.Module):          # stands in for ExtractorAttn (GPU only) so the patched forward runs on the host
+    def __init__(self, a):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.tensor(a))
+
+    def forward(self, source, target, flow):
+        return source * self.a + target * flow[:, :1]
+
+
+for i, a in ((0, 0.5), (1, -0.25)):
+    setattr(t, 'attn_p%%d' %% i, Stub(a))
+    setattr(t, 'attn_r%%d' %% i, Stub(a * 3))
+torch.manual_seed(0)
+B = 2
+BP = torch.randn(B, 16, 32, 32)
+feats = [torch.randn(B, 64, 4, 4), torch.randn(B, 32, 8, 8), None]
+flows = [torch.randn(B, 2, 4, 4), torch.randn(B, 2, 4, 4), torch.randn(B, 2, 8, 8), torch.randn(B, 2, 8, 8)]
+masks = [torch.rand(B, 1, 4, 4), torch.rand(B, 1, 4, 4), torch.rand(B, 1, 8, 8), torch.rand(B, 1, 8, 8)]
+t.eval()
+with torch.no_grad():
+    want = reference_forward(t, BP, feats, feats, flows, masks)
+    got = t(BP, feats, feats, flows, masks)
+assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+assert '_gfla_pairs' not in t.__dict__                         # nothing cached on the module (DataParallel.replicate)
+# a module swapped in after the first call is seen, and so is dual_stream
+t.attn_p0 = Stub(2.0)
+t.dual_stream = False
+with torch.no_grad():
+    want2 = reference_forward(t, BP, feats, feats, flows, masks)
+    got2 = t(BP, feats, feats, flows, masks)
+assert torch.allclose(got2, want2, atol=1e-6) and not torch.allclose(got2, got)
+copy.deepcopy(t)
+print('ok')
+"""
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present")
+def test_install_dual_stream_face_patches_the_reference_face_model():
+    """install(dual_stream_face=True): the reference's FaceGenerator builds through its own constructor with this package's
+    ops inside, FaceTargetNet.forward is the patched one, and on the host (stand-in attention modules) it equals the
+    reference's forward (generator.py:480-505) -- also after a module is swapped and dual_stream is toggled."""
+    out = subprocess.run([sys.executable, "-c", _FACE_CODE % ROOT], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
