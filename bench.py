@@ -674,6 +674,130 @@ def op_roofline(device, B=32, iters=20, layers=None, flow_kind="smooth"):
     return out
 
 
+def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "near_integer", "oob"), with_ref=True):
+    """BASELINE configs[1]: block_extractor (k = 3, 5) and resample2d(4, 1) forward / backward on ONE (1, 64, 256, 176) fp32
+    feature map, through the C ABI, HIP-event timed on the launch stream; SURVEY 8(d)'s algorithmic bytes / time / 8 TB/s.
+    Where the real reference kernels are present (oracle/_ref: the checker, never the thing measured) the same call is
+    timed on them (`ref_us`) and, on the smooth flow, compared in float64 (`max_abs_vs_ref`; the north star's bar is 1e-4)."""
+    B, C, H, W = 1, 64, 256, 176
+    ref = None
+    if with_ref:
+        try:
+            from oracle import ref_ext
+            ref = ref_ext if ref_ext.available() else None
+        except Exception:
+            ref = None
+    stream = torch.cuda.current_stream(device)
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3  # us
+
+    def flow_of(kind, seed):
+        g = torch.Generator(device=device).manual_seed(seed)
+        if kind == "zero":
+            return torch.zeros(B, 2, H, W, device=device)
+        if kind == "smooth":
+            return smooth_flow(B, H, W, device, g)
+        n = torch.randn(B, 2, H, W, device=device, generator=g)
+        if kind == "wild":
+            return n * 8
+        if kind == "integer":
+            return torch.round(n * 3)
+        if kind == "near_integer":
+            sign = torch.where(torch.randn(B, 2, H, W, device=device, generator=g) > 0, 1.0, -1.0)
+            return (torch.round(n * 3) + sign * 2.0 ** -22).contiguous()
+        f = n * 2                      # oob: every sample far outside the map, through all four sides
+        f[:, 0] += 1000.0
+        f[:, 1] -= 1000.0
+        return f.contiguous()
+
+    rows = []
+
+    def emit(op, kind, entry, plain, us, ref_us, err):
+        nbytes = algorithmic_bytes(entry, plain)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        row = {"op": op, "flow": kind, "alg_MB": round(nbytes / 1e6, 2), "us": round(us, 1), "GBps": round(gbs, 1),
+               "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if ref_us is not None:
+            row["ref_us"] = round(ref_us, 1)
+            row["speedup_vs_ref"] = round(ref_us / us, 2)
+        if err is not None:
+            row["max_abs_vs_ref"] = float("%.3g" % err)
+        rows.append(row)
+
+    gen = torch.Generator(device=device).manual_seed(42)
+    src = torch.randn(B, C, H, W, device=device, generator=gen)
+    for k in (3, 5):
+        out = torch.empty(B, C, k * H, k * W, device=device)
+        gout = torch.randn(B, C, k * H, k * W, device=device, generator=gen)
+        for kind in flows:
+            flow = flow_of(kind, 7)
+            gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
+            fwd = lambda: _lib.call("gfla_block_extractor_fwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(out), B, C, H, W, H, W, k)
+            bwd = lambda: _lib.call("gfla_block_extractor_bwd_f32", src, _lib.ptr(src), _lib.ptr(flow), _lib.ptr(gout), _lib.ptr(gs),
+                                    _lib.ptr(gf), B, C, H, W, H, W, k)
+            t_f, t_b = timed(fwd, iters), timed(bwd, max(3, iters // 2))
+            r_f = r_b = e_f = e_b = None
+            if ref is not None:
+                m = ref._mod("block_extractor_cuda")
+                ro, rgs, rgf = torch.empty_like(out), torch.zeros_like(src), torch.zeros_like(flow)
+                r_f = timed(lambda: m.forward(src, flow, ro, k), 5)
+                r_b = timed(lambda: m.backward(src, flow, gout, rgs, rgf, k), 2)
+                if kind == "smooth":
+                    sd, fd = src.double(), flow.double()
+                    e_f = (out.double() - ref.block_extractor_fwd(sd, fd, k)).abs().max().item()
+                    gs.zero_(), gf.zero_()
+                    bwd()
+                    ws, wf = ref.block_extractor_bwd(sd, fd, gout.double(), k)
+                    e_b = max((gs.double() - ws).abs().max().item(), (gf.double() - wf).abs().max().item())
+                    del sd, fd, ws, wf
+                del ro, rgs, rgf
+            emit("block_extractor_fwd k%d" % k, kind, "gfla_block_extractor_fwd_f32", (1, 1, 1, B, C, H, W, H, W, k), t_f, r_f, e_f)
+            emit("block_extractor_bwd k%d" % k, kind, "gfla_block_extractor_bwd_f32", (1, 1, 1, 1, 1, B, C, H, W, H, W, k), t_b, r_b, e_b)
+        del out, gout
+        torch.cuda.empty_cache()
+    gout = torch.randn(B, C, H, W, device=device, generator=gen)
+    out = torch.empty_like(src)
+    for kind in flows:
+        i2 = torch.cat((flow_of(kind, 9), torch.full((B, 1, H, W), 2.0, device=device)), 1).contiguous()
+        g1, g2 = torch.zeros_like(src), torch.zeros_like(i2)
+        fwd = lambda: _lib.call("gfla_resample2d_fwd_f32", src, _lib.ptr(src), _lib.ptr(i2), _lib.ptr(out), B, C, H, W, H, W, 4, 1)
+        bwd = lambda: _lib.call("gfla_resample2d_bwd_f32", src, _lib.ptr(src), _lib.ptr(i2), _lib.ptr(gout), _lib.ptr(g1), _lib.ptr(g2),
+                                B, C, H, W, H, W, 4, 1, 1)
+        t_f, t_b = timed(fwd, iters), timed(bwd, max(3, iters // 2))
+        r_f = r_b = e_f = e_b = None
+        if ref is not None:
+            m = ref._mod("resample2d_cuda")
+            ro, r1, r2 = torch.empty_like(out), torch.zeros_like(src), torch.zeros_like(i2)
+            r_f = timed(lambda: m.forward(src, i2, ro, 4, 1), 5)
+            r_b = timed(lambda: m.backward(src, i2, gout, r1, r2, 4, 1), 2)
+            if kind == "smooth":
+                e_f = (out.double() - ref.resample2d_fwd(src.double(), i2.double(), 4, 1)).abs().max().item()
+                g1.zero_(), g2.zero_()
+                bwd()
+                w1, w2 = ref.resample2d_bwd(src.double(), i2.double(), gout.double(), 4, 1)
+                e_b = max((g1.double() - w1).abs().max().item(), (g2.double() - w2).abs().max().item())
+                del w1, w2
+            del ro, r1, r2
+        emit("resample2d_fwd k4", kind, "gfla_resample2d_fwd_f32", (1, 1, 1, B, C, H, W, H, W, 4, 1), t_f, r_f, e_f)
+        emit("resample2d_bwd k4", kind, "gfla_resample2d_bwd_f32", (1, 1, 1, 1, 1, B, C, H, W, H, W, 4, 1, 1), t_b, r_b, e_b)
+    torch.cuda.empty_cache()
+    slower = [r for r in rows if "ref_us" in r and r["us"] > r["ref_us"]]
+    return {"what": "BASELINE configs[1]: block_extractor (k 3 / 5) + resample2d(4,1) forward and backward (both gradients) on one "
+                    "(1,64,256,176) fp32 map through the C ABI; HIP events; algorithmic bytes (SURVEY 8d) / time / 8 TB/s; ref_us = the "
+                    "reference's own kernels (oracle/_ref) on the same inputs in the same process" + ("" if ref is not None else
+                                                                                                   " -- not built on this box"),
+            "dims": [B, C, H, W], "rows": rows, "slower_than_reference_on": [[r["op"], r["flow"]] for r in slower]}
+
+
 def oracle_check(hp, resample, tol=1e-4):
     """Samples 0 and B-1 of the timed configuration through the reference composition with the CPU oracle kernels (the
     checker only): forward outputs and the gradients of source, target, flow and the warped VGG features of those samples
@@ -780,6 +904,11 @@ def extra_legs(args, device):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
+    # configs[1]: the standalone ops on one (1,64,256,176) map, every flow kind, next to the reference's kernels
+    try:
+        legs["config2_ops"] = config2_ops(device)
+    except Exception as exc:   # (the checker's build is optional; the timing itself must not be)
+        legs["config2_ops"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     # configs[2]: ExtractorAttn forward only (eval, no_grad) at the attention-layer shapes of a 256x256 image, batch 32
     from global_flow_local_attention_amd import fc_mfma
     for mode in (4, 0):

@@ -216,9 +216,11 @@ def set_tuning(key, value):
     return lib().gfla_set_tuning(int(key), int(value))
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
-PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_BE_FWD_PIX, PATH_COUNT = 0, 1, 2, 7, 12, 13
+PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_BE_FWD_PIX = 0, 1, 2, 7, 12
+# round 5: the big-plane kernels (few planes, each beyond the LDS budget; csrc/tile_map.h)
+PATH_BE_FWD_GPIX, PATH_BE_BWD_TILE, PATH_RS_FWD_BIG, PATH_RS_BWD1_TILE, PATH_RS_BWD2_BIG, PATH_COUNT = 13, 14, 15, 16, 17, 18
 
 
 def path_count(path):

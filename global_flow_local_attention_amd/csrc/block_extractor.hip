@@ -18,6 +18,7 @@
 #include "be_bwd_lds.h"
 #include "be_fwd_pix.h"
 #include "be_fwd_wrow.h"
+#include "be_tile.h"
 
 namespace gfla {
 
@@ -223,6 +224,19 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
   // TB/s), wider ones to the lane-per-pixel kernel (5.2 TB/s when its output rows are whole 128-byte lines, 3.8-4.7
   // otherwise), planes beyond the LDS budget to round 1's windowed kernel
   if constexpr (sizeof(T) >= 4) {
+    // few planes, each far beyond the LDS budget (BASELINE configs[1]): parallelism from pixel blocks, not planes (be_tile.h)
+    if (variant == 0 && k >= 2 && k <= 5 && big_plane_regime(B, C, Hs * Ws * (int64_t)sizeof(A), lds_budget())) {
+      bool done = false;
+      int st = GFLA_OK;
+      switch (k) {
+        case 2: st = launch_fwd_gpix<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 3: st = launch_fwd_gpix<T, 3>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 4: st = launch_fwd_gpix<T, 4>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        default: st = launch_fwd_gpix<T, 5>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+      }
+      if (done) note_path(GFLA_PATH_BE_FWD_GPIX);
+      if (done || st != GFLA_OK) return st;
+    }
     // small output planes (<= 32 KB: a whole plane is a few hundred lines that one workgroup writes within microseconds)
     // stream slightly faster from the lane-per-pixel kernel: (32,256,32,22) k=3 40 us against 41-45
     const bool small_plane = (int64_t)k * k * Hf * Wf * (int64_t)sizeof(T) <= 32 * 1024 && Wf <= 64;
@@ -417,6 +431,13 @@ static int launch_bwd_pix(const T *src, const T *flow, const T *gout, T *gsrc, t
                           int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
                           hipStream_t stream) {
   constexpr bool kBf16 = sizeof(T) == 2;
+  if (tuning(2) != 1 && !kBf16 &&
+      big_plane_regime(B, C, Hs * Ws * (int64_t)(sizeof(lds_acc_t) + sizeof(typename Num<T>::acc)), lds_budget())) {
+    bool done = false;   // few planes far beyond the LDS budget: flow-pixel tiles with bounding-box windows (be_tile.h)
+    int st = launch_be_bwd_tile<T, K>(src, flow, gout, gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);
+    if (done) note_path(GFLA_PATH_BE_BWD_TILE);
+    if (done || st != GFLA_OK) return st;
+  }
   if (tuning(2) != 1 || kBf16) {
     bool done = false;
     int st = launch_be_bwd_lds<T, K>(kGoutTensor, src, flow, gout, static_cast<const T *>(nullptr), gsrc, gflow, B, C, Hs, Ws, Hf, Wf, stream, &done);

@@ -16,6 +16,7 @@
 #include "lds_plane.h"
 #include "rs_taps.h"
 #include "patch_mfma.h"
+#include "tile_map.h"
 
 namespace gfla {
 
@@ -475,6 +476,174 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
   }
 }
 
+
+// ---- few planes, each beyond the LDS budget (BASELINE configs[1]; tile_map.h) --------------------------------------------
+// forward and d/d input2 are GATHERS: thread <-> pixel, a chunk of `cpt` channels per thread with one tap setup (single-
+// precision exps), taps read from global memory; blocks XCD-swizzled over (batch, pixel block) with a pixel block's
+// channel chunks adjacent.  (rs_fwd_kernel / rs_bwd2_kernel above are the same bodies with one thread per (pixel, channel
+// chunk) chosen for many planes; at B*C = 64 that geometry recomputed the taps for every channel.)
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_fwd_big_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
+                                                           T *__restrict__ out, int C, int Hi, int Wi, int H, int W, int dil,
+                                                           int cpt, int ncg, int nsp, int64_t nwg) {
+  using A = typename Num<T>::acc;
+  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
+  const int cg = (int)(v % ncg);
+  const int64_t rest = v / ncg;
+  const int sp = (int)(rest % nsp), b = (int)(rest / nsp);
+  const int HW = H * W;
+  const int p = sp * kBlock + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / W, x = p - y * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + p;
+  Taps<A, KH> t;
+  t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  rs_fwd_pixel<T, T, KH, A>(t, in1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, out + ((int64_t)b * C + c0) * HW + p, HW,
+                            c1 - c0);
+}
+
+template <typename T, int KH>
+__global__ __launch_bounds__(kBlock) void rs_bwd2_big_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
+                                                            const T *__restrict__ gout, T *__restrict__ gin2, int C, int Hi,
+                                                            int Wi, int H, int W, int dil, int cpt, int ncg, int nsp,
+                                                            int64_t nwg) {
+  using A = typename Num<T>::acc;
+  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
+  const int cg = (int)(v % ncg);
+  const int64_t rest = v / ncg;
+  const int sp = (int)(rest % nsp), b = (int)(rest / nsp);
+  const int HW = H * W;
+  const int p = sp * kBlock + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / W, x = p - y * W;
+  const T *i2 = in2 + (int64_t)b * 3 * HW + p;
+  Taps<A, KH> t;
+  t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
+  const int64_t plane_sz = (int64_t)Hi * Wi;
+  A rx, ry, rs;
+  rs_bwd2_pixel<T, T, KH, A>(t, in1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, gout + ((int64_t)b * C + c0) * HW + p, HW,
+                             c1 - c0, rx, ry, rs);
+  T *o = gin2 + (int64_t)b * 3 * HW + p;
+  if (ncg == 1) {  // sole writer of this pixel
+    o[0] = Num<T>::from(Num<T>::ld(o) + rx);
+    o[HW] = Num<T>::from(Num<T>::ld(o + HW) + ry);
+    o[2 * HW] = Num<T>::from(Num<T>::ld(o + 2 * HW) + rs);
+  } else {
+    atomic_add(o, (T)rx);
+    atomic_add(o + HW, (T)ry);
+    atomic_add(o + 2 * HW, (T)rs);
+  }
+}
+
+// d/d input1 is a SCATTER: workgroup = (tile of th x tw pixels, G channels), one pixel per thread with its taps kept in
+// registers.  The gradient planes are accumulated in an LDS window = the bounding box of the tile's taps (from the flow, on
+// the device), 64-bit fixed point for float (ds_add_u64, order-independent; lds_plane.h) / double planes for double, in as
+// many channel rounds as the window allows, and leave through one atomic per touched element.  A window that does not
+// hold a single channel: global atomics for that tile.
+template <typename T, int KH, bool FIX>
+__global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__ in2, const T *__restrict__ gout,
+                                                          T *__restrict__ gin1, int C, int Hi, int Wi, int H, int W, int dil,
+                                                          int trunc, int th, int tw, int ntx, int nty, int G, int ngroups,
+                                                          int lds_elems, int64_t nwg) {
+  using A = typename Num<T>::acc;
+  using PT = typename std::conditional<FIX, lds_fix_t, lds_acc_t>::type;
+  static_assert(!FIX || std::is_same<A, float>::value, "fixed-point planes: float scatter only");
+  constexpr int N = 2 * KH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  PT *planes = reinterpret_cast<PT *>(gfla_smem);
+  __shared__ int s_box[4];
+  __shared__ unsigned s_amax;
+  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
+  const int g = (int)(v % ngroups);
+  const int64_t rest = v / ngroups;
+  const int tile = (int)(rest % ((int64_t)ntx * nty)), b = (int)(rest / ((int64_t)ntx * nty));
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const int c0 = g * G, gc = min(G, C - c0);
+  const int ly = threadIdx.x / tw, lx = threadIdx.x - ly * tw;
+  const int y = ty * th + ly, x = tx * tw + lx;
+  const bool active = ly < th && y < H && x < W;
+  const int HW = H * W, plane_sz = Hi * Wi;
+  const int p = active ? y * W + x : 0;
+  box_init(s_box);
+  if (threadIdx.x == 0) s_amax = 0;
+  __syncthreads();
+  // ---- taps of this thread's pixel (rows as INDICES: pitch 1), kept for all channel rounds
+  int row[N], col[N];
+  A qy[N], wx[N];
+  {
+    const T *i2 = in2 + (int64_t)b * 3 * HW + p;
+    Taps<A, KH> t;
+    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, (trunc & 1) != 0, 1);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      row[r] = t.row_off(r);
+      col[r] = t.col_off(r);
+      qy[r] = (A)safe_div<A>(t.row_w(r), t.sum);
+      wx[r] = t.col_w(r);
+    }
+  }
+  // clamped taps are monotone in position order: the first and the last bound the pixel's reach
+  box_reduce(s_box, active ? row[0] : 0x7fffffff, active ? col[0] : 0x7fffffff, active ? row[N - 1] : -1, active ? col[N - 1] : -1);
+  const T *go0 = gout + ((int64_t)b * C + c0) * HW + p;
+  T *gin0 = gin1 + ((int64_t)b * C + c0) * plane_sz;
+  FixScale fix{1.f, 1.0, true};
+  if constexpr (FIX) {  // every contribution is one of these gradients times weights <= 1: their maximum sets the scale
+    unsigned m = 0;
+    if (active)
+      for (int c = 0; c < gc; ++c) m = max(m, __float_as_uint(fabsf(Num<T>::ld(go0 + (int64_t)c * HW))));
+    fix = fix_scale(block_umax(m, &s_amax));   // (contains the barrier that also publishes the box)
+  } else {
+    __syncthreads();
+  }
+  const int ymin = s_box[0], xmin = s_box[1];
+  const int rows = s_box[2] - ymin + 1, cols = s_box[3] - xmin + 1;
+  const int win = rows * cols;
+  const int g_fit = min(gc, lds_elems / max(win, 1));
+  if (g_fit == 0) {
+    if (active) {
+      int ro[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) ro[r] = row[r] * Wi;
+      rs_bwd1_apply<T, T, N, A, GlobalPlane>(ro, col, qy, wx, go0, HW, gin0, plane_sz, gc, (A)1);
+    }
+    return;
+  }
+  int ro[N], co[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    ro[r] = (row[r] - ymin) * cols;
+    co[r] = col[r] - xmin;
+  }
+  for (int cb = 0; cb < gc; cb += g_fit) {
+    const int n = min(g_fit, gc - cb);
+    zero_planes<PT>(planes, n * win);
+    __syncthreads();
+    if (active) {
+      const T *go = go0 + (int64_t)cb * HW;
+      if constexpr (FIX)
+        rs_bwd1_apply_fix<T, N>(ro, co, qy, wx, Num<T>::ld(go), go, HW, planes, win, n, fix.up);
+      else
+        rs_bwd1_apply<T, PT, N, A, LdsPlane>(ro, co, qy, wx, go, HW, planes, win, n, (A)1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * win; i += blockDim.x) {
+      const PT raw = planes[i];
+      if (raw != 0) {
+        const int c = i / win, e = i - c * win;
+        const int wr = e / cols, wc = e - wr * cols;
+        double val;
+        if constexpr (FIX) val = fix.finite ? (double)raw * fix.down : __longlong_as_double(0x7ff8000000000000ll);
+        else val = raw;
+        atomic_add(gin0 + (int64_t)(cb + c) * plane_sz + (ymin + wr) * Wi + xmin + wc, (T)val);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 struct Geo {
   int cpt, ncg, sp_blocks;
   int64_t blocks;
@@ -488,6 +657,14 @@ static Geo geometry(int64_t B, int64_t C, int64_t H, int64_t W, int max_cpt, int
   g.ncg = (int)ceil_div(C, cpt);
   g.blocks = (int64_t)g.sp_blocks * g.ncg * B;
   return g;
+}
+
+// big-plane gathers: channels per thread -- all of them unless that leaves fewer than `want` waves (tuning key 33)
+static int big_cpt(int64_t B, int64_t C, int64_t nsp, int64_t want) {
+  if (tuning(33) > 0) return tuning(33) < C ? tuning(33) : (int)C;
+  int64_t cpt = C;
+  while (cpt > 1 && B * nsp * (kBlock / 64) * ceil_div(C, cpt) < want) cpt = ceil_div(cpt, 2);
+  return (int)cpt;
 }
 
 template <typename T>
@@ -516,6 +693,17 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   if (!out) return GFLA_ERR_NULL_POINTER;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
+  if (tuning(6) != 1 && big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(A), lds_budget())) {
+    // few planes far beyond the LDS budget (BASELINE configs[1]): one tap setup per pixel and chunk of channels, global gathers
+    const int64_t nsp = ceil_div(H * W, kBlock);
+    const int cpt = big_cpt(B, C, nsp, 20 * kNumCU);
+    const int64_t ncg = ceil_div(C, cpt), nwg = B * nsp * ncg;
+    if (nwg <= 0x7fffffffLL) {
+      GFLA_KH_SWITCH(k / 2, rs_fwd_big_kernel<T, KH><<<dim3((unsigned)nwg), dim3(kBlock), 0, stream>>>(in1, in2, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, cpt, (int)ncg, (int)nsp, nwg));
+      note_path(GFLA_PATH_RS_FWD_BIG);
+      return launch_status();
+    }
+  }
   if (tuning(6) != 1) {
     PlaneGeo pg = lds_geometry(Hi, Wi, sizeof(A), B, C, H, W, (k - 1) * dil + 1, 1);
     if (pg.G > 0) {
@@ -543,6 +731,41 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   using A = typename Num<T>::acc;
   constexpr bool kBf16 = sizeof(T) == 2;
+  if constexpr (!kBf16) {
+    // few planes far beyond the LDS budget (BASELINE configs[1]; tile_map.h).  Not behind the matrix-core product's
+    // device-side switch (skip_stat): the _ws entry point does not try the product in this regime.
+    if (tuning(6) != 1 && !skip_stat && Hi * Wi <= 0x3fffffffLL &&
+        big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(lds_acc_t), lds_budget())) {
+      if (gin1) {
+        if (trunc & 2) {  // the tiles accumulate with atomics: zero-fill here
+          if (hipMemsetAsync(gin1, 0, (size_t)(B * C * Hi * Wi) * sizeof(T), stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+          trunc &= ~2;
+        }
+        const TileGeo tg = tile_geometry(H, W);
+        int G = tuning(34) > 0 ? tuning(34) : 4;
+        while (G > 1 && B * tg.nty * tg.ntx * ceil_div(C, G) < 3 * kNumCU) G /= 2;
+        if (G > C) G = (int)C;
+        const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+        if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+        const unsigned lds_bytes = (unsigned)lds_budget();
+        constexpr bool FIX = std::is_same<A, float>::value;
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg));
+        note_path(GFLA_PATH_RS_BWD1_TILE);
+        st = launch_status();
+        if (st != GFLA_OK) return st;
+      }
+      if (gin2) {
+        const int64_t nsp = ceil_div(H * W, kBlock);
+        const int cpt = big_cpt(B, C, nsp, 20 * kNumCU);
+        const int64_t ncg = ceil_div(C, cpt), nwg = B * nsp * ncg;
+        if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+        GFLA_KH_SWITCH(k / 2, rs_bwd2_big_kernel<T, KH><<<dim3((unsigned)nwg), dim3(kBlock), 0, stream>>>(in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, cpt, (int)ncg, (int)nsp, nwg));
+        note_path(GFLA_PATH_RS_BWD2_BIG);
+        st = launch_status();
+      }
+      return st;
+    }
+  }
   // double scatter planes.  bf16 storage: whole planes, one owner each (the flush is a plain read-modify-write)
   PlaneGeo pg1 = kBf16 ? plane_geometry(Hi * Wi, sizeof(lds_acc_t), B, C, H * W, false)
                        : lds_geometry(Hi, Wi, sizeof(lds_acc_t), B, C, H, W, (k - 1) * dil + 1);
@@ -657,7 +880,8 @@ int gfla_resample2d_bwd_ws_f32(const float *a, const float *b, const float *go, 
                                int trunc, gfla_stream_t st) {
   const unsigned *skip_stat = nullptr;
   unsigned skip_limit = 0;
-  if (g1 && workspace && d == 1 && gfla::tuning(6) != 1) {
+  const bool big = gfla::tuning(6) != 1 && gfla::big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(gfla::lds_acc_t), gfla::lds_budget());
+  if (g1 && workspace && d == 1 && gfla::tuning(6) != 1 && !big) {
     int rc = gfla::check<float>(a, b, B, C, Hi, Wi, H, W, k, d);
     if (rc != GFLA_OK) return rc;
     if (!go) return GFLA_ERR_NULL_POINTER;

@@ -52,9 +52,12 @@ struct Taps {
 
   // floor_alpha: fractional part from floor (forward, input2 gradient) or from int() truncation
   // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
+  // pitch: what a row index is multiplied by in yT / yB (the plane's row pitch Wi by default; the tile kernels pass 1 and
+  // place the rows in their own window)
   template <bool FAST = false>
   __device__ __forceinline__ void init(A dx, A dy, A sg, int x, int y, int Hi, int Wi, int dil,
-                                       bool trunc_alpha) {
+                                       bool trunc_alpha, int pitch = -1) {
+    if (pitch < 0) pitch = Wi;
     sigma = sg;
     const A xf = (A)x + dx, yf = (A)y + dy;  // :52-53
     const A fxf = floor_t<A>(xf), fyf = floor_t<A>(yf);
@@ -65,8 +68,8 @@ struct Taps {
     sum = 0;
 #pragma unroll
     for (int f = 0; f < KH; ++f) {
-      yT[f] = clampi((int)(fyf - (A)(f * dil)), 0, Hi - 1) * Wi;         // :62-63
-      yB[f] = clampi((int)(fyf + (A)((f + 1) * dil)), 0, Hi - 1) * Wi;
+      yT[f] = clampi((int)(fyf - (A)(f * dil)), 0, Hi - 1) * pitch;      // :62-63
+      yB[f] = clampi((int)(fyf + (A)((f + 1) * dil)), 0, Hi - 1) * pitch;
       xL[f] = clampi((int)(fxf - (A)(f * dil)), 0, Wi - 1);              // :66-67
       xR[f] = clampi((int)(fxf + (A)((f + 1) * dil)), 0, Wi - 1);
       xLd[f] = (A)(f * dil) + alpha;                                     // :70-73

@@ -1,0 +1,85 @@
+// Building blocks of the "big plane" kernels (round 5): feature planes far beyond the LDS budget and FEW of them --
+// BASELINE configs[1], (1, 64, 256, 176): 64 planes of 180 KB on 256 CUs.  The planes-in-LDS kernels get their parallelism
+// from (batch x channel group) workgroups, each owning whole planes; here it has to come from SPACE:
+//   * a workgroup owns a tile / a run of flow pixels and walks many channels with ONE per-pixel setup (at B*C = 64 the
+//     windowed round-1 kernels spent 3/4 of their instructions recomputing tap geometry per group of 2-4 channels);
+//   * workgroup -> tile mapping is XCD-aware: block b runs on XCD b % 8 (MI355X_MICROARCH.md, observed), so the blocks of
+//     one XCD are given a CONTIGUOUS range of the (batch, tile) order with the channel groups of a tile adjacent -- each of
+//     the eight L2s then holds one eighth of every plane (plus the flow's reach) instead of all of every plane;
+//   * gathers read global memory directly (lanes = consecutive pixels: a wave's tap loads fall into 2-3 cache lines for any
+//     flow that is locally coherent, and L1 / the XCD's L2 serve the overlap between taps); scatters accumulate in an LDS
+//     window that is the BOUNDING BOX of what the tile's pixels actually reach (computed on the device from the flow, so a
+//     smooth flow of any magnitude stays in LDS), processed in as many channel rounds as the box allows, and leave through
+//     one float atomic per window element; a box too large for a single channel takes global atomics for that tile only.
+#pragma once
+
+#include "gfla_common.h"
+
+namespace gfla {
+
+// Bijective XCD remap (cdna_hip_programming.md T1): the blocks that land on XCD x get the x-th contiguous share of
+// [0, nwg).  Correct for any nwg; a wrong placement guess only costs speed.
+__device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
+  const int64_t q = nwg / kNumXCD, r = nwg % kNumXCD, xcd = bid % kNumXCD;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / kNumXCD;
+}
+
+// Bounding box of a tile's taps, reduced over the workgroup: box = {ymin, xmin, ymax, xmax} in LDS, initialised by
+// box_init() before a barrier.  Inactive lanes pass an empty range.
+__device__ __forceinline__ void box_init(int *box) {
+  if (threadIdx.x == 0) {
+    box[0] = box[1] = 0x7fffffff;
+    box[2] = box[3] = -1;
+  }
+}
+__device__ __forceinline__ void box_reduce(int *box, int ylo, int xlo, int yhi, int xhi) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    ylo = min(ylo, __shfl_xor(ylo, o));
+    xlo = min(xlo, __shfl_xor(xlo, o));
+    yhi = max(yhi, __shfl_xor(yhi, o));
+    xhi = max(xhi, __shfl_xor(xhi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&box[0], ylo);
+    atomicMin(&box[1], xlo);
+    atomicMax(&box[2], yhi);
+    atomicMax(&box[3], xhi);
+  }
+}
+
+// Host side: is this the regime of the big-plane kernels?  Few planes (the planes-in-LDS / windowed kernels get fewer
+// than ~4 workgroups per CU out of batch x channel groups) AND planes beyond the LDS budget.  tuning key 30: 1 = never
+// (round 1's windowed kernels), 2 = always (tests drive the kernels at small shapes).
+inline bool big_plane_regime(int64_t B, int64_t C, int64_t plane_bytes, int64_t lds_budget) {
+  const int t = tuning(30);
+  if (t == 1) return false;
+  if (t == 2) return true;
+  return plane_bytes > lds_budget && B * C < 4 * kNumCU;
+}
+
+// Scatter tiles: th x tw flow pixels per workgroup, one pixel per thread (th * tw <= 512).  tuning keys 31 / 32.
+struct TileGeo {
+  int th, tw, nty, ntx, threads;
+};
+inline TileGeo tile_geometry(int64_t H, int64_t W) {
+  TileGeo g;
+  int tw = tuning(32) > 0 ? tuning(32) : 32;
+  if (tw > W) tw = (int)W;
+  if (tw > 512) tw = 512;
+  // columns split evenly: 176 -> 6 tiles of 30 rather than 5 of 32 and one of 16
+  const int ntx = (int)ceil_div(W, tw);
+  tw = (int)ceil_div(W, ntx);
+  int th = tuning(31) > 0 ? tuning(31) : 16;
+  if (th * tw > 512) th = 512 / tw;
+  if (th > H) th = (int)H;
+  if (th < 1) th = 1;
+  g.th = th;
+  g.tw = tw;
+  g.ntx = ntx;
+  g.nty = (int)ceil_div(H, th);
+  g.threads = (int)ceil_div((int64_t)th * tw, 64) * 64;
+  return g;
+}
+
+}  // namespace gfla

@@ -53,8 +53,9 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   3: round 3 (gfla_path_count, process-global tuning, arithmetic mode 4)
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
  *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX)
- *   6: round 4 (gfla_convert_multi) */
-#define GFLA_ABI_VERSION 6
+ *   6: round 4 (gfla_convert_multi)
+ *   7: round 5 (path ids 13-17, tuning keys 30-34: the big-plane kernels of csrc/tile_map.h) */
+#define GFLA_ABI_VERSION 7
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
@@ -82,6 +83,10 @@ const char *gfla_status_string(int status);
  *   key 27: (make PROBES=1 builds) timing ablations of the two round-4 block_extractor forward kernels
  *   key 29: Winograd-domain weight gradient: 1 = units of one tile row everywhere (round 3); 0 = whole tile rows per unit
  *           on maps whose tile rows fill at most half a unit (csrc/fc_wino.hip: MR)
+ *   key 30: big-plane kernels (few planes, each beyond the LDS budget: csrc/tile_map.h)   0 auto, 1 never (round 1's
+ *           row-window kernels), 2 always (tests drive them at small shapes)
+ *   key 31 / 32: rows / columns of a scatter tile (0 auto: 16 x 32)   key 33: channels per wave of the gather kernels
+ *   key 34: channels per workgroup of the scatter tiles (0 auto: 4)
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 
@@ -101,7 +106,12 @@ enum gfla_path {
   GFLA_PATH_FC_BWD_MODE3 = 10,
   GFLA_PATH_FC_BWD_MODE4 = 11,
   GFLA_PATH_BE_FWD_PIX = 12,   /* block_extractor forward: lane = flow pixel, padded planes in LDS (round 4) */
-  GFLA_PATH_COUNT = 13
+  GFLA_PATH_BE_FWD_GPIX = 13,  /* round 5, few planes beyond the LDS budget (csrc/tile_map.h): block_extractor forward */
+  GFLA_PATH_BE_BWD_TILE = 14,  /*   block_extractor backward, flow-pixel tiles with bounding-box LDS windows */
+  GFLA_PATH_RS_FWD_BIG = 15,   /*   resample2d forward */
+  GFLA_PATH_RS_BWD1_TILE = 16, /*   resample2d d/d input1, tiles with bounding-box LDS windows */
+  GFLA_PATH_RS_BWD2_BIG = 17,  /*   resample2d d/d input2 */
+  GFLA_PATH_COUNT = 18
 };
 int64_t gfla_path_count(int path);
 

@@ -1,0 +1,245 @@
+"""BASELINE configs[1] -- block_extractor + resample2d forward/backward on a (1, 64, 256, 176) fp32 feature map -- and the
+kernel family that serves it (round 5: few planes, each far beyond the LDS budget; csrc/tile_map.h, be_tile.h, the
+*_big / *_tile kernels of resample2d.hip).
+
+  1. the configuration itself, DEFAULT dispatch, on every flow kind of tests/test_default_path_gpu.py (smooth, wild, integer,
+     near-integer, out of bounds) against the REAL reference kernels (oracle/_ref), forward and every gradient, with the
+     dispatch trace asserting that the big-plane kernels ran;
+  2. the kernels forced on (tuning key 30 = 2) at small, ragged shapes (Hs != Hf, odd sizes, batch > 1, kernel sizes 2-5,
+     resample kernel sizes 2-6 and dilation 2) in float32 and float64 against the CPU oracle, over launch geometries the
+     heuristics do not pick: tile shapes, channels per workgroup / per thread, an LDS budget small enough that a tile's
+     bounding box needs several channel rounds, and one small enough that tiles fall to global atomics;
+  3. resample2d's int() quirk (resample2d_kernel.cu:137-138) both ways through the tile scatter.
+"""
+import pytest
+import torch
+
+from test_bench_shapes_gpu import _ref
+from test_default_path_gpu import KINDS, flow_of, rel_err
+from util import assert_close, make_flow, rand, randn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+CFG2 = (1, 64, 256, 176)
+
+
+def _flow(kind, B, H, W, seed):
+    return flow_of(kind, B, H, W, seed) if kind in KINDS else make_flow(kind, B, H, W, seed=seed)
+
+
+# ------------------------------------------------------------------------------------------ 1. the configuration itself
+@pytest.mark.parametrize("kind", ("smooth", "zero") + KINDS)
+@pytest.mark.parametrize("k", [3, 5])
+def test_config2_block_extractor_all_flows_vs_reference_kernels(gfla, k, kind):
+    ref = _ref()
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = CFG2
+    s, f = randn((B, C, H, W), seed=1210), _flow(kind, B, H, W, 1211)
+    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+    n_f, n_b = _lib.path_count(_lib.PATH_BE_FWD_GPIX), _lib.path_count(_lib.PATH_BE_BWD_TILE)
+    out = gfla.BlockExtractor(k)(sd, fd)
+    up = randn((B, C, k * H, k * W), seed=1212).to(DEV)
+    out.backward(up)
+    assert _lib.path_count(_lib.PATH_BE_FWD_GPIX) == n_f + 1, "forward did not take the big-plane kernel"
+    assert _lib.path_count(_lib.PATH_BE_BWD_TILE) == n_b + 1, "backward did not take the tile kernel"
+    dt = torch.float32 if kind == "near_integer" else torch.float64
+    sr, fr = s.to(dt).to(DEV), f.to(dt).to(DEV)
+    want = ref.block_extractor_fwd(sr, fr, k)
+    gs, gf = ref.block_extractor_bwd(sr, fr, up.to(dt), k)
+    errs = (("out", rel_err(out, want)), ("grad source", rel_err(sd.grad, gs)), ("grad flow", rel_err(fd.grad, gf)))
+    print("config2 block_extractor k%d %s: " % (k, kind) + " ".join("%s %.2e" % e for e in errs))
+    assert (out.detach().double() - want.double()).abs().max().item() <= 1e-4        # the north star's own bar, absolute
+    for n, e in errs:
+        assert e <= (1e-4 if dt == torch.float32 and n != "out" else TOL), "k%d %s %s: rel err %.3e" % (k, kind, n, e)
+    if kind == "zero":   # the reference's own KAT (test_block_extractor.py:46-55): centre tap = identity
+        assert torch.equal(out[:, :, k // 2::k, k // 2::k], sd.detach())
+
+
+@pytest.mark.parametrize("kind", ("smooth", "zero") + KINDS)
+def test_config2_resample2d_all_flows_vs_reference_kernels(gfla, kind):
+    ref = _ref()
+    from global_flow_local_attention_amd import _lib
+    B, C, H, W = CFG2
+    i1, fl, up = randn((B, C, H, W), seed=1220), _flow(kind, B, H, W, 1221), randn((B, C, H, W), seed=1222)
+    i1d, fld = i1.to(DEV).requires_grad_(), fl.to(DEV).requires_grad_()
+    ids = (_lib.PATH_RS_FWD_BIG, _lib.PATH_RS_BWD1_TILE, _lib.PATH_RS_BWD2_BIG)
+    before = [_lib.path_count(i) for i in ids]
+    out = gfla.Resample2d(4, 1, 2)(i1d, fld)
+    out.backward(up.to(DEV))
+    assert [_lib.path_count(i) for i in ids] == [b + 1 for b in before], "default dispatch did not take the big-plane kernels"
+    dt = torch.float32 if kind == "near_integer" else torch.float64
+    i2 = torch.cat((fl, torch.full((B, 1, H, W), 2.0)), 1).to(dt).to(DEV).contiguous()
+    i1r = i1.to(dt).to(DEV)
+    want = ref.resample2d_fwd(i1r, i2, 4, 1)
+    g1, g2 = ref.resample2d_bwd(i1r, i2, up.to(dt).to(DEV), 4, 1)
+    errs = (("out", rel_err(out, want)), ("grad input1", rel_err(i1d.grad, g1)),
+            ("grad flow", rel_err(fld.grad, g2[:, :2], 1.0 if kind == "oob" else 0.0)))
+    print("config2 resample2d %s: " % kind + " ".join("%s %.2e" % e for e in errs))
+    assert (out.detach().double() - want.double()).abs().max().item() <= 1e-4
+    for n, e in errs:
+        assert e <= (1e-4 if dt == torch.float32 and n != "out" else TOL), "resample2d %s %s: rel err %.3e" % (kind, n, e)
+
+
+# ------------------------------------------------------------------------------------------ 2. forced, small shapes
+# tuning keys: 30 = 2 force the family; 31 / 32 tile rows / columns; 33 channels per wave / thread of the gathers; 34 channels
+# per workgroup of the scatter tiles; 10 LDS budget in KB (16 KB = 2048 window elements)
+GEOS = [{}, {31: 3, 32: 5, 34: 1, 33: 1}, {31: 16, 32: 32, 34: 7, 33: 3}, {31: 4, 32: 64, 34: 3, 10: 16, 33: 2},
+        {31: 32, 32: 16, 34: 5, 10: 16}, {31: 1, 32: 512, 34: 2}]
+SHAPES = [  # B, C, Hs, Ws, Hf, Wf
+    (2, 5, 21, 17, 21, 17), (1, 9, 40, 60, 40, 60), (2, 3, 12, 20, 9, 14), (1, 6, 7, 5, 11, 3), (1, 4, 64, 48, 64, 48)]
+
+
+class _Tuning(object):
+    def __init__(self, gfla, keys):
+        self.gfla, self.keys = gfla, dict(keys)
+
+    def __enter__(self):
+        self.old = {k: self.gfla.set_tuning(k, v) for k, v in self.keys.items()}
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            self.gfla.set_tuning(k, v)
+
+
+@pytest.mark.parametrize("geo", range(len(GEOS)))
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
+def test_block_extractor_big_plane_kernels_forced(gfla, oracle, k, geo):
+    from global_flow_local_attention_amd import _lib
+    keys = dict(GEOS[geo])
+    keys[30] = 2
+    with _Tuning(gfla, keys):
+        for (B, C, Hs, Ws, Hf, Wf) in SHAPES:
+            for dtype, tf, tg in ((torch.float32, 2e-6, 2e-5), (torch.float64, 1e-12, 1e-11)):
+                for kind, scale in (("wild", 0.6), ("wild", 3.0), ("smooth", 1.0)):
+                    s = randn((B, C, Hs, Ws), dtype, seed=3)
+                    f = (make_flow(kind, B, Hf, Wf, seed=4) * scale).to(dtype)
+                    if kind == "smooth":   # a few lattice points and near-lattice points: the tap-by-tap branches
+                        f[:, :, ::3, ::2] = torch.round(f[:, :, ::3, ::2])
+                        f[:, :, 1::4, 1::3] = torch.round(f[:, :, 1::4, 1::3]) + (2.0 ** -22 if dtype == torch.float32 else 2.0 ** -50)
+                    up = randn((B, C, k * Hf, k * Wf), dtype, seed=5)
+                    want = oracle.block_extractor_fwd(s, f, k)
+                    gs_w, gf_w = oracle.block_extractor_bwd(s, f, up, k)
+                    sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+                    n_f, n_b = _lib.path_count(_lib.PATH_BE_FWD_GPIX), _lib.path_count(_lib.PATH_BE_BWD_TILE)
+                    out = gfla.BlockExtractorFunction.apply(sd, fd, k)
+                    out.backward(up.to(DEV))
+                    assert _lib.path_count(_lib.PATH_BE_FWD_GPIX) == n_f + 1 and _lib.path_count(_lib.PATH_BE_BWD_TILE) == n_b + 1
+                    what = "k%d %s x%.1f %s %s keys %s" % (k, kind, scale, (B, C, Hs, Ws, Hf, Wf), dtype, keys)
+                    assert_close(out.detach().cpu(), want, tf, "fwd " + what)
+                    assert_close(sd.grad.cpu(), gs_w, tg, "grad source " + what)
+                    assert_close(fd.grad.cpu(), gf_w, tg, "grad flow " + what)
+            # one gradient at a time (the NEED_SRC / NEED_FLOW instantiations)
+            s, f = randn((B, C, Hs, Ws), seed=6), make_flow("coherent", B, Hf, Wf, seed=7)
+            up = randn((B, C, k * Hf, k * Wf), seed=8)
+            gs_w, gf_w = oracle.block_extractor_bwd(s, f, up, k)
+            sd, fd, upd = s.to(DEV), f.to(DEV), up.to(DEV)
+            gs, gf = torch.zeros_like(sd), torch.zeros_like(fd)
+            _lib.call("gfla_block_extractor_bwd_f32", sd, _lib.ptr(sd), _lib.ptr(fd), _lib.ptr(upd), _lib.ptr(gs), None, B, C, Hs, Ws, Hf, Wf, k)
+            _lib.call("gfla_block_extractor_bwd_f32", sd, _lib.ptr(sd), _lib.ptr(fd), _lib.ptr(upd), None, _lib.ptr(gf), B, C, Hs, Ws, Hf, Wf, k)
+            assert_close(gs.cpu(), gs_w, 2e-5, "grad source alone")
+            assert_close(gf.cpu(), gf_w, 2e-5, "grad flow alone")
+
+
+@pytest.mark.parametrize("geo", range(len(GEOS)))
+@pytest.mark.parametrize("k,dil", [(4, 1), (2, 1), (6, 1), (4, 2), (5, 1)])
+def test_resample2d_big_plane_kernels_forced(gfla, oracle, k, dil, geo):
+    from global_flow_local_attention_amd import _lib
+    keys = dict(GEOS[geo])
+    keys[30] = 2
+    ids = (_lib.PATH_RS_FWD_BIG, _lib.PATH_RS_BWD1_TILE, _lib.PATH_RS_BWD2_BIG)
+    with _Tuning(gfla, keys):
+        for (B, C, Hi, Wi, H, W) in SHAPES:
+            for dtype, tf, tg in ((torch.float32, 4e-6, 3e-5), (torch.float64, 1e-12, 1e-10)):
+                for kind, scale in (("wild", 0.6), ("wild", 3.0), ("smooth", 1.0)):
+                    i1 = randn((B, C, Hi, Wi), dtype, seed=13)
+                    i2 = torch.cat(((make_flow(kind, B, H, W, seed=14) * scale).to(dtype),
+                                    rand((B, 1, H, W), dtype, seed=15) * 3 + 0.3), 1).contiguous()
+                    up = randn((B, C, H, W), dtype, seed=16)
+                    want = oracle.resample2d_fwd(i1, i2, k, dil)
+                    g1_w, g2_w = oracle.resample2d_bwd(i1, i2, up, k, dil, trunc_compat=True)
+                    i1d, i2d = i1.to(DEV).requires_grad_(), i2.to(DEV).requires_grad_()
+                    before = [_lib.path_count(i) for i in ids]
+                    out = gfla.Resample2dFunction.apply(i1d, i2d, k, dil)
+                    out.backward(up.to(DEV))
+                    assert [_lib.path_count(i) for i in ids] == [b + 1 for b in before]
+                    what = "k%d d%d %s x%.1f %s %s keys %s" % (k, dil, kind, scale, (B, C, Hi, Wi, H, W), dtype, keys)
+                    assert_close(out.detach().cpu(), want, tf, "fwd " + what)
+                    assert_close(i1d.grad.cpu(), g1_w, tg, "grad input1 " + what)
+                    assert_close(i2d.grad.cpu(), g2_w, tg, "grad (dx, dy, sigma) " + what)
+
+
+def test_resample2d_tile_scatter_trunc_compat_both_ways(gfla, oracle):
+    """resample2d_kernel.cu:137-138 -- int() instead of floor() in d/d input1 -- matters where x + dx < 0: wild flows near the
+    left / top border.  The tile scatter reproduces it by default and gives the forward's true gradient with it off."""
+    from global_flow_local_attention_amd import resample2d as rs
+    B, C, H, W = 2, 6, 24, 36
+    with _Tuning(gfla, {30: 2}):
+        for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+            i1 = randn((B, C, H, W), dtype, seed=19)
+            i2 = torch.cat((make_flow("wild", B, H, W, dtype, seed=20), rand((B, 1, H, W), dtype, seed=21) * 3 + 0.3), 1).contiguous()
+            g = randn((B, C, H, W), dtype, seed=22)
+            g1_t, _ = oracle.resample2d_bwd(i1, i2, g, 4, 1, trunc_compat=True)
+            g1_f, _ = oracle.resample2d_bwd(i1, i2, g, 4, 1, trunc_compat=False)
+            assert (g1_t - g1_f).abs().max().item() > 1e-3        # the quirk is visible on this input
+            for compat, want in ((True, g1_t), (False, g1_f)):
+                rs.TRUNC_COMPAT = compat
+                try:
+                    i1d = i1.to(DEV).requires_grad_()
+                    gfla.Resample2dFunction.apply(i1d, i2.to(DEV), 4, 1).backward(g.to(DEV))
+                    assert_close(i1d.grad.cpu(), want, tol, "trunc_compat=%s %s" % (compat, dtype))
+                finally:
+                    rs.TRUNC_COMPAT = True
+
+
+def test_tile_scatter_is_reproducible_and_handles_nonfinite_gradients(gfla):
+    """The float tile scatter accumulates 64-bit fixed point in LDS (order-independent); what leaves the window are float
+    atomics, one per element and tile -- elements reached from several tiles may differ in the last bit run to run, which
+    is the reference's own behaviour (float atomics everywhere).  A non-finite upstream gradient poisons what its tile
+    reaches and nothing crashes."""
+    B, C, H, W = CFG2
+    i1, fl = randn((B, C, H, W), seed=31).to(DEV), make_flow("smooth", B, H, W, seed=32).to(DEV)
+    up = randn((B, C, H, W), seed=33).to(DEV)
+    mod = gfla.Resample2d(4, 1, 2)
+    grads = []
+    for _ in range(3):
+        x = i1.clone().requires_grad_()
+        mod(x, fl).backward(up)
+        grads.append(x.grad)
+    for g in grads[1:]:
+        assert (g - grads[0]).abs().max().item() <= 1e-5 * grads[0].abs().max().item()
+    up2 = up.clone()
+    up2[0, 3, 100, 77] = float("inf")
+    x = i1.clone().requires_grad_()
+    mod(x, fl).backward(up2)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(x.grad[0, 3]).all() and torch.isfinite(x.grad[0, 4]).all()
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_config2_round1_row_window_kernels_still_agree(gfla, oracle, k):
+    """tuning key 30 = 1: the configuration on round 1's row-window kernels (what serves planes beyond the LDS budget when
+    there are MANY of them, B*C >= 1024) -- kept under test now that the default dispatch at this shape has moved on."""
+    from global_flow_local_attention_amd import _lib
+    with _Tuning(gfla, {30: 1}):
+        s, f = randn((1, 16, 256, 176), seed=34), make_flow("smooth", 1, 256, 176, seed=35)
+        sd, fd = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+        n_f, n_b = _lib.path_count(_lib.PATH_BE_FWD_GPIX), _lib.path_count(_lib.PATH_BE_BWD_TILE)
+        out = gfla.BlockExtractor(k)(sd, fd)
+        assert_close(out.detach().cpu(), oracle.block_extractor_fwd(s, f, k), 2e-6, "windowed fwd")
+        g = randn(tuple(out.shape), seed=36)
+        out.backward(g.to(DEV))
+        assert _lib.path_count(_lib.PATH_BE_FWD_GPIX) == n_f and _lib.path_count(_lib.PATH_BE_BWD_TILE) == n_b
+        gs, gf = oracle.block_extractor_bwd(s, f, g, k)
+        assert_close(sd.grad.cpu(), gs, 2e-5, "windowed grad_source")
+        assert_close(fd.grad.cpu(), gf, 2e-5, "windowed grad_flow")
+        if k == 3:
+            i1d, fld = s.to(DEV).requires_grad_(), f.to(DEV).requires_grad_()
+            o = gfla.Resample2d(4, 1, 2)(i1d, fld)
+            i2 = torch.cat((f, torch.full((1, 1, 256, 176), 2.0)), 1).contiguous()
+            assert_close(o.detach().cpu(), oracle.resample2d_fwd(s, i2, 4, 1), 4e-6, "windowed resample fwd")
+            g = randn(tuple(o.shape), seed=39)
+            o.backward(g.to(DEV))
+            g1, g2 = oracle.resample2d_bwd(s, i2, g, 4, 1)
+            assert_close(i1d.grad.cpu(), g1, 2e-5)
+            assert_close(fld.grad.cpu(), g2[:, :2], 2e-5)
