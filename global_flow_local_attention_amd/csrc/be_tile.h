@@ -1,18 +1,24 @@
 // block_extractor for FEW, LARGE planes (BASELINE configs[1]: (1, 64, 256, 176), planes of 180 KB on 256 CUs), round 5.
 // tile_map.h has the regime and the shared pieces.  Semantics: block_extractor_kernel.cu:20-85 (forward), :89-170 (backward).
 //
-// forward  be_fwd_gpix_kernel   lane = flow pixel (64 consecutive pixels per wave), the four waves of a workgroup take four
-//          channel ranges of the SAME pixels; setup (flow pair, K fractions, patch origin) once per pixel for `cpw`
-//          channels; the dense (K+1)^2 patch of a channel is read from global memory (row r: K+1 loads whose lanes are
-//          consecutive addresses up to the flow's local variation), evaluated separably exactly as be_fwd_pix.h does, and
-//          the K outputs of an output row leave as one 16-byte + one 4-byte store (k = 5).  The op is 96 % writes: what
-//          the launch has to provide is enough waves streaming stores, which at B*C = 64 only spatial blocks can.
-// backward be_bwd_tile_kernel   workgroup = (tile of th x tw flow pixels, G channels), lane = flow pixel.  The K*K incoming
-//          gradients of a pixel are folded into its dense (K+1)^2 patch in registers (be_bwd_lds.h's fold) and added to
-//          an LDS window = the bounding box of everything the tile's pixels reach, computed from the flow on the device;
-//          the window leaves through one float atomic per touched element.  The window is processed in as many channel
-//          rounds as fit the LDS budget; a window too large for one channel (wild flow) sends that tile to global atomics.
-//          d/dflow is reduced in registers over taps and the G channels (source values from global memory / L1).
+// Both directions: workgroup = (tile of th x tw flow pixels, G channels), lane = flow pixel, per-pixel setup once for the G
+// channels.  The tile's BOUNDING BOX in the source plane (everything its pixels reach, from the flow, on the device) is the
+// LDS window; the G channels pass through it in as many rounds as the LDS budget allows; a box too large for one channel
+// (wild flow) sends that tile -- and only that tile -- to global memory.
+//
+// forward  be_fwd_tile_kernel   the window holds the source; a pixel's dense (K+1)^2 patch is read from it with ds_reads and
+//          evaluated separably exactly as be_fwd_pix.h does; the K outputs of an output row leave as one 16-byte + one
+//          4-byte store (k = 5).  Default tiles are WHOLE flow rows (tile_map.h: row_tile_geometry): the K*th output rows
+//          of a channel are then one contiguous piece of the output plane per workgroup -- the op is 96 % writes.
+//          (First version, measured and replaced: lane = pixel with the patch read from GLOBAL memory -- be_fwd_gpix_kernel,
+//          kept as the per-tile fallback and under tuning key 38 = 1.  At (1,64,256,176) it ran at the store stream's rate
+//          on a zero flow, 23 us = 0.62 of HBM, but at 47 us on a smooth one whatever the channels per wave: every per-tap
+//          wave load costs ~40 CU cycles once the lanes' rows differ, 16 of them per pixel and channel;
+//          profiles/r5_config2_first_kernels.txt.)
+// backward be_bwd_tile_kernel   the K*K incoming gradients of a pixel are folded into its dense (K+1)^2 patch in registers
+//          (be_bwd_lds.h's fold) and added to the window (double planes, ds_add_f64), which leaves through one float atomic
+//          per touched element; d/dflow is reduced in registers over taps and the G channels, its source values come from a
+//          second (float) window staged next to the accumulators.
 #pragma once
 
 #include "be_fwd_pix.h"
@@ -20,11 +26,117 @@
 
 namespace gfla {
 
+// ---- forward: per-pixel bodies shared by the window kernel (P = arithmetic type, LDS) and the global one (P = storage) ----
+// row(cc, r): pointer p such that p[c] is the source value at plane column c of the CLAMPED patch row r (0..K) of chunk
+// channel cc.  Output rows go to oc0 + cc * oplane + i * Wo.
+template <typename T, typename P, int K, int CH, typename RowFn>
+__device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const int (&col)[K + 1], const typename Num<T>::acc (&ax)[K],
+                                                   const typename Num<T>::acc (&ay)[K], T *__restrict__ oc0, int64_t oplane, int Wo,
+                                                   bool active) {
+  using A = typename Num<T>::acc;
+  // the bilinear form separated (be_fwd_wrow.h has the derivation): patch rows interpolated along x once, output row i = the
+  // blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand
+  auto hrow = [&](int cc, int r, A (&h)[K]) {
+    const P *pc = row(min(cc, ncc - 1), r);
+    A vv[K + 1];
+#pragma unroll
+    for (int q = 0; q <= K; ++q) vv[q] = Num<P>::ld(pc + col[q]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) h[j] = fma_t(ax[j], vv[j + 1], (1 - ax[j]) * vv[j]);
+  };
+  A hA[CH][K];
+#pragma unroll
+  for (int cc = 0; cc < CH; ++cc) hrow(cc, 0, hA[cc]);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const A yB_P = ay[i], yT_P = 1 - yB_P;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      A hB[K];
+      hrow(cc, i + 1, hB);
+      T o[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[j], yT_P * hA[cc][j]));
+      if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
+#pragma unroll
+      for (int j = 0; j < K; ++j) hA[cc][j] = hB[j];
+    }
+  }
+}
+// a coordinate within rounding of an integer: tap by tap, as the reference does (:69-84).  at(yrow) -> pointer to plane row
+// yrow (clamped) of this channel, indexed by clamped plane columns.
+template <typename T, typename P, int K, typename RowAt>
+__device__ __forceinline__ void be_fwd_taps_channel(RowAt at, int Hs, const int (&xL)[K], const int (&xR)[K],
+                                                    const typename Num<T>::acc (&ax)[K], typename Num<T>::acc fy0, int yf,
+                                                    T *__restrict__ oc, int Wo) {
+  using A = typename Num<T>::acc;
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+    const A fdy = floor_t<A>(dy);
+    const P *rT = at(clampi((int)fdy, 0, Hs - 1)), *rB = at(clampi((int)(fdy + 1), 0, Hs - 1));
+    const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+    T o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const A xR_P = ax[j], xL_P = 1 - xR_P;
+      A s = (xL_P * yT_P) * Num<P>::ld(rT + xL[j]);
+      s = fma_t(xR_P * yT_P, Num<P>::ld(rT + xR[j]), s);
+      s = fma_t(xL_P * yB_P, Num<P>::ld(rB + xL[j]), s);
+      s = fma_t(xR_P * yB_P, Num<P>::ld(rB + xR[j]), s);
+      o[j] = Num<T>::from(s);
+    }
+    store_row<T, K, false>(oc + (int64_t)i * Wo, o);
+  }
+}
+
+// Per-pixel setup of both directions: flow pair, K fractions per axis, patch origin, dense flag, clamped columns.
+template <typename T, int K>
+struct BePixel {
+  using A = typename Num<T>::acc;
+  A fx0, fy0, ax[K], ay[K];
+  int x0c, y0c, xL[K], xR[K], col[K + 1];
+  bool dense;
+  __device__ __forceinline__ void init(const T *__restrict__ flow_b, int HW, int p, int xf, int yf, int Hs, int Ws, bool active) {
+    fx0 = active ? Num<T>::ld(flow_b + p) : (A)0;
+    fy0 = active ? Num<T>::ld(flow_b + HW + p) : (A)0;
+    int x0 = 0, y0 = 0;
+    dense = true;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:62-67 / :132-136
+      const A dy = (fy0 + (A)(t - K / 2)) + (A)yf;
+      const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
+      if (t == 0) {
+        x0 = (int)fdx;
+        y0 = (int)fdy;
+      }
+      dense &= ((int)fdx == x0 + t) & ((int)fdy == y0 + t);
+      xL[t] = clampi((int)fdx, 0, Ws - 1);  // :69-72
+      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
+      ax[t] = dx - fdx;
+      ay[t] = dy - fdy;
+    }
+    // the clamp of the origin only keeps the sums below in range
+    x0c = clampi(x0, -(K + 2), Ws + 1);
+    y0c = clampi(y0, -(K + 2), Hs + 1);
+#pragma unroll
+    for (int q = 0; q <= K; ++q) col[q] = clampi(x0c + q, 0, Ws - 1);
+  }
+  // what the pixel can reach, one row / column of slack for the taps of the non-dense case
+  __device__ __forceinline__ void reach(int Hs, int Ws, bool active, int &ylo, int &xlo, int &yhi, int &xhi) const {
+    ylo = active ? clampi(y0c - 1, 0, Hs - 1) : 0x7fffffff;
+    xlo = active ? clampi(x0c - 1, 0, Ws - 1) : 0x7fffffff;
+    yhi = active ? clampi(y0c + K + 1, 0, Hs - 1) : -1;
+    xhi = active ? clampi(x0c + K + 1, 0, Ws - 1) : -1;
+  }
+};
+
+// ---- forward, first version: patch read from global memory (the per-tile fallback of the window kernel; key 38 = 1) --------
 template <typename T, int K, int CH>
 __global__ __launch_bounds__(256) void be_fwd_gpix_kernel(const T *__restrict__ src, const T *__restrict__ flow,
                                                          T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf,
                                                          int cpw, int ncs4, int nblk, int64_t nwg) {
-  using A = typename Num<T>::acc;
   const int64_t v = xcd_swizzle(blockIdx.x, nwg);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cs = (int)(v % ncs4) * 4 + wave;
@@ -39,96 +151,24 @@ __global__ __launch_bounds__(256) void be_fwd_gpix_kernel(const T *__restrict__ 
   const bool active = pl < HW;
   const int p = active ? pl : HW - 1;
   const int yf = p / Wf, xf = p - yf * Wf;
-  const A fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
-  const A fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
-  A ax[K], ay[K];
-  int x0 = 0, y0 = 0;
-  bool dense = true;
-#pragma unroll
-  for (int t = 0; t < K; ++t) {
-    const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;  // block_extractor_kernel.cu:62-67
-    const A dy = (fy0 + (A)(t - K / 2)) + (A)yf;
-    const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
-    if (t == 0) {
-      x0 = (int)fdx;
-      y0 = (int)fdy;
-    }
-    dense &= ((int)fdx == x0 + t) & ((int)fdy == y0 + t);
-    ax[t] = dx - fdx;
-    ay[t] = dy - fdy;
-  }
+  BePixel<T, K> px;
+  px.init(flow + (int64_t)b * 2 * HW, HW, p, xf, yf, Hs, Ws, true);
   const int ooff = (K * yf) * Wo + K * xf;
   const T *src_b = src + (int64_t)b * C * plane;
   T *out_b = out + (int64_t)b * C * oplane;
-  if (dense) {
-    // clamped columns / rows of the dense patch (:69-72); the clamp of the origin only keeps the sums in range
-    const int x0c = clampi(x0, -(K + 1), Ws), y0c = clampi(y0, -(K + 1), Hs);
-    int col[K + 1];
-#pragma unroll
-    for (int q = 0; q <= K; ++q) col[q] = clampi(x0c + q, 0, Ws - 1);
+  if (px.dense) {
     for (int cb = c_begin; cb < c_end; cb += CH) {
-      const int ncc = min(CH, c_end - cb);
       const T *plc = src_b + (int64_t)cb * plane;
-      T *oc0 = out_b + (int64_t)cb * oplane + ooff;
-      // the bilinear form separated (be_fwd_wrow.h has the derivation): patch rows interpolated along x once, output row
-      // i = the blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand
-      auto hrow = [&](int cc, int r, A (&h)[K]) {
-        const T *pc = plc + (int64_t)min(cc, ncc - 1) * plane + clampi(y0c + r, 0, Hs - 1) * Ws;
-        A vv[K + 1];
-#pragma unroll
-        for (int q = 0; q <= K; ++q) vv[q] = Num<T>::ld(pc + col[q]);
-#pragma unroll
-        for (int j = 0; j < K; ++j) h[j] = fma_t(ax[j], vv[j + 1], (1 - ax[j]) * vv[j]);
-      };
-      A hA[CH][K];
-#pragma unroll
-      for (int cc = 0; cc < CH; ++cc) hrow(cc, 0, hA[cc]);
-#pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const A yB_P = ay[i], yT_P = 1 - yB_P;
-#pragma unroll
-        for (int cc = 0; cc < CH; ++cc) {
-          A hB[K];
-          hrow(cc, i + 1, hB);
-          T o[K];
-#pragma unroll
-          for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[j], yT_P * hA[cc][j]));
-          if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
-#pragma unroll
-          for (int j = 0; j < K; ++j) hA[cc][j] = hB[j];
-        }
-      }
+      const int y0c = px.y0c;
+      auto row = [=](int cc, int r) { return plc + (int64_t)cc * plane + clampi(y0c + r, 0, Hs - 1) * Ws; };
+      be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, c_end - cb), px.col, px.ax, px.ay, out_b + (int64_t)cb * oplane + ooff, oplane,
+                                      Wo, active);
     }
   } else if (active) {
-    // a coordinate within rounding of an integer: tap by tap, as the reference does (:69-84)
-    int xL[K], xR[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;
-      const A fdx = floor_t<A>(dx);
-      xL[t] = clampi((int)fdx, 0, Ws - 1);
-      xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
-    }
     for (int c = c_begin; c < c_end; ++c) {
       const T *pc = src_b + (int64_t)c * plane;
-#pragma unroll 1
-      for (int i = 0; i < K; ++i) {
-        const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
-        const A fdy = floor_t<A>(dy);
-        const int yT = clampi((int)fdy, 0, Hs - 1) * Ws, yB = clampi((int)(fdy + 1), 0, Hs - 1) * Ws;
-        const A yB_P = dy - fdy, yT_P = 1 - yB_P;
-        T o[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const A xR_P = ax[j], xL_P = 1 - xR_P;
-          A s = (xL_P * yT_P) * Num<T>::ld(pc + yT + xL[j]);
-          s = fma_t(xR_P * yT_P, Num<T>::ld(pc + yT + xR[j]), s);
-          s = fma_t(xL_P * yB_P, Num<T>::ld(pc + yB + xL[j]), s);
-          s = fma_t(xR_P * yB_P, Num<T>::ld(pc + yB + xR[j]), s);
-          o[j] = Num<T>::from(s);
-        }
-        store_row<T, K, false>(out_b + (int64_t)c * oplane + (int64_t)i * Wo + ooff, o);
-      }
+      auto at = [=](int yrow) { return pc + yrow * Ws; };
+      be_fwd_taps_channel<T, T, K>(at, Hs, px.xL, px.xR, px.ax, px.fy0, yf, out_b + (int64_t)c * oplane + ooff, Wo);
     }
   }
 }
@@ -142,19 +182,117 @@ inline int big_channels_per_wave(int64_t B, int64_t C, int64_t nblk, int ch, int
   return (int)(cpw < C ? cpw : C);
 }
 
+// ---- forward: the window kernel ------------------------------------------------------------------------------------------
+template <typename T, int K, int CH>
+__global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ src, const T *__restrict__ flow,
+                                                         T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf, int th,
+                                                         int tw, int ntx, int nty, int G, int ngroups, int lds_elems,
+                                                         int64_t nwg) {
+  using A = typename Num<T>::acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  __shared__ int s_box[4];
+  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
+  const int g = (int)(v % ngroups);
+  const int64_t rest = v / ngroups;
+  const int tile = (int)(rest % ((int64_t)ntx * nty)), b = (int)(rest / ((int64_t)ntx * nty));
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const int c0 = g * G, gc = min(G, C - c0);
+  const int ly = threadIdx.x / tw, lx = threadIdx.x - ly * tw;
+  const int yf = ty * th + ly, xf = tx * tw + lx;
+  const bool active = ly < th && yf < Hf && xf < Wf;
+  const int HW = Hf * Wf, Wo = K * Wf, plane = Hs * Ws;
+  const int64_t oplane = (int64_t)(K * Hf) * Wo;
+  const int p = active ? yf * Wf + xf : 0;
+  box_init(s_box);
+  __syncthreads();
+  BePixel<T, K> px;
+  px.init(flow + (int64_t)b * 2 * HW, HW, p, xf, yf, Hs, Ws, active);
+  {
+    int ylo, xlo, yhi, xhi;
+    px.reach(Hs, Ws, active, ylo, xlo, yhi, xhi);
+    box_reduce(s_box, ylo, xlo, yhi, xhi);
+  }
+  __syncthreads();
+  const TileWin w = tile_window(s_box);
+  const int g_fit = min(gc, lds_elems / max(w.size, 1));
+  const T *src0 = src + ((int64_t)b * C + c0) * plane;
+  T *out0 = out + ((int64_t)b * C + c0) * oplane + (int64_t)(K * yf) * Wo + K * xf;
+  if (g_fit == 0) {   // the tile reaches further than one channel's window holds: its patches come from global memory
+    if (px.dense) {
+      for (int cb = 0; cb < gc; cb += CH) {
+        const T *plc = src0 + (int64_t)cb * plane;
+        const int y0c = px.y0c;
+        auto row = [=](int cc, int r) { return plc + (int64_t)cc * plane + clampi(y0c + r, 0, Hs - 1) * Ws; };
+        be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, gc - cb), px.col, px.ax, px.ay, out0 + (int64_t)cb * oplane, oplane, Wo, active);
+      }
+    } else if (active) {
+      for (int c = 0; c < gc; ++c) {
+        const T *pc = src0 + (int64_t)c * plane;
+        auto at = [=](int yrow) { return pc + yrow * Ws; };
+        be_fwd_taps_channel<T, T, K>(at, Hs, px.xL, px.xR, px.ax, px.fy0, yf, out0 + (int64_t)c * oplane, Wo);
+      }
+    }
+    return;
+  }
+  const A *win0 = planes - (w.ymin * w.cols + w.xmin);   // (plane row, plane column) -> win0[row * cols + column]
+  for (int cb = 0; cb < gc; cb += g_fit) {
+    const int n = min(g_fit, gc - cb);
+    stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, planes, w, n);
+    __syncthreads();
+    if (px.dense) {
+      for (int cc0 = 0; cc0 < n; cc0 += CH) {
+        const A *wc = win0 + (size_t)cc0 * w.size;
+        const int y0c = px.y0c, cols = w.cols, wsz = w.size;
+        auto row = [=](int cc, int r) { return wc + cc * wsz + clampi(y0c + r, 0, Hs - 1) * cols; };
+        be_fwd_dense_chunk<T, A, K, CH>(row, min(CH, n - cc0), px.col, px.ax, px.ay, out0 + (int64_t)(cb + cc0) * oplane, oplane, Wo,
+                                        active);
+      }
+    } else if (active) {
+      for (int c = 0; c < n; ++c) {
+        const A *wc = win0 + (size_t)c * w.size;
+        const int cols = w.cols;
+        auto at = [=](int yrow) { return wc + yrow * cols; };
+        be_fwd_taps_channel<T, A, K>(at, Hs, px.xL, px.xR, px.ax, px.fy0, yf, out0 + (int64_t)(cb + c) * oplane, Wo);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// channels per workgroup of a tile kernel: `dflt` unless that leaves the launch under three workgroups per CU
+inline int tile_channels(int key, int dflt, int64_t tiles, int64_t C) {
+  int G = tuning(key) > 0 ? tuning(key) : dflt;
+  if (tuning(key) <= 0)
+    while (G > 1 && tiles * ceil_div(C, G) < 3 * kNumCU) G /= 2;
+  return G > C ? (int)C : G;
+}
+
 template <typename T, int K>
-static int launch_fwd_gpix(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
-                           int64_t Wf, hipStream_t stream, bool *done) {
+static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                          int64_t Wf, hipStream_t stream, bool *done) {
   using A = typename Num<T>::acc;
   constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 5 ? 2 : 4);
   *done = false;
-  const int64_t nblk = ceil_div(Hf * Wf, 64);
-  const int cpw = big_channels_per_wave(B, C, nblk, CH, 24 * kNumCU);
-  const int64_t ncs = ceil_div(C, cpw), ncs4 = ceil_div(ncs, 4);
-  const int64_t nwg = B * nblk * ncs4;
+  if (Hs * Ws > 0x3fffffffLL) return GFLA_OK;
+  if (tuning(38) == 1) {   // first version: global gathers, lane = pixel, four channel ranges per workgroup
+    const int64_t nblk = ceil_div(Hf * Wf, 64);
+    const int cpw = big_channels_per_wave(B, C, nblk, CH, 24 * kNumCU);
+    const int64_t ncs = ceil_div(C, cpw), ncs4 = ceil_div(ncs, 4);
+    const int64_t nwg = B * nblk * ncs4;
+    if (nwg > 0x7fffffffLL) return GFLA_OK;
+    be_fwd_gpix_kernel<T, K, CH><<<dim3((unsigned)nwg), dim3(256), 0, stream>>>(src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf,
+                                                                               (int)Wf, cpw, (int)ncs4, (int)nblk, nwg);
+    *done = true;
+    return launch_status();
+  }
+  const TileGeo tg = row_tile_geometry(Hf, Wf);
+  const int G = tile_channels(37, 8, B * tg.nty * tg.ntx, C);
+  const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
   if (nwg > 0x7fffffffLL) return GFLA_OK;
-  be_fwd_gpix_kernel<T, K, CH><<<dim3((unsigned)nwg), dim3(256), 0, stream>>>(src, flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf,
-                                                                             (int)Wf, cpw, (int)ncs4, (int)nblk, nwg);
+  const unsigned lds_bytes = (unsigned)lds_budget();
+  launch_lds(be_fwd_tile_kernel<T, K, CH>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C,
+             (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg);
   *done = true;
   return launch_status();
 }
@@ -163,42 +301,40 @@ static int launch_fwd_gpix(const T *src, const T *flow, T *out, int64_t B, int64
 // backward
 // ---------------------------------------------------------------------------------------------------------------------------
 // Where a folded patch row goes: the LDS window (double planes: ds_add_f64) or, for a tile whose reach does not fit, the
-// gradient plane itself (float / double atomics).
-template <typename T>
+// gradient plane itself (float / double atomics).  Both index (plane row, plane column) as base[row * pitch + col].
 struct BeWinSink {
-  lds_acc_t *plane;  // this channel's window, element (row - ymin) * cols + (col - xmin)
-  int cols, ymin, xmin;
-  __device__ __forceinline__ void add(int row, int col, typename Num<T>::acc v) const {
-    lds_add(plane + (row - ymin) * cols + (col - xmin), (lds_acc_t)v);
-  }
+  lds_acc_t *base;
+  int pitch;
+  template <typename A>
+  __device__ __forceinline__ void add(int row, int col, A v) const { lds_add(base + row * pitch + col, (lds_acc_t)v); }
 };
 template <typename T>
 struct BeGlobalSink {
-  T *plane;
-  int Ws;
-  __device__ __forceinline__ void add(int row, int col, typename Num<T>::acc v) const { atomic_add(plane + row * Ws + col, (T)v); }
+  T *base;
+  int pitch;
+  template <typename A>
+  __device__ __forceinline__ void add(int row, int col, A v) const { atomic_add(base + row * pitch + col, (T)v); }
 };
 
 // One channel of one flow pixel: fold the K x K gradients into the dense patch and hand its rows to `sink`; accumulate
-// d/dflow.  `spl` = this channel's source plane (global), `gblk` = &grad_out[b, c, yf*K, xf*K].
-template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, typename Sink>
-__device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const T *__restrict__ spl, const T *__restrict__ gblk,
-                                                   int Wo, int Hs, int Ws, int y0c, const int (&col)[K + 1],
-                                                   const typename Num<T>::acc (&ax)[K], typename Num<T>::acc fy0, int yf,
+// d/dflow.  spl[row * spitch + col] = this channel's source value (a window or the plane), gblk = &grad_out[b, c, yf*K, xf*K].
+template <typename T, typename P, int K, bool NEED_SRC, bool NEED_FLOW, typename Sink>
+__device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__restrict__ spl, int spitch,
+                                                   const T *__restrict__ gblk, int Wo, int Hs, const BePixel<T, K> &px, int yf,
                                                    typename Num<T>::acc &gx_acc, typename Num<T>::acc &gy_acc) {
   using A = typename Num<T>::acc;
   A rowA[K + 1], vA[K + 1];
-  int rA = clampi(y0c, 0, Hs - 1);
+  int rA = clampi(px.y0c, 0, Hs - 1);
 #pragma unroll
   for (int q = 0; q <= K; ++q) {
     rowA[q] = 0;
-    vA[q] = NEED_FLOW ? Num<T>::ld(spl + rA * Ws + col[q]) : (A)0;
+    vA[q] = NEED_FLOW ? (A)Num<P>::ld(spl + rA * spitch + px.col[q]) : (A)0;
   }
 #pragma unroll 1
   for (int i = 0; i < K; ++i) {
-    const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;  // block_extractor_kernel.cu:132-136
+    const A dy = (px.fy0 + (A)(i - K / 2)) + (A)yf;  // block_extractor_kernel.cu:132-136
     const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
-    const int rB = clampi(y0c + i + 1, 0, Hs - 1);
+    const int rB = clampi(px.y0c + i + 1, 0, Hs - 1);
     A gv[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) gv[j] = Num<T>::ld(gblk + i * Wo + j);
@@ -206,11 +342,11 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const T *__
 #pragma unroll
     for (int q = 0; q <= K; ++q) {
       rowB[q] = 0;
-      vB[q] = NEED_FLOW ? Num<T>::ld(spl + rB * Ws + col[q]) : (A)0;
+      vB[q] = NEED_FLOW ? (A)Num<P>::ld(spl + rB * spitch + px.col[q]) : (A)0;
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const A xL_P = 1 - ax[j], xR_P = ax[j];
+      const A xL_P = 1 - px.ax[j], xR_P = px.ax[j];
       if (NEED_SRC) {  // :158-161, folded into the patch
         rowA[j] += gv[j] * xL_P * yT_P;
         rowA[j + 1] += gv[j] * xR_P * yT_P;
@@ -225,7 +361,7 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const T *__
     if (NEED_SRC) {
 #pragma unroll
       for (int q = 0; q <= K; ++q)
-        if (rowA[q] != 0) sink.add(rA, col[q], rowA[q]);
+        if (rowA[q] != 0) sink.add(rA, px.col[q], rowA[q]);
     }
 #pragma unroll
     for (int q = 0; q <= K; ++q) {
@@ -237,38 +373,38 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const T *__
   if (NEED_SRC) {
 #pragma unroll
     for (int q = 0; q <= K; ++q)
-      if (rowA[q] != 0) sink.add(rA, col[q], rowA[q]);
+      if (rowA[q] != 0) sink.add(rA, px.col[q], rowA[q]);
   }
 }
 
 // the reference's own tap-by-tap form (a tap's floor() landed one off the dense patch)
-template <typename T, int K, bool NEED_SRC, bool NEED_FLOW, typename Sink>
-__device__ __forceinline__ void be_bwd_pixel_taps(const Sink &sink, const T *__restrict__ spl, const T *__restrict__ gblk, int Wo,
-                                                  int Hs, int Ws, const int (&xL)[K], const int (&xR)[K],
-                                                  const typename Num<T>::acc (&ax)[K], typename Num<T>::acc fy0, int yf,
+template <typename T, typename P, int K, bool NEED_SRC, bool NEED_FLOW, typename Sink>
+__device__ __forceinline__ void be_bwd_pixel_taps(const Sink &sink, const P *__restrict__ spl, int spitch,
+                                                  const T *__restrict__ gblk, int Wo, int Hs, const BePixel<T, K> &px, int yf,
                                                   typename Num<T>::acc &gx_acc, typename Num<T>::acc &gy_acc) {
   using A = typename Num<T>::acc;
 #pragma unroll 1
   for (int i = 0; i < K; ++i) {
-    const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+    const A dy = (px.fy0 + (A)(i - K / 2)) + (A)yf;
     const A fdy = floor_t<A>(dy);
     const int yT = clampi((int)fdy, 0, Hs - 1), yB = clampi((int)(fdy + 1), 0, Hs - 1);
     const A yB_P = dy - fdy, yT_P = 1 - yB_P;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const A g = Num<T>::ld(gblk + i * Wo + j);
-      const A xL_P = 1 - ax[j], xR_P = ax[j];
+      const A xL_P = 1 - px.ax[j], xR_P = px.ax[j];
+      const int xL = px.xL[j], xR = px.xR[j];
       if (NEED_FLOW) {
-        const A vTL = Num<T>::ld(spl + yT * Ws + xL[j]), vTR = Num<T>::ld(spl + yT * Ws + xR[j]);
-        const A vBL = Num<T>::ld(spl + yB * Ws + xL[j]), vBR = Num<T>::ld(spl + yB * Ws + xR[j]);
+        const A vTL = Num<P>::ld(spl + yT * spitch + xL), vTR = Num<P>::ld(spl + yT * spitch + xR);
+        const A vBL = Num<P>::ld(spl + yB * spitch + xL), vBR = Num<P>::ld(spl + yB * spitch + xR);
         gy_acc += g * (-xL_P * vTL - xR_P * vTR + xL_P * vBL + xR_P * vBR);
         gx_acc += g * (-yT_P * vTL - yB_P * vBL + yT_P * vTR + yB_P * vBR);
       }
       if (NEED_SRC) {
-        sink.add(yT, xL[j], g * xL_P * yT_P);
-        sink.add(yT, xR[j], g * xR_P * yT_P);
-        sink.add(yB, xL[j], g * xL_P * yB_P);
-        sink.add(yB, xR[j], g * xR_P * yB_P);
+        sink.add(yT, xL, g * xL_P * yT_P);
+        sink.add(yT, xR, g * xR_P * yT_P);
+        sink.add(yB, xL, g * xL_P * yB_P);
+        sink.add(yB, xR, g * xR_P * yB_P);
       }
     }
   }
@@ -279,10 +415,9 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
                                                          const T *__restrict__ gout, T *__restrict__ gsrc,
                                                          typename Num<T>::acc *__restrict__ gflow, int C, int Hs, int Ws,
                                                          int Hf, int Wf, int th, int tw, int ntx, int nty, int G, int ngroups,
-                                                         int lds_elems, int64_t nwg) {
+                                                         int lds_bytes, int64_t nwg) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  lds_acc_t *planes = reinterpret_cast<lds_acc_t *>(gfla_smem);
   __shared__ int s_box[4];
   const int64_t v = xcd_swizzle(blockIdx.x, nwg);
   const int g = (int)(v % ngroups);
@@ -296,92 +431,66 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
   const int HW = Hf * Wf, Wo = K * Wf;
   const int plane = Hs * Ws;
   const int64_t oplane = (int64_t)K * Hf * Wo;
+  const int p = active ? yf * Wf + xf : 0;
   box_init(s_box);
   __syncthreads();
-  // ---- per-pixel setup, once for the G channels
-  A fx0 = 0, fy0 = 0, ax[K];
-  int xL[K], xR[K], col[K + 1];
-  int x0 = 0, y0 = 0, y0c = 0;
-  bool dense = true;
-  int bylo = 0x7fffffff, bxlo = 0x7fffffff, byhi = -1, bxhi = -1;
-  const int p = active ? yf * Wf + xf : 0;
-  if (active) {
-    fx0 = Num<T>::ld(flow + (int64_t)(b * 2 + 0) * HW + p);
-    fy0 = Num<T>::ld(flow + (int64_t)(b * 2 + 1) * HW + p);
-  }
-#pragma unroll
-  for (int t = 0; t < K; ++t) {
-    const A dx = (fx0 + (A)(t - K / 2)) + (A)xf;
-    const A dy = (fy0 + (A)(t - K / 2)) + (A)yf;
-    const A fdx = floor_t<A>(dx), fdy = floor_t<A>(dy);
-    if (t == 0) {
-      x0 = (int)fdx;
-      y0 = (int)fdy;
-    }
-    dense = dense && ((int)fdx == x0 + t) && ((int)fdy == y0 + t);
-    xL[t] = clampi((int)fdx, 0, Ws - 1);
-    xR[t] = clampi((int)(fdx + 1), 0, Ws - 1);
-    ax[t] = dx - fdx;
-  }
+  BePixel<T, K> px;
+  px.init(flow + (int64_t)b * 2 * HW, HW, p, xf, yf, Hs, Ws, active);
   {
-    const int x0c = clampi(x0, -(K + 2), Ws + 1);
-    y0c = clampi(y0, -(K + 2), Hs + 1);
-#pragma unroll
-    for (int q = 0; q <= K; ++q) col[q] = clampi(x0c + q, 0, Ws - 1);
-    if (active) {  // one row / column of slack covers the taps of the non-dense case
-      bylo = clampi(y0c - 1, 0, Hs - 1), byhi = clampi(y0c + K + 1, 0, Hs - 1);
-      bxlo = clampi(x0c - 1, 0, Ws - 1), bxhi = clampi(x0c + K + 1, 0, Ws - 1);
-    }
+    int ylo, xlo, yhi, xhi;
+    px.reach(Hs, Ws, active, ylo, xlo, yhi, xhi);
+    box_reduce(s_box, ylo, xlo, yhi, xhi);
   }
-  if (NEED_SRC) box_reduce(s_box, bylo, bxlo, byhi, bxhi);
   __syncthreads();
-  const int ymin = s_box[0], xmin = s_box[1];
-  const int rows = s_box[2] - ymin + 1, cols = s_box[3] - xmin + 1;
-  const int win = NEED_SRC ? rows * cols : 1;   // (rows <= 0: a tile without pixels, impossible by construction)
-  const int g_fit = NEED_SRC ? min(gc, lds_elems / max(win, 1)) : gc;
+  const TileWin w = tile_window(s_box);
+  constexpr int kPerElem = (NEED_SRC ? (int)sizeof(lds_acc_t) : 0) + (NEED_FLOW ? (int)sizeof(A) : 0);
+  const int g_fit = min(gc, lds_bytes / max(w.size * kPerElem, 1));
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
   T *gsrc0 = NEED_SRC ? gsrc + ((int64_t)b * C + c0) * plane : nullptr;
   const T *gblk0 = gout + ((int64_t)b * C + c0) * oplane + (int64_t)(yf * K) * Wo + xf * K;
   A gx_acc = 0, gy_acc = 0;
   if (g_fit == 0) {
-    // the tile reaches further than one channel's window holds: global atomics for this tile
+    // the tile reaches further than one channel's window holds: global memory for this tile
     if (active) {
       for (int c = 0; c < gc; ++c) {
         BeGlobalSink<T> sink{gsrc0 + (int64_t)c * plane, Ws};
-        if (dense)
-          be_bwd_pixel_dense<T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, gblk0 + (int64_t)c * oplane, Wo, Hs, Ws,
-                                                        y0c, col, ax, fy0, yf, gx_acc, gy_acc);
+        if (px.dense)
+          be_bwd_pixel_dense<T, T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, Ws, gblk0 + (int64_t)c * oplane, Wo, Hs,
+                                                           px, yf, gx_acc, gy_acc);
         else
-          be_bwd_pixel_taps<T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, gblk0 + (int64_t)c * oplane, Wo, Hs, Ws,
-                                                       xL, xR, ax, fy0, yf, gx_acc, gy_acc);
+          be_bwd_pixel_taps<T, T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, Ws, gblk0 + (int64_t)c * oplane, Wo, Hs,
+                                                          px, yf, gx_acc, gy_acc);
       }
     }
   } else {
+    // LDS: [g_fit windows of double accumulators][g_fit windows of source values]
+    lds_acc_t *gplanes = reinterpret_cast<lds_acc_t *>(gfla_smem);
+    A *splanes = reinterpret_cast<A *>(gfla_smem + (NEED_SRC ? sizeof(lds_acc_t) * (size_t)g_fit * w.size : 0));
+    const int shift = w.ymin * w.cols + w.xmin;
     for (int cb = 0; cb < gc; cb += g_fit) {
       const int n = min(g_fit, gc - cb);
-      if (NEED_SRC) {
-        zero_planes<lds_acc_t>(planes, n * win);
-        __syncthreads();
-      }
+      if (NEED_SRC) zero_planes<lds_acc_t>(gplanes, n * w.size);
+      if (NEED_FLOW) stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, splanes, w, n);
+      __syncthreads();
       if (active) {
         for (int c = 0; c < n; ++c) {
-          BeWinSink<T> sink{planes + (size_t)c * win, cols, ymin, xmin};
-          const T *spl = src0 + (int64_t)(cb + c) * plane;
+          BeWinSink sink{gplanes + (size_t)c * w.size - shift, w.cols};
+          const A *spl = splanes + (size_t)c * w.size - shift;
           const T *gb = gblk0 + (int64_t)(cb + c) * oplane;
-          if (dense)
-            be_bwd_pixel_dense<T, K, NEED_SRC, NEED_FLOW>(sink, spl, gb, Wo, Hs, Ws, y0c, col, ax, fy0, yf, gx_acc, gy_acc);
+          if (px.dense)
+            be_bwd_pixel_dense<T, A, K, NEED_SRC, NEED_FLOW>(sink, spl, w.cols, gb, Wo, Hs, px, yf, gx_acc, gy_acc);
           else
-            be_bwd_pixel_taps<T, K, NEED_SRC, NEED_FLOW>(sink, spl, gb, Wo, Hs, Ws, xL, xR, ax, fy0, yf, gx_acc, gy_acc);
+            be_bwd_pixel_taps<T, A, K, NEED_SRC, NEED_FLOW>(sink, spl, w.cols, gb, Wo, Hs, px, yf, gx_acc, gy_acc);
         }
       }
+      __syncthreads();
       if (NEED_SRC) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < n * win; i += blockDim.x) {
-          const lds_acc_t val = planes[i];
+        for (int i = threadIdx.x; i < n * w.size; i += blockDim.x) {
+          const lds_acc_t val = gplanes[i];
           if (val != 0) {
-            const int c = i / win, e = i - c * win;
-            const int wr = e / cols, wc = e - wr * cols;
-            atomic_add(gsrc0 + (int64_t)(cb + c) * plane + (ymin + wr) * Ws + xmin + wc, (T)val);
+            const int c = i / w.size, e = i - c * w.size;
+            const int wr = e / w.cols, wc = e - wr * w.cols;
+            atomic_add(gsrc0 + (int64_t)(cb + c) * plane + (w.ymin + wr) * Ws + w.xmin + wc, (T)val);
           }
         }
         __syncthreads();
@@ -403,19 +512,15 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
   } else {
     if (Hs * Ws > 0x3fffffffLL || (int64_t)K * Hf * K * Wf > 0x7fffffffLL) return GFLA_OK;
     const TileGeo tg = tile_geometry(Hf, Wf);
-    int G = tuning(34) > 0 ? tuning(34) : 4;
-    // fewer channels per workgroup while the launch has under three workgroups per CU
-    while (G > 1 && B * tg.nty * tg.ntx * ceil_div(C, G) < 3 * kNumCU) G /= 2;
-    if (G > C) G = (int)C;
+    const int G = tile_channels(34, 8, B * tg.nty * tg.ntx, C);
     const int64_t ngroups = ceil_div(C, G);
     const int64_t nwg = B * tg.nty * tg.ntx * ngroups;
     if (nwg > 0x7fffffffLL) return GFLA_OK;
-    const unsigned lds_bytes = gsrc ? (unsigned)lds_budget() : 0u;
-    const int lds_elems = (int)(lds_bytes / sizeof(lds_acc_t));
+    const unsigned lds_bytes = (unsigned)lds_budget();
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \
-             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, lds_elems, nwg)
+             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg)
     if (gsrc && gflow) GFLA_BE_TILE_LAUNCH(true, true);
     else if (gsrc) GFLA_BE_TILE_LAUNCH(true, false);
     else GFLA_BE_TILE_LAUNCH(false, true);

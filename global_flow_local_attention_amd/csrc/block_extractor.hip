@@ -229,10 +229,10 @@ static int launch_fwd(const T *src, const T *flow, T *out, int64_t B, int64_t C,
       bool done = false;
       int st = GFLA_OK;
       switch (k) {
-        case 2: st = launch_fwd_gpix<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
-        case 3: st = launch_fwd_gpix<T, 3>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
-        case 4: st = launch_fwd_gpix<T, 4>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
-        default: st = launch_fwd_gpix<T, 5>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 2: st = launch_fwd_big<T, 2>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 3: st = launch_fwd_big<T, 3>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        case 4: st = launch_fwd_big<T, 4>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
+        default: st = launch_fwd_big<T, 5>(src, flow, out, B, C, Hs, Ws, Hf, Wf, stream, &done); break;
       }
       if (done) note_path(GFLA_PATH_BE_FWD_GPIX);
       if (done || st != GFLA_OK) return st;

@@ -538,6 +538,92 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_big_kernel(const T *__restrict
   }
 }
 
+// The gathers on LDS windows (second version; the global-gather kernels above stay as the per-tile fallback and under tuning
+// key 38 = 1: at (1,64,256,176) every per-tap wave load cost ~40 CU cycles on a smooth flow -- forward 42 us whatever the
+// channels per thread, profiles/r5_config2_first_kernels.txt): workgroup = (tile of th x tw pixels, G channels), one pixel per
+// thread with its taps in registers, the source planes staged into the bounding-box window of the tile's taps.
+// MODE 0 forward, MODE 2 d/d input2.
+template <typename T, int KH, int MODE>
+__global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
+                                                            const T *__restrict__ gout, T *__restrict__ outp, int C, int Hi,
+                                                            int Wi, int H, int W, int dil, int th, int tw, int ntx, int nty, int G,
+                                                            int ngroups, int lds_elems, int64_t nwg) {
+  using A = typename Num<T>::acc;
+  constexpr int N = 2 * KH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  A *planes = reinterpret_cast<A *>(gfla_smem);
+  __shared__ int s_box[4];
+  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
+  const int g = (int)(v % ngroups);
+  const int64_t rest = v / ngroups;
+  const int tile = (int)(rest % ((int64_t)ntx * nty)), b = (int)(rest / ((int64_t)ntx * nty));
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const int c0 = g * G, gc = min(G, C - c0);
+  const int ly = threadIdx.x / tw, lx = threadIdx.x - ly * tw;
+  const int y = ty * th + ly, x = tx * tw + lx;
+  const bool active = ly < th && y < H && x < W;
+  const int HW = H * W, plane_sz = Hi * Wi;
+  const int p = active ? y * W + x : 0;
+  box_init(s_box);
+  __syncthreads();
+  Taps<A, KH> t;   // rows as INDICES (pitch 1) until the window is known
+  {
+    const T *i2 = in2 + (int64_t)b * 3 * HW + p;
+    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false, 1);
+  }
+  box_reduce(s_box, active ? t.row_off(0) : 0x7fffffff, active ? t.col_off(0) : 0x7fffffff, active ? t.row_off(N - 1) : -1,
+             active ? t.col_off(N - 1) : -1);
+  __syncthreads();
+  const TileWin w = tile_window(s_box);
+  const int g_fit = min(gc, lds_elems / max(w.size, 1));
+  const int pitch = g_fit == 0 ? Wi : w.cols;
+#pragma unroll
+  for (int f = 0; f < KH; ++f) {
+    t.yT[f] *= pitch;
+    t.yB[f] *= pitch;
+  }
+  const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
+  const T *go0 = MODE == 2 ? gout + ((int64_t)b * C + c0) * HW + p : nullptr;
+  A rx = 0, ry = 0, rs = 0;
+  if (g_fit == 0) {   // the tile reaches further than one channel's window holds: global memory for this tile
+    if (active) {
+      if constexpr (MODE == 0) rs_fwd_pixel<T, T, KH, A>(t, in1_0, plane_sz, outp + ((int64_t)b * C + c0) * HW + p, HW, gc);
+      else rs_bwd2_pixel<T, T, KH, A>(t, in1_0, plane_sz, go0, HW, gc, rx, ry, rs);
+    }
+  } else {
+    const A *win0 = planes - (w.ymin * w.cols + w.xmin);
+    for (int cb = 0; cb < gc; cb += g_fit) {
+      const int n = min(g_fit, gc - cb);
+      stage_windows<T, A>(in1_0 + (int64_t)cb * plane_sz, plane_sz, Wi, planes, w, n);
+      __syncthreads();
+      if (active) {
+        if constexpr (MODE == 0) {
+          rs_fwd_pixel<T, A, KH, A>(t, win0, w.size, outp + ((int64_t)b * C + c0 + cb) * HW + p, HW, n);
+        } else {   // linear in the channel sums: rounds combine by addition
+          A ax_, ay_, as_;
+          rs_bwd2_pixel<T, A, KH, A>(t, win0, w.size, go0 + (int64_t)cb * HW, HW, n, ax_, ay_, as_);
+          rx += ax_, ry += ay_, rs += as_;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (MODE == 2) {
+    if (active) {
+      T *o = outp + (int64_t)b * 3 * HW + p;
+      if (ngroups == 1) {  // sole writer of this pixel
+        o[0] = Num<T>::from(Num<T>::ld(o) + rx);
+        o[HW] = Num<T>::from(Num<T>::ld(o + HW) + ry);
+        o[2 * HW] = Num<T>::from(Num<T>::ld(o + 2 * HW) + rs);
+      } else {
+        atomic_add(o, (T)rx);
+        atomic_add(o + HW, (T)ry);
+        atomic_add(o + 2 * HW, (T)rs);
+      }
+    }
+  }
+}
+
 // d/d input1 is a SCATTER: workgroup = (tile of th x tw pixels, G channels), one pixel per thread with its taps kept in
 // registers.  The gradient planes are accumulated in an LDS window = the bounding box of the tile's taps (from the flow, on
 // the device), 64-bit fixed point for float (ds_add_u64, order-independent; lds_plane.h) / double planes for double, in as
@@ -659,6 +745,15 @@ static Geo geometry(int64_t B, int64_t C, int64_t H, int64_t W, int max_cpt, int
   return g;
 }
 
+// channels per workgroup of a tile kernel: `dflt` (tuning key `key` overrides) unless that leaves the launch under three
+// workgroups per CU
+static int rs_tile_channels(int key, int dflt, int64_t tiles, int64_t C) {
+  int G = tuning(key) > 0 ? tuning(key) : dflt;
+  if (tuning(key) <= 0)
+    while (G > 1 && tiles * ceil_div(C, G) < 3 * kNumCU) G /= 2;
+  return G > C ? (int)C : G;
+}
+
 // big-plane gathers: channels per thread -- all of them unless that leaves fewer than `want` waves (tuning key 33)
 static int big_cpt(int64_t B, int64_t C, int64_t nsp, int64_t want) {
   if (tuning(33) > 0) return tuning(33) < C ? tuning(33) : (int)C;
@@ -695,6 +790,17 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   using A = typename Num<T>::acc;
   if (tuning(6) != 1 && big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(A), lds_budget())) {
     // few planes far beyond the LDS budget (BASELINE configs[1]): one tap setup per pixel and chunk of channels, global gathers
+    if (tuning(38) != 1 && sizeof(T) >= 4 && Hi * Wi <= 0x3fffffffLL) {   // planes staged into bounding-box windows
+      const TileGeo tg = tile_geometry(H, W);
+      const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
+      const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+      if (nwg <= 0x7fffffffLL) {
+        const unsigned lds_bytes = (unsigned)lds_budget();
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
+        note_path(GFLA_PATH_RS_FWD_BIG);
+        return launch_status();
+      }
+    }
     const int64_t nsp = ceil_div(H * W, kBlock);
     const int cpt = big_cpt(B, C, nsp, 20 * kNumCU);
     const int64_t ncg = ceil_div(C, cpt), nwg = B * nsp * ncg;
@@ -742,9 +848,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
           trunc &= ~2;
         }
         const TileGeo tg = tile_geometry(H, W);
-        int G = tuning(34) > 0 ? tuning(34) : 4;
-        while (G > 1 && B * tg.nty * tg.ntx * ceil_div(C, G) < 3 * kNumCU) G /= 2;
-        if (G > C) G = (int)C;
+        const int G = rs_tile_channels(34, 8, B * tg.nty * tg.ntx, C);
         const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
         const unsigned lds_bytes = (unsigned)lds_budget();
@@ -754,7 +858,16 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         st = launch_status();
         if (st != GFLA_OK) return st;
       }
-      if (gin2) {
+      if (gin2 && tuning(38) != 1) {
+        const TileGeo tg = tile_geometry(H, W);
+        const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
+        const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+        if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+        const unsigned lds_bytes = (unsigned)lds_budget();
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
+        note_path(GFLA_PATH_RS_BWD2_BIG);
+        st = launch_status();
+      } else if (gin2) {
         const int64_t nsp = ceil_div(H * W, kBlock);
         const int cpt = big_cpt(B, C, nsp, 20 * kNumCU);
         const int64_t ncg = ceil_div(C, cpt), nwg = B * nsp * ncg;

@@ -48,6 +48,33 @@ __device__ __forceinline__ void box_reduce(int *box, int ylo, int xlo, int yhi, 
   }
 }
 
+// The LDS window of a tile: the bounding box [ymin, ymin + rows) x [xmin, xmin + cols) of the plane positions its pixels
+// reach; element (y, x) of channel slot c lives at c * size + (y - ymin) * cols + (x - xmin).
+struct TileWin {
+  int ymin, xmin, rows, cols, size;
+};
+__device__ __forceinline__ TileWin tile_window(const int *box) {
+  TileWin w;
+  w.ymin = box[0];
+  w.xmin = box[1];
+  w.rows = box[2] - box[0] + 1;
+  w.cols = box[3] - box[1] + 1;
+  w.size = w.rows * w.cols;
+  return w;
+}
+// global planes (row pitch Ws, `plane` elements apart) -> the windows of n channel slots; a wave per window row, lanes along
+// the row (coalesced segments of `cols` elements)
+template <typename T, typename A>
+__device__ __forceinline__ void stage_windows(const T *__restrict__ src0, int64_t plane, int Ws, A *lds, const TileWin &w, int n) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  for (int rr = wave; rr < n * w.rows; rr += nw) {
+    const int c = rr / w.rows, r = rr - c * w.rows;
+    const T *g = src0 + (int64_t)c * plane + (int64_t)(w.ymin + r) * Ws + w.xmin;
+    A *d = lds + (size_t)c * w.size + r * w.cols;
+    for (int q = lane; q < w.cols; q += 64) d[q] = Num<T>::ld(g + q);
+  }
+}
+
 // Host side: is this the regime of the big-plane kernels?  Few planes (the planes-in-LDS / windowed kernels get fewer
 // than ~4 workgroups per CU out of batch x channel groups) AND planes beyond the LDS budget.  tuning key 30: 1 = never
 // (round 1's windowed kernels), 2 = always (tests drive the kernels at small shapes).
@@ -71,6 +98,26 @@ inline TileGeo tile_geometry(int64_t H, int64_t W) {
   const int ntx = (int)ceil_div(W, tw);
   tw = (int)ceil_div(W, ntx);
   int th = tuning(31) > 0 ? tuning(31) : 16;
+  if (th * tw > 512) th = 512 / tw;
+  if (th > H) th = (int)H;
+  if (th < 1) th = 1;
+  g.th = th;
+  g.tw = tw;
+  g.ntx = ntx;
+  g.nty = (int)ceil_div(H, th);
+  g.threads = (int)ceil_div((int64_t)th * tw, 64) * 64;
+  return g;
+}
+
+// Gather tiles of block_extractor's forward: whole flow rows when a row fits a workgroup (the K*th output rows of a
+// channel are then ONE contiguous piece of the output plane per workgroup), else th x tw.  tuning keys 35 / 36.
+inline TileGeo row_tile_geometry(int64_t H, int64_t W) {
+  TileGeo g;
+  int tw = tuning(36) > 0 ? tuning(36) : (W <= 512 ? (int)W : 32);
+  if (tw > W) tw = (int)W;
+  const int ntx = (int)ceil_div(W, tw);
+  tw = (int)ceil_div(W, ntx);
+  int th = tuning(35) > 0 ? tuning(35) : (tw >= 256 ? 1 : 384 / tw);
   if (th * tw > 512) th = 512 / tw;
   if (th > H) th = (int)H;
   if (th < 1) th = 1;

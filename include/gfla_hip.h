@@ -85,8 +85,9 @@ const char *gfla_status_string(int status);
  *           on maps whose tile rows fill at most half a unit (csrc/fc_wino.hip: MR)
  *   key 30: big-plane kernels (few planes, each beyond the LDS budget: csrc/tile_map.h)   0 auto, 1 never (round 1's
  *           row-window kernels), 2 always (tests drive them at small shapes)
- *   key 31 / 32: rows / columns of a scatter tile (0 auto: 16 x 32)   key 33: channels per wave of the gather kernels
- *   key 34: channels per workgroup of the scatter tiles (0 auto: 4)
+ *   key 31 / 32: rows / columns of a tile (0 auto: 16 x 32)   key 35 / 36: the same for block_extractor's forward (0 auto:
+ *           whole flow rows)   key 34 / 37: channels per workgroup of the scatter / gather tiles (0 auto: 8 / 8-16)
+ *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
 
