@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
   }
   __syncthreads();
   const TileWin w = tile_window(s_box);
-  const int g_fit = min(gc, lds_elems / max(w.size, 1));
+  const int g_fit = window_worth_staging(w, th, tw) ? min(gc, lds_elems / max(w.size, 1)) : 0;
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
   T *out0 = out + ((int64_t)b * C + c0) * oplane + (int64_t)(K * yf) * Wo + K * xf;
   if (g_fit == 0) {   // the tile reaches further than one channel's window holds: its patches come from global memory
@@ -290,7 +290,7 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
   const int G = tile_channels(37, 8, B * tg.nty * tg.ntx, C);
   const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
   if (nwg > 0x7fffffffLL) return GFLA_OK;
-  const unsigned lds_bytes = (unsigned)lds_budget();
+  const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, K + 1, G, (int)sizeof(A), lds_budget());
   launch_lds(be_fwd_tile_kernel<T, K, CH>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C,
              (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg);
   *done = true;
@@ -485,14 +485,7 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
       }
       __syncthreads();
       if (NEED_SRC) {
-        for (int i = threadIdx.x; i < n * w.size; i += blockDim.x) {
-          const lds_acc_t val = gplanes[i];
-          if (val != 0) {
-            const int c = i / w.size, e = i - c * w.size;
-            const int wr = e / w.cols, wc = e - wr * w.cols;
-            atomic_add(gsrc0 + (int64_t)(cb + c) * plane + (w.ymin + wr) * Ws + w.xmin + wc, (T)val);
-          }
-        }
+        flush_windows<T>(gsrc0 + (int64_t)cb * plane, plane, Ws, w, n, [gplanes](int i) { return (double)gplanes[i]; });
         __syncthreads();
       }
     }
@@ -516,7 +509,7 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
     const int64_t ngroups = ceil_div(C, G);
     const int64_t nwg = B * tg.nty * tg.ntx * ngroups;
     if (nwg > 0x7fffffffLL) return GFLA_OK;
-    const unsigned lds_bytes = (unsigned)lds_budget();
+    const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, K + 1, G, (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(typename Num<T>::acc) : 0), lds_budget());
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict
              active ? t.col_off(N - 1) : -1);
   __syncthreads();
   const TileWin w = tile_window(s_box);
-  const int g_fit = min(gc, lds_elems / max(w.size, 1));
+  const int g_fit = window_worth_staging(w, th, tw) ? min(gc, lds_elems / max(w.size, 1)) : 0;
   const int pitch = g_fit == 0 ? Wi : w.cols;
 #pragma unroll
   for (int f = 0; f < KH; ++f) {
@@ -715,16 +715,15 @@ __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__
         rs_bwd1_apply<T, PT, N, A, LdsPlane>(ro, co, qy, wx, go, HW, planes, win, n, (A)1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n * win; i += blockDim.x) {
-      const PT raw = planes[i];
-      if (raw != 0) {
-        const int c = i / win, e = i - c * win;
-        const int wr = e / cols, wc = e - wr * cols;
-        double val;
-        if constexpr (FIX) val = fix.finite ? (double)raw * fix.down : __longlong_as_double(0x7ff8000000000000ll);
-        else val = raw;
-        atomic_add(gin0 + (int64_t)(cb + c) * plane_sz + (ymin + wr) * Wi + xmin + wc, (T)val);
-      }
+    {
+      const TileWin w{ymin, xmin, rows, cols, win};
+      const double down = fix.finite ? fix.down : __longlong_as_double(0x7ff8000000000000ll);
+      const bool finite = fix.finite;
+      flush_windows<T>(gin0 + (int64_t)cb * plane_sz, plane_sz, Wi, w, n, [=](int i) {
+        const PT raw = planes[i];
+        if constexpr (FIX) return raw == 0 ? 0.0 : (finite ? (double)raw * down : down);
+        else return (double)raw;
+      });
     }
     __syncthreads();
   }
@@ -795,7 +794,7 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
       const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
       const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
       if (nwg <= 0x7fffffffLL) {
-        const unsigned lds_bytes = (unsigned)lds_budget();
+        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
         note_path(GFLA_PATH_RS_FWD_BIG);
         return launch_status();
@@ -851,7 +850,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         const int G = rs_tile_channels(34, 8, B * tg.nty * tg.ntx, C);
         const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-        const unsigned lds_bytes = (unsigned)lds_budget();
+        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, 8, lds_budget());
         constexpr bool FIX = std::is_same<A, float>::value;
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg));
         note_path(GFLA_PATH_RS_BWD1_TILE);
@@ -863,7 +862,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
         const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-        const unsigned lds_bytes = (unsigned)lds_budget();
+        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
         note_path(GFLA_PATH_RS_BWD2_BIG);
         st = launch_status();

@@ -63,16 +63,62 @@ __device__ __forceinline__ TileWin tile_window(const int *box) {
   return w;
 }
 // global planes (row pitch Ws, `plane` elements apart) -> the windows of n channel slots; a wave per window row, lanes along
-// the row (coalesced segments of `cols` elements)
+// the row (coalesced segments of `cols` elements).  EIGHT rows per wave are requested before the first is stored: written
+// as load -> store per row the loop keeps one request in flight per wave, and a workgroup then spends its life waiting for
+// ~30 dependent round trips (measured: the first window kernels were SLOWER than the global gathers they replaced,
+// profiles/r5_config2_window_kernels_unpipelined_staging.txt).
 template <typename T, typename A>
 __device__ __forceinline__ void stage_windows(const T *__restrict__ src0, int64_t plane, int Ws, A *lds, const TileWin &w, int n) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int total = n * w.rows;
+  for (int q = lane; q < w.cols; q += 64) {
+    for (int rr0 = wave; rr0 < total; rr0 += nw * U) {
+      A v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = min(rr0 + u * nw, total - 1);   // (clamped: a repeated load, no branch between the requests)
+        const int c = rr / w.rows, r = rr - c * w.rows;
+        v[u] = Num<T>::ld(src0 + (int64_t)c * plane + (int64_t)(w.ymin + r) * Ws + w.xmin + q);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = rr0 + u * nw;
+        if (rr < total) {
+          const int c = rr / w.rows, r = rr - c * w.rows;
+          lds[(size_t)c * w.size + r * w.cols + q] = v[u];
+        }
+      }
+    }
+  }
+}
+// the windows of n channel slots -> atomics into the global planes; val(i) = the value of window element i (0 = untouched:
+// no atomic).  A wave per window row, lanes along the row.
+template <typename T, typename F>
+__device__ __forceinline__ void flush_windows(T *__restrict__ g0, int64_t plane, int Ws, const TileWin &w, int n, F val) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   for (int rr = wave; rr < n * w.rows; rr += nw) {
     const int c = rr / w.rows, r = rr - c * w.rows;
-    const T *g = src0 + (int64_t)c * plane + (int64_t)(w.ymin + r) * Ws + w.xmin;
-    A *d = lds + (size_t)c * w.size + r * w.cols;
-    for (int q = lane; q < w.cols; q += 64) d[q] = Num<T>::ld(g + q);
+    const int base = c * w.size + r * w.cols;
+    T *grow = g0 + (int64_t)c * plane + (int64_t)(w.ymin + r) * Ws + w.xmin;
+    for (int q = lane; q < w.cols; q += 64) {
+      const double v = val(base + q);
+      if (v != 0) atomic_add(grow + q, (T)v);
+    }
   }
+}
+// A gather tile whose bounding box is many times its own area (wild flow) is not worth staging: each staged element would
+// be read less than once.  Such a tile reads global memory.
+__device__ __forceinline__ bool window_worth_staging(const TileWin &w, int th, int tw) { return w.size <= 6 * th * tw + 512; }
+
+// LDS a tile kernel asks for: G windows of the tile plus `span` taps and a flow reach of 8 positions either side -- not
+// the whole budget, so that several workgroups share a CU and one's staging overlaps another's arithmetic (a tile that
+// reaches further takes more channel rounds; correctness never depends on this estimate).
+inline unsigned tile_lds_request(int th, int tw, int span, int G, int bytes_per_elem, int64_t budget) {
+  int64_t want = (int64_t)(th + span + 16) * (tw + span + 16) * G * bytes_per_elem;
+  if (want < 16 * 1024) want = 16 * 1024;
+  if (want > budget) want = budget;
+  return (unsigned)((want + 255) & ~(int64_t)255);
 }
 
 // Host side: is this the regime of the big-plane kernels?  Few planes (the planes-in-LDS / windowed kernels get fewer

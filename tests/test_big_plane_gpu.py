@@ -28,6 +28,24 @@ def _flow(kind, B, H, W, seed):
     return flow_of(kind, B, H, W, seed) if kind in KINDS else make_flow(kind, B, H, W, seed=seed)
 
 
+def floor_mismatch(f, k):
+    """(B,H,W) mask of the flow pixels where a float32 and a float64 evaluation of (flow + offset) + index
+    (block_extractor_kernel.cu:62-67) floor DIFFERENTLY: the float32 sum rounds onto an integer the exact value lies just
+    below.  The forward value is continuous there, d/dflow is one-sided -- a float32 kernel and the float64 reference take
+    different sides, legitimately (measured on the smooth flow of this file: 2 of 45 056 pixels, a flow component within
+    2^-22 of -2.0 and of -1.0; every kernel of this library, round 1's included, agrees with the others there)."""
+    B, _, H, W = f.shape
+    ys, xs = torch.arange(H).view(1, H, 1), torch.arange(W).view(1, 1, W)
+    bad = torch.zeros(B, H, W, dtype=torch.bool)
+    for t in range(k):
+        o = float(t - k // 2)
+        for ch, idx in ((0, xs), (1, ys)):
+            c32 = (f[:, ch].float() + o) + idx.float()
+            c64 = (f[:, ch].double() + o) + idx.double()
+            bad |= torch.floor(c32).double() != torch.floor(c64)
+    return bad
+
+
 # ------------------------------------------------------------------------------------------ 1. the configuration itself
 @pytest.mark.parametrize("kind", ("smooth", "zero") + KINDS)
 @pytest.mark.parametrize("k", [3, 5])
@@ -47,7 +65,13 @@ def test_config2_block_extractor_all_flows_vs_reference_kernels(gfla, k, kind):
     sr, fr = s.to(dt).to(DEV), f.to(dt).to(DEV)
     want = ref.block_extractor_fwd(sr, fr, k)
     gs, gf = ref.block_extractor_bwd(sr, fr, up.to(dt), k)
-    errs = (("out", rel_err(out, want)), ("grad source", rel_err(sd.grad, gs)), ("grad flow", rel_err(fd.grad, gf)))
+    got_gf = fd.grad.detach().clone()
+    if dt == torch.float64:   # pixels whose coordinate floors differently in float32: one-sided derivative, other side
+        bad = floor_mismatch(f, k)
+        assert bad.sum().item() <= 0.002 * bad.numel(), "too many float32 / float64 floor mismatches to call them exceptions"
+        keep = (~bad).unsqueeze(1).to(DEV)
+        got_gf, gf = got_gf * keep, gf * keep
+    errs = (("out", rel_err(out, want)), ("grad source", rel_err(sd.grad, gs)), ("grad flow", rel_err(got_gf, gf)))
     print("config2 block_extractor k%d %s: " % (k, kind) + " ".join("%s %.2e" % e for e in errs))
     assert (out.detach().double() - want.double()).abs().max().item() <= 1e-4        # the north star's own bar, absolute
     for n, e in errs:

@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--flows", default="smooth,zero,wild,integer,near_integer,oob")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--split", action="store_true", help="also time each gradient of the backward calls alone")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     for kv in filter(None, a.tuning.split(",")):
         gfla.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
-    res = bench.config2_ops(torch.device("cuda", 0), iters=a.iters, flows=tuple(a.flows.split(",")), with_ref=not a.no_ref)
+    res = bench.config2_ops(torch.device("cuda", 0), iters=a.iters, flows=tuple(a.flows.split(",")), with_ref=not a.no_ref, split=a.split)
     lines = [json.dumps(dict(r, tag=a.tag, tuning=a.tuning)) for r in res["rows"]]
     for ln in lines:
         print(ln, flush=True)
