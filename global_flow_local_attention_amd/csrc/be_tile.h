@@ -22,6 +22,7 @@
 #pragma once
 
 #include "be_fwd_pix.h"
+#include "pin_regs.h"
 #include "tile_map.h"
 
 namespace gfla {
@@ -34,32 +35,50 @@ __device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const int
                                                    const typename Num<T>::acc (&ay)[K], T *__restrict__ oc0, int64_t oplane, int Wo,
                                                    bool active) {
   using A = typename Num<T>::acc;
+  // no lane of the wave has a patch column clamped at the border: a patch row is base + 0..K (immediate offsets, pairs)
+  const bool contiguous = __all(col[K] - col[0] == K);
   // the bilinear form separated (be_fwd_wrow.h has the derivation): patch rows interpolated along x once, output row i = the
-  // blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand
-  auto hrow = [&](int cc, int r, A (&h)[K]) {
-    const P *pc = row(min(cc, ncc - 1), r);
-    A vv[K + 1];
+  // blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand.  A patch row of ALL CH
+  // channels is requested at once (pin_regs.h), then interpolated.
+  auto hrows = [&](int r, A (&h)[CH][K]) {
+    A vv[CH * (K + 1)];
+    if (contiguous) {
 #pragma unroll
-    for (int q = 0; q <= K; ++q) vv[q] = Num<P>::ld(pc + col[q]);
+      for (int cc = 0; cc < CH; ++cc) {
+        const P *p0 = row(min(cc, ncc - 1), r) + col[0];
 #pragma unroll
-    for (int j = 0; j < K; ++j) h[j] = fma_t(ax[j], vv[j + 1], (1 - ax[j]) * vv[j]);
+        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(p0 + q);
+      }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const P *pc = row(min(cc, ncc - 1), r);
+#pragma unroll
+        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(pc + col[q]);
+      }
+    }
+    pin_regs(vv);
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        h[cc][j] = fma_t(ax[j], vv[cc * (K + 1) + j + 1], (1 - ax[j]) * vv[cc * (K + 1) + j]);
   };
   A hA[CH][K];
-#pragma unroll
-  for (int cc = 0; cc < CH; ++cc) hrow(cc, 0, hA[cc]);
+  hrows(0, hA);
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const A yB_P = ay[i], yT_P = 1 - yB_P;
+    A hB[CH][K];
+    hrows(i + 1, hB);
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
-      A hB[K];
-      hrow(cc, i + 1, hB);
       T o[K];
 #pragma unroll
-      for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[j], yT_P * hA[cc][j]));
+      for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
       if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
 #pragma unroll
-      for (int j = 0; j < K; ++j) hA[cc][j] = hB[j];
+      for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
     }
   }
 }
@@ -335,14 +354,23 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__
     const A dy = (px.fy0 + (A)(i - K / 2)) + (A)yf;  // block_extractor_kernel.cu:132-136
     const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
     const int rB = clampi(px.y0c + i + 1, 0, Hs - 1);
-    A gv[K];
+    // this row's K incoming gradients and (for d/dflow) the next patch row, requested together (pin_regs.h)
+    A ld_[NEED_FLOW ? 2 * K + 1 : K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) gv[j] = Num<T>::ld(gblk + i * Wo + j);
-    A rowB[K + 1], vB[K + 1];
+    for (int j = 0; j < K; ++j) ld_[j] = Num<T>::ld(gblk + i * Wo + j);
+    if constexpr (NEED_FLOW) {
+#pragma unroll
+      for (int q = 0; q <= K; ++q) ld_[K + q] = (A)Num<P>::ld(spl + rB * spitch + px.col[q]);
+    }
+    pin_regs(ld_);
+    A gv[K], rowB[K + 1], vB[K + 1];
+#pragma unroll
+    for (int j = 0; j < K; ++j) gv[j] = ld_[j];
 #pragma unroll
     for (int q = 0; q <= K; ++q) {
       rowB[q] = 0;
-      vB[q] = NEED_FLOW ? (A)Num<P>::ld(spl + rB * spitch + px.col[q]) : (A)0;
+      if constexpr (NEED_FLOW) vB[q] = ld_[K + q];
+      else vB[q] = 0;
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {

@@ -53,31 +53,65 @@ struct LdsFixPlane {  // fixed-point planes (lds_plane.h): the caller pre-scales
 // the taps is evaluated separably: 2*KH row/column weights in registers instead of (2*KH)^2 products.
 
 // forward: `nch` channels, planes `plane_sz` apart starting at `plane`, outputs `ostride` apart.
+// Round 5: the N x N taps of a channel are REQUESTED TOGETHER, then combined (written as a running sum over loads hipcc
+// emitted ds_read -> s_waitcnt lgkmcnt(0) -> fma sixteen times per channel: the loop was one LDS round trip per tap); where
+// no lane of the wave has a tap column clamped at the border the taps of a row are base + 0..N-1 (immediate offsets, read
+// in pairs); SAFE_DIV(val, sum) (:93) is a multiplication by the reciprocal formed once per pixel (the float AND the double
+// division of the macro sat in the channel loop) -- an ulp of the result.
 template <typename T, typename PT, int KH, typename A>
 __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__restrict__ plane, int64_t plane_sz,
                                              T *__restrict__ o, int64_t ostride, int nch) {
   constexpr int N = 2 * KH;
   int ro[N], co[N];
   A wy[N], wx[N];
+  bool consecutive = true;
 #pragma unroll
   for (int r = 0; r < N; ++r) {
     ro[r] = t.row_off(r);
     co[r] = t.col_off(r);
     wy[r] = t.row_w(r);
     wx[r] = t.col_w(r);
+    consecutive = consecutive && co[r] == co[0] + r;
   }
-  for (int c = 0; c < nch; ++c) {
+  const A inv = (t.sum == 0) ? (A)(1.0 / kEps) : (A)1 / t.sum;
+  auto combine = [&](const A (&v)[N][N]) {
     A val = 0;  // resample2d_kernel.cu:85-88: sum_r wy[r] * sum_q wx[q] * v[r][q]
 #pragma unroll
     for (int r = 0; r < N; ++r) {
       A rowacc = 0;
 #pragma unroll
-      for (int q = 0; q < N; ++q) rowacc += wx[q] * Num<PT>::ld(plane + ro[r] + co[q]);
+      for (int q = 0; q < N; ++q) rowacc += wx[q] * v[r][q];
       val += wy[r] * rowacc;
     }
-    *o = Num<T>::from((A)safe_div<A>(val, t.sum));  // :93
-    plane += plane_sz;
-    o += ostride;
+    return val * inv;
+  };
+  if (__all(consecutive)) {
+    const PT *base = plane + co[0];
+    for (int c = 0; c < nch; ++c) {
+      A v[N][N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const PT *rp = base + ro[r];
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[r][q] = Num<PT>::ld(rp + q);
+      }
+      pin_taps<A, N>(v);   // every request above, every use below
+      *o = Num<T>::from(combine(v));
+      base += plane_sz;
+      o += ostride;
+    }
+  } else {
+    for (int c = 0; c < nch; ++c) {
+      A v[N][N];
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[r][q] = Num<PT>::ld(plane + ro[r] + co[q]);
+      pin_taps<A, N>(v);
+      *o = Num<T>::from(combine(v));
+      plane += plane_sz;
+      o += ostride;
+    }
   }
 }
 
@@ -230,10 +264,31 @@ __device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__
     wx[r] = t.col_w(r);
   }
   A Racc[N], Cacc[N];
+  bool consecutive = true;
 #pragma unroll
-  for (int r = 0; r < N; ++r) Racc[r] = Cacc[r] = 0;
+  for (int r = 0; r < N; ++r) {
+    Racc[r] = Cacc[r] = 0;
+    consecutive = consecutive && co[r] == co[0] + r;
+  }
+  const bool fast = __all(consecutive);   // no lane's tap columns clamped: row taps are base + 0..N-1
+  // (round 5: a channel's taps and its gradient are requested together, see rs_fwd_pixel)
   for (int c = 0; c < nch; ++c) {
     const A go = Num<T>::ld(g);
+    A v[N][N];
+    if (fast) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const PT *rp = plane + ro[r] + co[0];
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[r][q] = Num<PT>::ld(rp + q);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[r][q] = Num<PT>::ld(plane + ro[r] + co[q]);
+    }
+    pin_taps<A, N>(v);   // every request above, every use below
     A cs[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) cs[q] = 0;
@@ -242,9 +297,8 @@ __device__ __forceinline__ void rs_bwd2_pixel(const Taps<A, KH> &t, const PT *__
       A rsum = 0;
 #pragma unroll
       for (int q = 0; q < N; ++q) {
-        const A v = Num<PT>::ld(plane + ro[r] + co[q]);
-        rsum += wx[q] * v;
-        cs[q] += wy[r] * v;
+        rsum += wx[q] * v[r][q];
+        cs[q] += wy[r] * v[r][q];
       }
       Racc[r] += go * rsum;
     }

@@ -89,6 +89,22 @@ struct Taps {
   }
 };
 
+// "All of these values are needed HERE": an empty asm that takes the taps of a channel as read-write register operands.
+// hipcc otherwise sinks each LDS / global load down to its first use -- the channel loop of the forward then reads
+// ds_read -> s_waitcnt lgkmcnt(0) -> fma, sixteen round trips per channel (seen in the ISA, round 5); with the pin the
+// sixteen requests are issued back to back and waited for once.  kernel_size 4 / 5 (the reference's production
+// configuration) only: an asm statement takes at most 30 operands.
+template <typename A, int N>
+__device__ __forceinline__ void pin_taps(A (&v)[N][N]) {
+  if constexpr (N == 4) {
+    asm volatile("" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]),
+                      "+v"(v[1][3]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]), "+v"(v[3][0]), "+v"(v[3][1]),
+                      "+v"(v[3][2]), "+v"(v[3][3]));
+  } else if constexpr (N == 2) {
+    asm volatile("" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]));
+  }
+}
+
 // resample2d d/d input2 (kernel_size 4, dilation 1, f32 / bf16 storage) on the aggregation's streaming machinery
 // (local_attn_aggregate.hip); GFLA_ERR_UNSUPPORTED where the shape does not fit it
 template <typename T>

@@ -111,11 +111,11 @@ __device__ __forceinline__ void flush_windows(T *__restrict__ g0, int64_t plane,
 // be read less than once.  Such a tile reads global memory.
 __device__ __forceinline__ bool window_worth_staging(const TileWin &w, int th, int tw) { return w.size <= 6 * th * tw + 512; }
 
-// LDS a tile kernel asks for: G windows of the tile plus `span` taps and a flow reach of 8 positions either side -- not
+// LDS a tile kernel asks for: G windows of the tile plus `span` taps and a flow reach of 4 positions either side -- not
 // the whole budget, so that several workgroups share a CU and one's staging overlaps another's arithmetic (a tile that
 // reaches further takes more channel rounds; correctness never depends on this estimate).
 inline unsigned tile_lds_request(int th, int tw, int span, int G, int bytes_per_elem, int64_t budget) {
-  int64_t want = (int64_t)(th + span + 16) * (tw + span + 16) * G * bytes_per_elem;
+  int64_t want = (int64_t)(th + span + 8) * (tw + span + 8) * G * bytes_per_elem;
   if (want < 16 * 1024) want = 16 * 1024;
   if (want > budget) want = budget;
   return (unsigned)((want + 255) & ~(int64_t)255);
