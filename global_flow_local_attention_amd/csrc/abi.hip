@@ -6,7 +6,7 @@
 namespace gfla {
 // PROCESS-global: torch runs the backward of a GPU autograd Function on the engine's per-device worker thread and
 // nn.DataParallel runs replicas on worker threads, so a per-thread table would silently drop the caller's choice there.
-constexpr int kTuningKeys = 40;
+constexpr int kTuningKeys = 64;
 static std::atomic<int> g_tuning[kTuningKeys];
 int tuning(int key) { return (key >= 0 && key < kTuningKeys) ? g_tuning[key].load(std::memory_order_relaxed) : 0; }
 

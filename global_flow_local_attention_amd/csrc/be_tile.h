@@ -233,9 +233,10 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
     box_reduce(s_box, ylo, xlo, yhi, xhi);
   }
   __syncthreads();
-  const TileWin w = tile_window(s_box);
-  const int g_fit = window_worth_staging(w, th, tw) ? min(gc, lds_elems / max(w.size, 1)) : 0;
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
+  const bool vec = window_vec_ok(src0, plane, Ws);
+  const TileWin w = tile_window_vec(s_box, Ws, vec);
+  const int g_fit = window_worth_staging(w, th, tw) ? min(gc, lds_elems / max(w.size, 1)) : 0;
   T *out0 = out + ((int64_t)b * C + c0) * oplane + (int64_t)(K * yf) * Wo + K * xf;
   if (g_fit == 0) {   // the tile reaches further than one channel's window holds: its patches come from global memory
     if (px.dense) {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
   const A *win0 = planes - (w.ymin * w.cols + w.xmin);   // (plane row, plane column) -> win0[row * cols + column]
   for (int cb = 0; cb < gc; cb += g_fit) {
     const int n = min(g_fit, gc - cb);
-    stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, planes, w, n);
+    stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, planes, w, n, vec);
     __syncthreads();
     if (px.dense) {
       for (int cc0 = 0; cc0 < n; cc0 += CH) {
@@ -291,7 +292,7 @@ template <typename T, int K>
 static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
                           int64_t Wf, hipStream_t stream, bool *done) {
   using A = typename Num<T>::acc;
-  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 5 ? 2 : 4);
+  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 3 ? 2 : 4);   // (K = 3: 4 -> 2 measured 28.4 -> 27.2 us)
   *done = false;
   if (Hs * Ws > 0x3fffffffLL) return GFLA_OK;
   if (tuning(38) == 1) {   // first version: global gathers, lane = pixel, four channel ranges per workgroup
@@ -310,8 +311,18 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
   const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
   if (nwg > 0x7fffffffLL) return GFLA_OK;
   const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, K + 1, G, (int)sizeof(A), lds_budget());
-  launch_lds(be_fwd_tile_kernel<T, K, CH>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C,
-             (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg);
+#define GFLA_BE_FWD_TILE(CH_)                                                                                                       \
+  launch_lds(be_fwd_tile_kernel<T, K, CH_>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C, \
+             (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg)
+  if constexpr (sizeof(A) == 4) {   // tuning key 40: channels evaluated together per pixel (registers against requests in flight)
+    if (tuning(40) == 1) GFLA_BE_FWD_TILE(1);
+    else if (tuning(40) == 2) GFLA_BE_FWD_TILE(2);
+    else if (tuning(40) == 4 && K <= 4) GFLA_BE_FWD_TILE(4);
+    else GFLA_BE_FWD_TILE(CH);
+  } else {
+    GFLA_BE_FWD_TILE(CH);
+  }
+#undef GFLA_BE_FWD_TILE
   *done = true;
   return launch_status();
 }
@@ -386,6 +397,8 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__
         gx_acc += gv[j] * (-yT_P * vA[j] - yB_P * vB[j] + yT_P * vA[j + 1] + yB_P * vB[j + 1]);
       }
     }
+    // (the test for zero stays: dropping it -- an exec-mask round trip per atomic -- measured 67 -> 66 us (k = 3) on a smooth
+    // flow and costs integer flows 16 atomics instead of 9)
     if (NEED_SRC) {
 #pragma unroll
       for (int q = 0; q <= K; ++q)
@@ -443,7 +456,9 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
                                                          const T *__restrict__ gout, T *__restrict__ gsrc,
                                                          typename Num<T>::acc *__restrict__ gflow, int C, int Hs, int Ws,
                                                          int Hf, int Wf, int th, int tw, int ntx, int nty, int G, int ngroups,
-                                                         int lds_bytes, int64_t nwg) {
+                                                         int lds_bytes, int64_t nwg, int abl) {
+  // abl (tuning key 39, timing ablations, results garbage): 1 = stop after setup / box, 2 = no pixel loop, 4 = no flush,
+  // 8 = no staging of the source window
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   __shared__ int s_box[4];
@@ -470,13 +485,18 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
     box_reduce(s_box, ylo, xlo, yhi, xhi);
   }
   __syncthreads();
-  const TileWin w = tile_window(s_box);
+  const bool vec = NEED_FLOW && window_vec_ok(src + ((int64_t)b * C + g * G) * plane, plane, Ws);
+  const TileWin w = tile_window_vec(s_box, Ws, vec);
   constexpr int kPerElem = (NEED_SRC ? (int)sizeof(lds_acc_t) : 0) + (NEED_FLOW ? (int)sizeof(A) : 0);
   const int g_fit = min(gc, lds_bytes / max(w.size * kPerElem, 1));
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
   T *gsrc0 = NEED_SRC ? gsrc + ((int64_t)b * C + c0) * plane : nullptr;
   const T *gblk0 = gout + ((int64_t)b * C + c0) * oplane + (int64_t)(yf * K) * Wo + xf * K;
   A gx_acc = 0, gy_acc = 0;
+  if (abl & 1) {
+    if (active && px.fx0 == (A)-1.2345e30) gflow[p] = px.ax[0];
+    return;
+  }
   if (g_fit == 0) {
     // the tile reaches further than one channel's window holds: global memory for this tile
     if (active) {
@@ -498,9 +518,9 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
     for (int cb = 0; cb < gc; cb += g_fit) {
       const int n = min(g_fit, gc - cb);
       if (NEED_SRC) zero_planes<lds_acc_t>(gplanes, n * w.size);
-      if (NEED_FLOW) stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, splanes, w, n);
+      if (NEED_FLOW && !(abl & 8)) stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, splanes, w, n, vec);
       __syncthreads();
-      if (active) {
+      if (active && !(abl & 2)) {
         for (int c = 0; c < n; ++c) {
           BeWinSink sink{gplanes + (size_t)c * w.size - shift, w.cols};
           const A *spl = splanes + (size_t)c * w.size - shift;
@@ -512,7 +532,7 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
         }
       }
       __syncthreads();
-      if (NEED_SRC) {
+      if (NEED_SRC && !(abl & 4)) {
         flush_windows<T>(gsrc0 + (int64_t)cb * plane, plane, Ws, w, n, [gplanes](int i) { return (double)gplanes[i]; });
         __syncthreads();
       }
@@ -541,7 +561,7 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \
-             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg)
+             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg, tuning(39))
     if (gsrc && gflow) GFLA_BE_TILE_LAUNCH(true, true);
     else if (gsrc) GFLA_BE_TILE_LAUNCH(true, false);
     else GFLA_BE_TILE_LAUNCH(false, true);

@@ -85,6 +85,52 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
     }
     return val * inv;
   };
+  if constexpr (std::is_same<A, float>::value && std::is_same<PT, float>::value && N == 4) {
+    // kernel_size 4 / 5 in float, no clamped column in the wave: the sixteen normalised weights wy[r] wx[q] / sum once per
+    // pixel, then per channel 8 reads of pairs + 8 packed multiply-adds (the channel loop was ~60 instructions, 9 of the
+    // forward's 21 us at (1,64,256,176))
+    if (__all(consecutive)) {
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f w2[N][2];
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        const float qy = wy[r] * inv;
+        w2[r][0] = v2f{qy * wx[0], qy * wx[1]};
+        w2[r][1] = v2f{qy * wx[2], qy * wx[3]};
+      }
+      const PT *base = plane + co[0];
+      auto request = [&](const PT *b, A (&v)[N][N]) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          const PT *rp = b + ro[r];
+#pragma unroll
+          for (int q = 0; q < N; ++q) v[r][q] = rp[q];
+        }
+      };
+      auto combine2 = [&](const A (&v)[N][N]) {   // two independent chains of packed multiply-adds
+        v2f a0 = w2[0][0] * v2f{v[0][0], v[0][1]}, a1 = w2[0][1] * v2f{v[0][2], v[0][3]};
+#pragma unroll
+        for (int r = 1; r < N; ++r) {
+          a0 = w2[r][0] * v2f{v[r][0], v[r][1]} + a0;
+          a1 = w2[r][1] * v2f{v[r][2], v[r][3]} + a1;
+        }
+        a0 += a1;
+        return a0.x + a0.y;
+      };
+      // (A software pipeline over the channels -- channel c + 1's taps requested before channel c's are combined -- was
+      // measured and dropped: 19.9 -> 25.6 us at (1,64,256,176); the second register set costs more waves than the overlap
+      // buys.  profiles/r5_config2_sweeps.txt)
+      for (int c = 0; c < nch; ++c) {
+        A v[N][N];
+        request(base, v);
+        pin_taps<A, N>(v);
+        *o = Num<T>::from(combine2(v));
+        base += plane_sz;
+        o += ostride;
+      }
+      return;
+    }
+  }
   if (__all(consecutive)) {
     const PT *base = plane + co[0];
     for (int c = 0; c < nch; ++c) {
@@ -601,7 +647,9 @@ template <typename T, int KH, int MODE>
 __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict__ in1, const T *__restrict__ in2,
                                                             const T *__restrict__ gout, T *__restrict__ outp, int C, int Hi,
                                                             int Wi, int H, int W, int dil, int th, int tw, int ntx, int nty, int G,
-                                                            int ngroups, int lds_elems, int64_t nwg) {
+                                                            int ngroups, int lds_elems, int64_t nwg, int abl) {
+  // abl (tuning key 39, timing ablations -- results are garbage for bits 1-4): 1 = stop after the per-pixel setup and the
+  // box, 2 = no staging, 4 = no channel loop; 8 = staging with 4-byte requests, a window row per wave (valid results)
   using A = typename Num<T>::acc;
   constexpr int N = 2 * KH;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
@@ -623,12 +671,14 @@ __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict
   Taps<A, KH> t;   // rows as INDICES (pitch 1) until the window is known
   {
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
-    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false, 1);
+    t.template init<2>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false, 1);
   }
   box_reduce(s_box, active ? t.row_off(0) : 0x7fffffff, active ? t.col_off(0) : 0x7fffffff, active ? t.row_off(N - 1) : -1,
              active ? t.col_off(N - 1) : -1);
   __syncthreads();
-  const TileWin w = tile_window(s_box);
+  const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
+  const bool vec = window_vec_ok(in1_0, plane_sz, Wi);
+  const TileWin w = tile_window_vec(s_box, Wi, vec);
   const int g_fit = window_worth_staging(w, th, tw) ? min(gc, lds_elems / max(w.size, 1)) : 0;
   const int pitch = g_fit == 0 ? Wi : w.cols;
 #pragma unroll
@@ -636,9 +686,12 @@ __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict
     t.yT[f] *= pitch;
     t.yB[f] *= pitch;
   }
-  const T *in1_0 = in1 + ((int64_t)b * C + c0) * plane_sz;
   const T *go0 = MODE == 2 ? gout + ((int64_t)b * C + c0) * HW + p : nullptr;
   A rx = 0, ry = 0, rs = 0;
+  if (abl & 1) {
+    if (active && t.sum == (A)-1.25) outp[p] = Num<T>::from(t.sum);   // (keeps the setup alive)
+    return;
+  }
   if (g_fit == 0) {   // the tile reaches further than one channel's window holds: global memory for this tile
     if (active) {
       if constexpr (MODE == 0) rs_fwd_pixel<T, T, KH, A>(t, in1_0, plane_sz, outp + ((int64_t)b * C + c0) * HW + p, HW, gc);
@@ -648,9 +701,9 @@ __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict
     const A *win0 = planes - (w.ymin * w.cols + w.xmin);
     for (int cb = 0; cb < gc; cb += g_fit) {
       const int n = min(g_fit, gc - cb);
-      stage_windows<T, A>(in1_0 + (int64_t)cb * plane_sz, plane_sz, Wi, planes, w, n);
+      if (!(abl & 2)) stage_windows<T, A>(in1_0 + (int64_t)cb * plane_sz, plane_sz, Wi, planes, w, n, vec && !(abl & 8));
       __syncthreads();
-      if (active) {
+      if (active && !(abl & 4)) {
         if constexpr (MODE == 0) {
           rs_fwd_pixel<T, A, KH, A>(t, win0, w.size, outp + ((int64_t)b * C + c0 + cb) * HW + p, HW, n);
         } else {   // linear in the channel sums: rounds combine by addition
@@ -687,7 +740,8 @@ template <typename T, int KH, bool FIX>
 __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__ in2, const T *__restrict__ gout,
                                                           T *__restrict__ gin1, int C, int Hi, int Wi, int H, int W, int dil,
                                                           int trunc, int th, int tw, int ntx, int nty, int G, int ngroups,
-                                                          int lds_elems, int64_t nwg) {
+                                                          int lds_elems, int64_t nwg, int abl) {
+  // abl (tuning key 39, timing ablations, results garbage): 1 = stop after setup / box / scale, 2 = no scatter, 4 = no flush
   using A = typename Num<T>::acc;
   using PT = typename std::conditional<FIX, lds_fix_t, lds_acc_t>::type;
   static_assert(!FIX || std::is_same<A, float>::value, "fixed-point planes: float scatter only");
@@ -716,7 +770,7 @@ __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__
   {
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
     Taps<A, KH> t;
-    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, (trunc & 1) != 0, 1);
+    t.template init<2>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, (trunc & 1) != 0, 1);
 #pragma unroll
     for (int r = 0; r < N; ++r) {
       row[r] = t.row_off(r);
@@ -742,6 +796,10 @@ __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__
   const int rows = s_box[2] - ymin + 1, cols = s_box[3] - xmin + 1;
   const int win = rows * cols;
   const int g_fit = min(gc, lds_elems / max(win, 1));
+  if (abl & 1) {
+    if (active && qy[0] == (A)-1.25) gin0[p] = Num<T>::from(qy[0] * fix.up);
+    return;
+  }
   if (g_fit == 0) {
     if (active) {
       int ro[N];
@@ -761,7 +819,7 @@ __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__
     const int n = min(g_fit, gc - cb);
     zero_planes<PT>(planes, n * win);
     __syncthreads();
-    if (active) {
+    if (active && !(abl & 2)) {
       const T *go = go0 + (int64_t)cb * HW;
       if constexpr (FIX)
         rs_bwd1_apply_fix<T, N>(ro, co, qy, wx, Num<T>::ld(go), go, HW, planes, win, n, fix.up);
@@ -769,7 +827,7 @@ __global__ __launch_bounds__(512) void rs_bwd1_tile_kernel(const T *__restrict__
         rs_bwd1_apply<T, PT, N, A, LdsPlane>(ro, co, qy, wx, go, HW, planes, win, n, (A)1);
     }
     __syncthreads();
-    {
+    if (!(abl & 4)) {
       const TileWin w{ymin, xmin, rows, cols, win};
       const double down = fix.finite ? fix.down : __longlong_as_double(0x7ff8000000000000ll);
       const bool finite = fix.finite;
@@ -849,7 +907,7 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
       const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
       if (nwg <= 0x7fffffffLL) {
         const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_FWD_BIG);
         return launch_status();
       }
@@ -906,7 +964,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
         const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, 8, lds_budget());
         constexpr bool FIX = std::is_same<A, float>::value;
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_BWD1_TILE);
         st = launch_status();
         if (st != GFLA_OK) return st;
@@ -917,7 +975,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
         const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_BWD2_BIG);
         st = launch_status();
       } else if (gin2) {

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "gfla_common.h"
+#include <type_traits>
 
 namespace gfla {
 
@@ -54,7 +55,13 @@ struct Taps {
   // (the reference's input1 gradient, resample2d_kernel.cu:137-138).
   // pitch: what a row index is multiplied by in yT / yB (the plane's row pitch Wi by default; the tile kernels pass 1 and
   // place the rows in their own window)
-  template <bool FAST = false>
+  // FAST: 0 = the reference's evaluation (double exp of the float quotient), 1 = expf of the float quotient (the planes-in-LDS
+  // kernels: within an ulp of the weight), 2 = round 5's tile kernels, float only: ONE division 1 / (2 sigma^2), the eight
+  // exponentials as v_exp_f32 of q * log2(e) (__expf), the normalisation as (sum of row weights) x (sum of column weights)
+  // instead of the sixteen products -- every weight within ~2e-7 relative of the reference's, far inside the 2e-6 bar, and
+  // ~150 instructions per pixel instead of ~1000 (the setup was 6 of the forward's 21 us at (1,64,256,176),
+  // profiles/r5_rs_fwd_tile_ablations.txt).  sigma == 0 takes the reference's SAFE_DIV path in every mode.
+  template <int FAST = 0>
   __device__ __forceinline__ void init(A dx, A dy, A sg, int x, int y, int Hi, int Wi, int dil,
                                        bool trunc_alpha, int pitch = -1) {
     if (pitch < 0) pitch = Wi;
@@ -76,10 +83,34 @@ struct Taps {
       xRd[f] = (A)((1. + f) * dil) - alpha;
       yTd[f] = (A)(f * dil) + beta;
       yBd[f] = (A)((1. + f) * dil) - beta;
-      xLp[f] = FAST ? gauss_fast<A>(xLd[f], sg) : gauss<A>(xLd[f], sg);
-      xRp[f] = FAST ? gauss_fast<A>(xRd[f], sg) : gauss<A>(xRd[f], sg);
-      yTp[f] = FAST ? gauss_fast<A>(yTd[f], sg) : gauss<A>(yTd[f], sg);
-      yBp[f] = FAST ? gauss_fast<A>(yBd[f], sg) : gauss<A>(yBd[f], sg);
+      if constexpr (FAST != 2 || !std::is_same<A, float>::value) {
+        xLp[f] = FAST ? gauss_fast<A>(xLd[f], sg) : gauss<A>(xLd[f], sg);
+        xRp[f] = FAST ? gauss_fast<A>(xRd[f], sg) : gauss<A>(xRd[f], sg);
+        yTp[f] = FAST ? gauss_fast<A>(yTd[f], sg) : gauss<A>(yTd[f], sg);
+        yBp[f] = FAST ? gauss_fast<A>(yBd[f], sg) : gauss<A>(yBd[f], sg);
+      }
+    }
+    if constexpr (FAST == 2 && std::is_same<A, float>::value) {
+      const float den = 2 * sg * sg;
+      if (den == 0) {
+#pragma unroll
+        for (int f = 0; f < KH; ++f) {
+          xLp[f] = gauss_fast<A>(xLd[f], sg), xRp[f] = gauss_fast<A>(xRd[f], sg);
+          yTp[f] = gauss_fast<A>(yTd[f], sg), yBp[f] = gauss_fast<A>(yBd[f], sg);
+        }
+      } else {
+        const float s2 = -1.4426950408889634f / den;   // exp(-d^2 / den) = 2^(d^2 * s2)
+        float sx = 0, sy = 0;
+#pragma unroll
+        for (int f = 0; f < KH; ++f) {
+          xLp[f] = __builtin_amdgcn_exp2f(xLd[f] * xLd[f] * s2), xRp[f] = __builtin_amdgcn_exp2f(xRd[f] * xRd[f] * s2);
+          yTp[f] = __builtin_amdgcn_exp2f(yTd[f] * yTd[f] * s2), yBp[f] = __builtin_amdgcn_exp2f(yBd[f] * yBd[f] * s2);
+          sx += xLp[f] + xRp[f];
+          sy += yTp[f] + yBp[f];
+        }
+        sum = sx * sy;
+        return;
+      }
     }
 #pragma unroll
     for (int fy = 0; fy < KH; ++fy)

@@ -62,13 +62,75 @@ __device__ __forceinline__ TileWin tile_window(const int *box) {
   w.size = w.rows * w.cols;
   return w;
 }
+// Windows that are STAGED from global memory (gathers) want 16-byte traffic: when the plane allows it (row pitch and plane
+// size multiples of four floats, base 16-byte aligned) the box is widened to whole groups of four columns, so that every
+// window row starts on a 16-byte boundary in global memory and in LDS.
+template <typename T>
+__device__ __forceinline__ bool window_vec_ok(const T *src0, int64_t plane, int Ws) {
+  return sizeof(T) == 4 && (Ws & 3) == 0 && (plane & 3) == 0 && (reinterpret_cast<uintptr_t>(src0) & 15) == 0;
+}
+__device__ __forceinline__ TileWin tile_window_vec(const int *box, int Ws, bool vec) {
+  TileWin w = tile_window(box);
+  if (vec) {
+    const int x1 = min(Ws, (box[3] + 4) & ~3);   // one past the last column, rounded up (Ws is a multiple of 4)
+    w.xmin = box[1] & ~3;
+    w.cols = x1 - w.xmin;
+    w.size = w.rows * w.cols;
+  }
+  return w;
+}
+// 16 bytes per lane, the (channel slot, row, group of four columns) space flattened over the workgroup, U requests per
+// thread in flight.  (Measured with the loads of one window ROW per wave and request, 45 floats of 64 lanes: the staging of
+// resample2d's forward at (1,64,256,176) took 17.5 of the kernel's 35 us whatever the rows per wave and the workgroups per
+// CU -- ~60 CU cycles per wave load; profiles/r5_rs_fwd_tile_ablations.txt.)
+template <typename A>
+__device__ __forceinline__ void stage_windows_vec(const float *__restrict__ src0, int64_t plane, int Ws, A *lds, const TileWin &w, int n) {
+  constexpr int U = 6;
+  const int c4 = w.cols >> 2, per = w.rows * c4, total = n * per;
+  const float inv_per = 1.0f / (float)per, inv_c4 = 1.0f / (float)c4;
+  auto locate = [&](int f, int &goff, int &loff) {   // exact for the sizes at hand (f < 2^20): float reciprocal + fix-up
+    int c = (int)(((float)f + 0.5f) * inv_per);
+    c -= (c * per > f);
+    c += ((c + 1) * per <= f);
+    const int e = f - c * per;
+    int r = (int)(((float)e + 0.5f) * inv_c4);
+    r -= (r * c4 > e);
+    r += ((r + 1) * c4 <= e);
+    const int q = (e - r * c4) << 2;
+    goff = (w.ymin + r) * Ws + w.xmin + q;
+    loff = c * w.size + r * w.cols + q;
+    return c;
+  };
+  for (int f0 = threadIdx.x; f0 < total; f0 += blockDim.x * U) {
+    float4 v[U];
+    int lo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = min(f0 + u * (int)blockDim.x, total - 1);
+      int go;
+      const int c = locate(f, go, lo[u]);
+      v[u] = *reinterpret_cast<const float4 *>(src0 + (int64_t)c * plane + go);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (f0 + u * (int)blockDim.x < total) *reinterpret_cast<float4 *>(lds + lo[u]) = v[u];
+  }
+}
+
 // global planes (row pitch Ws, `plane` elements apart) -> the windows of n channel slots; a wave per window row, lanes along
 // the row (coalesced segments of `cols` elements).  EIGHT rows per wave are requested before the first is stored: written
 // as load -> store per row the loop keeps one request in flight per wave, and a workgroup then spends its life waiting for
 // ~30 dependent round trips (measured: the first window kernels were SLOWER than the global gathers they replaced,
 // profiles/r5_config2_window_kernels_unpipelined_staging.txt).
 template <typename T, typename A>
-__device__ __forceinline__ void stage_windows(const T *__restrict__ src0, int64_t plane, int Ws, A *lds, const TileWin &w, int n) {
+__device__ __forceinline__ void stage_windows(const T *__restrict__ src0, int64_t plane, int Ws, A *lds, const TileWin &w, int n,
+                                              bool vec = false) {
+  if constexpr (sizeof(T) == 4 && sizeof(A) == 4) {
+    if (vec) {
+      stage_windows_vec<A>(reinterpret_cast<const float *>(src0), plane, Ws, lds, w, n);
+      return;
+    }
+  }
   constexpr int U = 8;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int total = n * w.rows;
@@ -140,9 +202,9 @@ inline TileGeo tile_geometry(int64_t H, int64_t W) {
   int tw = tuning(32) > 0 ? tuning(32) : 32;
   if (tw > W) tw = (int)W;
   if (tw > 512) tw = 512;
-  // columns split evenly: 176 -> 6 tiles of 30 rather than 5 of 32 and one of 16
+  // NOT split evenly (176 -> 6 tiles of 30): tiles of 32 columns start on 128-byte lines of every per-pixel tensor, and what a
+  // wave writes per row is then a whole line, not the tail of one and the head of the next (5 tiles of 32 and one of 16)
   const int ntx = (int)ceil_div(W, tw);
-  tw = (int)ceil_div(W, ntx);
   int th = tuning(31) > 0 ? tuning(31) : 16;
   if (th * tw > 512) th = 512 / tw;
   if (th > H) th = (int)H;
@@ -155,15 +217,16 @@ inline TileGeo tile_geometry(int64_t H, int64_t W) {
   return g;
 }
 
-// Gather tiles of block_extractor's forward: whole flow rows when a row fits a workgroup (the K*th output rows of a
-// channel are then ONE contiguous piece of the output plane per workgroup), else th x tw.  tuning keys 35 / 36.
+// Gather tiles of block_extractor's forward: 8 x 32 flow pixels (256 threads: many small workgroups in different phases keep
+// the store stream busy).  Whole flow rows per workgroup -- one contiguous piece of the output plane per channel -- were the
+// first default and measured at half the rate: their windows are 12+ full-width rows for 2 rows of pixels
+// (profiles/r5_config2_sweeps.txt).  tuning keys 35 / 36.
 inline TileGeo row_tile_geometry(int64_t H, int64_t W) {
   TileGeo g;
-  int tw = tuning(36) > 0 ? tuning(36) : (W <= 512 ? (int)W : 32);
+  int tw = tuning(36) > 0 ? tuning(36) : 32;
   if (tw > W) tw = (int)W;
   const int ntx = (int)ceil_div(W, tw);
-  tw = (int)ceil_div(W, ntx);
-  int th = tuning(35) > 0 ? tuning(35) : (tw >= 256 ? 1 : 384 / tw);
+  int th = tuning(35) > 0 ? tuning(35) : 8;
   if (th * tw > 512) th = 512 / tw;
   if (th > H) th = (int)H;
   if (th < 1) th = 1;
