@@ -409,7 +409,7 @@ def pmc_traffic(entry, dims, ptrs=""):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
-    table = json.load(open(path))
+    table = {k: v for k, v in json.load(open(path)).items() if not k.startswith("_")}
     base = entry.rsplit("_", 1)[0]
     B, C = dims[0], dims[1]
 
@@ -457,6 +457,17 @@ def pmc_traffic(entry, dims, ptrs=""):
     return total
 
 
+def pmc_table_provenance():
+    """Which counter run profiles/pmc_traffic.json came from (tools/pmc_summary.py stamps it)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return "absent"
+    meta = json.load(open(path)).get("_meta")
+    if not meta:
+        return "unstamped (made before round 5)"
+    return "%s, generated %s" % (meta.get("tag") or "untagged", meta.get("generated_utc"))
+
+
 def pmc_traffic_kernel(kernel_label, in_step=False):
     """HBM bytes per launch of one FC kernel from the committed PMC profile (profiles/pmc_traffic.json), matched by the
     kernel template and the layer's kernel size; when several launches match (source / target half, forward / data
@@ -465,7 +476,7 @@ def pmc_traffic_kernel(kernel_label, in_step=False):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
-    table = json.load(open(path))
+    table = {k: v for k, v in json.load(open(path)).items() if not k.startswith("_")}
     name = kernel_label.split("<")[0]
     m = re.search(r"k (\d+)>", kernel_label)
     k = m.group(1) if m else None
@@ -1196,7 +1207,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                                if "useful_GFLOP" in dom else {}),
                             "traffic": pmc_traffic_kernel(dom["kernel"], in_step=bool(dom.get("in_step"))),
                             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
-                                              "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch",
+                                              "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; table: "
+                                              + pmc_table_provenance(),
                             "flops": ("Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "
                                       "(2*36*tiles*C*128; tiles = ceil(rows/m)*ceil(cols/m) of the output domain, m = 2 for "
                                       "F(2x2,5x5), 4 for F(4x4,3x3)) / time; effective_TFLOPs = the reference formulation's "

@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kAggStreamWaves * 64) void agg_ga_stream_kernel(
   bool dense;
   if constexpr (EPI == 1) {
     static_assert(EPI == 0 || K == 3, "resample2d's 4 x 4 taps are a K = 3 patch");
-    rt.template init<true>(fx0, fy0, Num<T>::ld(flow + (int64_t)(b * 3 + 2) * HW + p), xf, yf, Hs, Ws, 1, false);
+    rt.template init<2>(fx0, fy0, Num<T>::ld(flow + (int64_t)(b * 3 + 2) * HW + p), xf, yf, Hs, Ws, 1, false);
     px0 = (int)fminf(fmaxf(floorf((float)xf + fx0), -1048576.f), 1048576.f) - 1;
     py0 = (int)fminf(fmaxf(floorf((float)yf + fy0), -1048576.f), 1048576.f) - 1;
     dense = active;

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void rs_patch_table_kernel(const float *__rest
     const int y = p / W, x = p - y * W;
     const float *i2 = in2 + b * 3 * (int64_t)HW + p;
     Taps<float, KH> t;
-    t.template init<true>(i2[0], i2[HW], i2[2 * (int64_t)HW], x, y, Hi, Wi, 1, trunc != 0);
+    t.template init<2>(i2[0], i2[HW], i2[2 * (int64_t)HW], x, y, Hi, Wi, 1, trunc != 0);
     const int y0 = pm_safe_int((float)t.iy0) - (KH - 1), x0 = pm_safe_int((float)t.ix0) - (KH - 1);
     lo = clampi(y0, 0, Hi - 1);
     hi = clampi(y0 + P - 1, 0, Hi - 1);

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void rs_tap_table_kernel(const float *__restri
   const int y = p / W, x = p - y * W;
   const float *i2 = in2 + (int64_t)b * 3 * HW + p;
   Taps<float, 2> t;
-  t.template init<true>(i2[0], i2[HW], i2[2 * HW], x, y, Hi, Wi, dil, (trunc & 1) != 0);
+  t.template init<2>(i2[0], i2[HW], i2[2 * HW], x, y, Hi, Wi, dil, (trunc & 1) != 0);
   RsTapRec r;
   unsigned ri[4], ci[4];
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kLdsThreads) void rs_lds_kernel(const T *__restrict
     const int y = p / W, x = p - y * W;
     const T *i2 = in2 + (int64_t)b * 3 * HW + p;
     Taps<A, KH> t;
-    t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
+    t.template init<2>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil,
                           MODE == 1 && (trunc & 1) != 0);
     // outermost taps bound the rows this pixel touches; beyond the window it uses global memory
     const bool inside = !WIN || (t.yT[KH - 1] >= lo_off && t.yB[KH - 1] < hi_off);
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void rs_fwd_big_kernel(const T *__restrict_
   const int y = p / W, x = p - y * W;
   const T *i2 = in2 + (int64_t)b * 3 * HW + p;
   Taps<A, KH> t;
-  t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  t.template init<2>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
   const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
   const int64_t plane_sz = (int64_t)Hi * Wi;
   rs_fwd_pixel<T, T, KH, A>(t, in1 + ((int64_t)b * C + c0) * plane_sz, plane_sz, out + ((int64_t)b * C + c0) * HW + p, HW,
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void rs_bwd2_big_kernel(const T *__restrict
   const int y = p / W, x = p - y * W;
   const T *i2 = in2 + (int64_t)b * 3 * HW + p;
   Taps<A, KH> t;
-  t.template init<true>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
+  t.template init<2>(Num<T>::ld(i2), Num<T>::ld(i2 + HW), Num<T>::ld(i2 + 2 * HW), x, y, Hi, Wi, dil, false);
   const int c0 = cg * cpt, c1 = min(C, c0 + cpt);
   const int64_t plane_sz = (int64_t)Hi * Wi;
   A rx, ry, rs;

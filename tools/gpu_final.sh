@@ -18,10 +18,19 @@ for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_ns_$C -o pmc -- $NS > $OUT/pmc_ns_$C.log 2>&1); echo "north star $C rc=$?"
 done
 F=$(find /tmp/fin_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1 && cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+# (only gpurun_out/ travels back: copy $OUT/pmc_traffic.json to profiles/pmc_traffic.json in the build container afterwards)
+python tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json "$TAG" > $OUT/pmc_traffic.txt 2>&1
 grep -E "fc_conv|fc_wgrad|fc_wino|agg_|be_bwd|rs_lds|patch_" $OUT/pmc_traffic.txt | cut -c1-160 | head -40
 F=$(find /tmp/fin_ns_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_ns_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-python tools/pmc_summary.py "$F" "$W" $OUT/north_star_pmc_traffic.json > $OUT/north_star_pmc_traffic.txt 2>&1; cat $OUT/north_star_pmc_traffic.txt | cut -c1-170
+python tools/pmc_summary.py "$F" "$W" $OUT/north_star_pmc_traffic.json "$TAG north star" > $OUT/north_star_pmc_traffic.txt 2>&1; cat $OUT/north_star_pmc_traffic.txt | cut -c1-170
+# BASELINE configs[1]: traffic of the big-plane kernels (smooth flow, no reference kernels in the traced process)
+C2="python $PWD/tools/bench_config2.py --no-ref --flows smooth --iters 3"
+for C in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/fin_c2_$C -o pmc -- $C2 > $OUT/pmc_c2_$C.log 2>&1); echo "config2 $C rc=$?"
+done
+F=$(find /tmp/fin_c2_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find /tmp/fin_c2_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/pmc_summary.py "$F" "$W" $OUT/config2_pmc_traffic.json "$TAG config2" > $OUT/config2_pmc_traffic.txt 2>&1; cat $OUT/config2_pmc_traffic.txt | cut -c1-170
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fin_c2_trace -o c2 -- python $OLDPWD/tools/bench_config2.py --no-ref --flows smooth --iters 10 > $OUT/rocprof_config2.log 2>&1); cp /tmp/fin_c2_trace/c2_kernel_stats.csv $OUT/config2_kernel_stats.csv 2>/dev/null
 bash tools/gpu_pmc_fc.sh $TAG/mfma --no-variants --no-legs > $OUT/mfma.log 2>&1; grep -E "fc_conv|fc_wgrad|fc_wino" $OUT/mfma/pmc_set1.txt 2>/dev/null | cut -c1-250 | head -12
 bash tools/gpu_pmc_lds.sh $TAG/ns_lds "_kernel" -- $NS > /dev/null 2>&1
 grep -E "be_fwd|agg_" $OUT/ns_lds/pmc_summary.txt | cut -c1-330

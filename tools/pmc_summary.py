@@ -28,9 +28,13 @@ def load(path):
     return agg
 
 
-def main(fetch_csv, write_csv, out_json):
+def main(fetch_csv, write_csv, out_json, tag=""):
+    import datetime
     rd, wr = load(fetch_csv), load(write_csv)
     out = collections.OrderedDict()
+    # provenance: bench.py quotes it next to roofline.traffic, so a table from an earlier round cannot pass for this one's
+    out["_meta"] = {"tag": tag, "generated_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
+                    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -> tools/pmc_summary.py"}
     for key in rd:
         f = sum(rd[key]) / len(rd[key])
         w = sum(wr[key]) / len(wr[key]) if key in wr else 0.0
@@ -39,10 +43,12 @@ def main(fetch_csv, write_csv, out_json):
             "traffic_bytes": int((2 * f + w) * 1024), "traffic_bytes_uncorrected": int((f + w) * 1024)})
     json.dump(out, open(out_json, "w"), indent=1)
     for k, rows in out.items():
+        if k.startswith("_"):
+            continue
         for r in rows:
             print("%-58s grid=%-8d n=%-3d fetch %10.1f KiB  write %10.1f KiB  traffic<= %8.1f MB" %
                   (k, r["grid"], r["launches"], r["FETCH_SIZE_KiB"], r["WRITE_SIZE_KiB"], r["traffic_bytes"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
