@@ -5,34 +5,40 @@
 // element, so every store is a full coalesced line and no atomics are needed (the reference's
 // backward issues one atomicAdd per element onto a bijection, :106).
 #include "gfla_common.h"
+#include <algorithm>
 
 namespace gfla {
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void lar_fwd_kernel(const T *__restrict__ in, T *__restrict__ out,
-                                                        int64_t n, int H, int W, int k) {
-  const int64_t index = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (index >= n) return;
-  const int Wo = k * W, Ho = k * H;
-  const int x = (int)(index % Wo);
-  const int y = (int)((index / Wo) % Ho);
-  const int64_t b = index / ((int64_t)Wo * Ho);
+// Round 5: the first version indexed with 64-bit divisions by run-time values (~100 instructions each, emulated) and was
+// SLOWER than the reference's kernel at the layer-3 shape (7.1 us against 4.0: both launch-sized, ours arithmetic-bound).
+// Now: batch on grid.y, 32-bit index arithmetic inside a sample, the kernel size a template parameter for 2..5 (divisions by
+// constants), 0 = any.
+template <typename T, int KT>
+__global__ __launch_bounds__(kBlock) void lar_fwd_kernel(const T *__restrict__ in, T *__restrict__ out, int n1, int H, int W,
+                                                        int k_rt) {
+  const int k = KT ? KT : k_rt;
+  const int index = blockIdx.x * kBlock + threadIdx.x;   // inside one sample's (k*H, k*W) map
+  if (index >= n1) return;
+  const int Wo = k * W;
+  const int y = index / Wo, x = index - y * Wo;
   const int ys = y / k, xs = x / k;
   const int cs = (y - ys * k) * k + (x - xs * k);
-  out[index] = in[((b * k * k + cs) * H + ys) * W + xs];
+  const int64_t base = (int64_t)blockIdx.y * n1;
+  out[base + index] = in[base + (cs * H + ys) * W + xs];
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void lar_bwd_kernel(const T *__restrict__ gout, T *__restrict__ gin,
-                                                        int64_t n, int H, int W, int k) {
-  const int64_t index = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // over grad_in (B,k*k,H,W)
-  if (index >= n) return;
-  const int xs = (int)(index % W);
-  const int ys = (int)((index / W) % H);
-  const int cs = (int)((index / ((int64_t)W * H)) % (k * k));
-  const int64_t b = index / ((int64_t)W * H * k * k);
+template <typename T, int KT>
+__global__ __launch_bounds__(kBlock) void lar_bwd_kernel(const T *__restrict__ gout, T *__restrict__ gin, int n1, int H, int W,
+                                                        int k_rt) {
+  const int k = KT ? KT : k_rt;
+  const int index = blockIdx.x * kBlock + threadIdx.x;  // inside one sample's grad_in (k*k, H, W)
+  if (index >= n1) return;
+  const int HW = H * W;
+  const int cs = index / HW, rem = index - cs * HW;
+  const int ys = rem / W, xs = rem - ys * W;
   const int i = cs / k, j = cs - i * k;
-  gin[index] = gout[(b * (k * H) + (ys * k + i)) * (int64_t)(k * W) + (xs * k + j)];
+  const int64_t base = (int64_t)blockIdx.y * n1;
+  gin[base + index] = gout[base + (ys * k + i) * (k * W) + (xs * k + j)];
 }
 
 template <typename T>
@@ -41,16 +47,26 @@ static int reshape(bool fwd, const T *a, T *bptr, int64_t B, int64_t H, int64_t 
   if (!a || !bptr) return GFLA_ERR_NULL_POINTER;
   if (B <= 0 || H <= 0 || W <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
   if ((k * H) * (k * W) > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  const int64_t n = B * k * k * H * W;
-  const int64_t blocks = ceil_div(n, kBlock);
-  if (blocks > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  const int64_t n1 = (int64_t)k * k * H * W;
+  const int64_t blocks = ceil_div(n1, kBlock);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (fwd)
-    hipLaunchKernelGGL((lar_fwd_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, bptr, n,
-                       (int)H, (int)W, k);
-  else
-    hipLaunchKernelGGL((lar_bwd_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, bptr, n,
-                       (int)H, (int)W, k);
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {   // grid.y limit
+    const unsigned nb = (unsigned)std::min<int64_t>(65535, B - b0);
+    const dim3 grid((unsigned)blocks, nb), blk(kBlock);
+    const T *ap = a + b0 * n1;
+    T *bp = bptr + b0 * n1;
+#define GFLA_LAR(KT_)                                                                                                   \
+  if (fwd) lar_fwd_kernel<T, KT_><<<grid, blk, 0, stream>>>(ap, bp, (int)n1, (int)H, (int)W, k);                          \
+  else lar_bwd_kernel<T, KT_><<<grid, blk, 0, stream>>>(ap, bp, (int)n1, (int)H, (int)W, k)
+    switch (k) {
+      case 2: GFLA_LAR(2); break;
+      case 3: GFLA_LAR(3); break;
+      case 4: GFLA_LAR(4); break;
+      case 5: GFLA_LAR(5); break;
+      default: GFLA_LAR(0); break;
+    }
+#undef GFLA_LAR
+  }
   return launch_status();
 }
 

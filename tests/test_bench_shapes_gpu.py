@@ -33,6 +33,9 @@ BENCH_SHAPES = [  # (name, B, C, H, W, k)
     ("attn2_256x176", 32, 128, 64, 44, 5),
     ("attn3_256x256", 32, 256, 32, 32, 3),
     ("attn2_256x256", 32, 128, 64, 64, 5),
+    # Market-1501 recipe (PERSON_IMAGE_GENERATION.md:53-57: 128x64 images, --attn_layer=2 --kernel_size=2=3): kernel size 3 on
+    # the 128-channel layer, a combination the two DeepFashion layers do not have
+    ("attn2_market_128x64", 32, 128, 32, 16, 3),
 ]
 FC_PATHS = [("mfma", 0), ("mfma", 4), ("mfma", 3), ("mfma", 2), ("library", 0)]
 

@@ -301,3 +301,44 @@ def test_extractor_attn_bf16_features(lib, gfla, oracle, k, C, H, W):
     # (heavy cancellation: 2^-9 relative noise per term against a sum much smaller than its terms): 2^-5 there
     bad = {n_: e for n_, e in errs.items() if e > (2 * tol if n_.startswith("fully_connect") else tol)}
     assert not bad, errs
+
+
+@pytest.mark.parametrize("mode", (4, 0))
+@pytest.mark.parametrize("k,C", [(3, 16), (5, 8)])
+def test_leaky_relu_at_exactly_zero_takes_the_negative_slope(lib, gfla, oracle, mode, k, C):
+    """A hidden unit whose pre-activation is EXACTLY 0 everywhere (zero weights, zero bias): torch's LeakyReLU backward uses
+    the negative slope at 0 (x > 0 ? 1 : slope), and so does csrc/fc_sample.hip / fc_tail.hip.  The bench-shape parity
+    checks push their biases to +-8 to keep every unit off the kink; this is the one place where the value AT the kink is
+    pinned: the gradients of that unit's bias and of everything behind it must be slope x (not 1 x, not 0 x) the upstream
+    gradient, for both float32 FC arithmetic modes and the round-1 library path."""
+    from oracle import cpu_modules
+    B, H, W, slope, dead = 2, 12, 10, 0.1, 7
+    torch.manual_seed(3)
+    m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(slope), softmax=True)
+    with torch.no_grad():
+        # every other unit far from the kink (+-8, as the bench-shape tests), the pinned one exactly on it
+        m.fully_connect_layer[0].bias.copy_(torch.where(torch.arange(128) % 2 == 0, 8.0, -8.0))
+        m.fully_connect_layer[0].weight[dead].zero_()
+        m.fully_connect_layer[0].bias[dead] = 0.0
+    ref = cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(slope), softmax=True).double()
+    ref.load_state_dict({n: v.double() for n, v in m.state_dict().items()})
+    s, t = randn((B, C, H, W), seed=51), randn((B, C, H, W), seed=52)
+    f = make_flow("coherent", B, H, W, seed=53)
+    up = randn((B, C, H, W), seed=54)
+    cargs = [x.double().clone().requires_grad_() for x in (s, t, f)]
+    ref(*cargs).backward(up.double())
+    want_b0 = ref.fully_connect_layer[0].bias.grad
+    assert want_b0[dead].abs().item() > 1e-6          # the pinned unit does carry gradient: slope x something
+    m = m.to(DEV)
+    for impl in ("mfma", "library"):
+        m.fc_impl, m.fc_mode = impl, mode
+        args = [x.to(DEV).requires_grad_() for x in (s, t, f)]
+        m.zero_grad()
+        m(*args).backward(up.to(DEV))
+        got_b0 = m.fully_connect_layer[0].bias.grad.cpu().double()
+        assert abs(got_b0[dead].item() - want_b0[dead].item()) <= 1e-4 * want_b0.abs().max().item(), \
+            "%s mode %d: d/d bias of the unit at the kink %.6e, reference %.6e (slope %.2f)" % (impl, mode, got_b0[dead], want_b0[dead], slope)
+        for n_, g, w_ in zip(["source", "target", "flow"] + [n for n, _ in m.named_parameters()],
+                             [a.grad.cpu() for a in args] + [p.grad.cpu() for p in m.parameters()],
+                             [a.grad for a in cargs] + [p.grad for p in ref.parameters()]):
+            assert_close(g, w_, 1e-4, "%s mode %d grad %s with a unit exactly on the kink" % (impl, mode, n_))
