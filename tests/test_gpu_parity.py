@@ -1078,11 +1078,16 @@ def test_resample2d_input1_gradient_non_finite_is_not_silently_lost(gfla, kernel
 
 
 def test_bf16_features_beyond_the_lds_backward_fall_back_to_f32(gfla, oracle, kernel_variant):
-    """128x128 bf16 maps: the bf16 aggregation backward does not take planes that large; the block must
-    still train -- evaluated in float32, results handed back in bf16 -- instead of raising in backward."""
+    """128x128 bf16 maps: the bf16 aggregation backward (planes in LDS) does not take planes that large.  The
+    block must still train.  Round 5: with the default float32 aggregation backward the bf16 path has no such
+    limit any more and takes these maps itself; with extractor_attn.BF16_BACKWARD_F32_AGGREGATE = False the block is
+    evaluated through the float32 view of the module (a warning; the per-call shadow of _fused_attention_f32_module) and
+    the results are handed back in bf16.  Both ways: the module deep-copies afterwards and the parity bars hold."""
     if kernel_variant == "global":
         pytest.skip("gate test")
+    import copy
     import warnings
+    from global_flow_local_attention_amd import extractor_attn as ea
     from oracle import cpu_modules
     B, C, H, W, k = 1, 16, 128, 128, 3
     torch.manual_seed(0)
@@ -1093,16 +1098,25 @@ def test_bf16_features_beyond_the_lds_backward_fall_back_to_f32(gfla, oracle, ke
     bf = lambda x: x.to(torch.bfloat16)
     s, t = bf(randn((B, C, H, W), seed=1)), bf(randn((B, C, H, W), seed=2))
     f = bf(make_flow("smooth", B, H, W, seed=3))
-    sd, td, fd = (x.to(DEV).requires_grad_() for x in (s, t, f))
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        out = mod(sd, td, fd)
-    assert any("float32" in str(x.message) for x in w)
-    assert out.dtype == torch.bfloat16
-    out.float().sum().backward()
     sc, tc, fc = (x.float().requires_grad_() for x in (s, t, f))
     want = ref(sc, tc, fc)
     want.sum().backward()
-    assert_close(out.float().cpu(), want.detach(), 2 ** -7, "bf16 fallback forward")
-    assert_close(sd.grad.float().cpu(), sc.grad, 2 ** -6, "bf16 fallback grad source")
-    assert_close(fd.grad.float().cpu(), fc.grad, 2 ** -5, "bf16 fallback grad flow")
+    old = ea.BF16_BACKWARD_F32_AGGREGATE
+    try:
+        for f32_aggregate, expect_warning in ((True, False), (False, True)):
+            ea.BF16_BACKWARD_F32_AGGREGATE = f32_aggregate
+            mod.__dict__.pop("_library_warned", None)
+            sd, td, fd = (x.to(DEV).requires_grad_() for x in (s, t, f))
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                out = mod(sd, td, fd)
+            assert any("float32" in str(x.message) for x in w) == expect_warning, (f32_aggregate, [str(x.message)[:80] for x in w])
+            assert out.dtype == torch.bfloat16
+            out.float().sum().backward()
+            what = "bf16 128x128, float32 aggregation backward %s: " % f32_aggregate
+            assert_close(out.float().cpu(), want.detach(), 2 ** -7, what + "forward")
+            assert_close(sd.grad.float().cpu(), sc.grad, 2 ** -6, what + "grad source")
+            assert_close(fd.grad.float().cpu(), fc.grad, 2 ** -5, what + "grad flow")
+            copy.deepcopy(mod)        # nothing non-leaf left on the module (the float32 view is built per call)
+    finally:
+        ea.BF16_BACKWARD_F32_AGGREGATE = old
