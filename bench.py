@@ -892,39 +892,50 @@ def oracle_check(hp, resample, tol=1e-4):
 
 
 def cpu_baseline(budget_s=20.0):
-    """The reference composition on the host cores with the oracle kernels (kind "port")."""
-    from oracle import cpu_modules, cpu_oracle
-    cpu_oracle.build()
-    # the literal port keeps the reference's atomics (as `omp atomic`); beyond a few tens of threads
-    # they thrash (measured 0.055 img/s on 256 threads vs 1.3 img/s on 8), so the baseline uses at
-    # most 16 host threads and says so in `cores`.
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    cpu_oracle.set_threads(cores)
-    b = 1
-    mods = [cpu_modules.ExtractorAttnCPU(C, k, torch.nn.LeakyReLU(0.1), softmax=True) for (_, C, _, _, k) in LAYERS]
-    hp = HotPath(b, "cpu", seed=0, modules=mods)
-    res = cpu_modules.Resample2dCPU(4, 1, 2)
-    hp.step(res, allreduce=False)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        hp.step(res, allreduce=False)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 50:
-            break
-    dt = time.perf_counter() - t0
+    """The reference composition on the host cores with the oracle kernels (kind "port").
+
+    The literal port keeps the reference's atomics (as `omp atomic`); inside ONE image they thrash beyond a few tens of
+    threads (measured 0.055 images/s on 256 threads vs 1.3 on 8), so a single process uses 16.  Round 5: the batch is
+    what parallelises on a host as it does on the GPU -- independent images -- so the baseline runs one 16-thread worker per
+    16 usable CPUs (tools/cpu_baseline_worker.py, pinned to disjoint CPU ranges, same start time, batch 1 each) and reports
+    the SUM of their rates with `cores` = the threads actually used."""
+    import subprocess
     host = os.cpu_count() or 1
     try:
-        usable = len(os.sched_getaffinity(0))
+        usable = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        usable = host
-    return {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "host_logical_cpus": host,
-            "host_cpus_usable_by_this_process": usable, "kind": "port",
-            "threads_note": "the literal port keeps the reference's atomics (omp atomic); beyond ~16 threads they thrash "
-                            "(0.055 images/s on 256 threads vs 1.3 on 8), so `cores` = the %d threads used, not the host's %d "
-                            "logical CPUs" % (cores, host),
-            "sample": "%d step(s) of batch %d of the same workload (reference op-by-op composition, oracle/gfla_oracle.c "
-                      "kernels with OpenMP + torch CPU convolutions), %.1f s" % (n, b, dt)}
+        usable = list(range(host))
+    per = 16
+    workers = max(1, min(len(usable) // per, 16))
+    budget = max(5.0, min(budget_s, 20.0))
+    start_at = time.time() + 30.0          # imports + the warm-up step of every worker fit in here; late workers start at once
+    procs = []
+    for w in range(workers):
+        cpus = usable[w * per:(w + 1) * per] if len(usable) >= per else usable
+        rng = "%d-%d" % (cpus[0], cpus[-1]) if cpus == list(range(cpus[0], cpus[-1] + 1)) else ""
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "--threads",
+                                       str(min(per, len(cpus))), "--cpus", rng, "--budget", str(budget), "--start-at", str(start_at)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+    done = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=budget + 240)
+            done.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pr.kill()
+    if not done:
+        raise RuntimeError("cpu_baseline: no worker finished")
+    rate = sum(d["steps"] / d["seconds"] for d in done)
+    threads = min(per, len(usable)) * len(done)
+    return {"value": round(rate, 3), "unit": "images/s", "cores": threads, "host_logical_cpus": host,
+            "host_cpus_usable_by_this_process": len(usable), "kind": "port", "workers": len(done),
+            "per_worker_images_per_s": round(rate / len(done), 3),
+            "threads_note": "%d workers x %d threads, one image each at a time: the literal port keeps the reference's atomics "
+                            "(omp atomic), which thrash beyond ~16 threads inside one image (0.055 images/s on 256 threads vs "
+                            "1.3 on 8); independent images are what parallelises, as on the GPU" % (len(done), min(per, len(usable))),
+            "sample": "%d step(s) of batch 1 of the same workload over %d concurrent workers (reference op-by-op composition, "
+                      "oracle/gfla_oracle.c kernels with OpenMP + torch CPU convolutions), %.1f s each"
+                      % (sum(d["steps"] for d in done), len(done), budget)}
 
 
 def extra_legs(args, device):
@@ -1370,7 +1381,7 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path); run it through gpurun")
-    if args.gpus > torch.cuda.device_count():
+    if args.gpus > torch.cuda.device_count() and "GFLA_DEVICE" not in os.environ:   # (GFLA_DEVICE: ranks sharing a GPU, tests)
         raise SystemExit("--gpus %d but %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     # bind the device BEFORE anything touches the GPU or the process group (RCCL communicators are per device)
     local = int(os.environ.get("GFLA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
