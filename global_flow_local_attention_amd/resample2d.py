@@ -92,6 +92,9 @@ class Resample2d(nn.Module):
         if self.sigma is None or self.sigma.device != input2.device:
             self.sigma = torch.tensor(self._sigma_value, dtype=torch.float, device=input2.device)
         B, _, H, W = input2.shape
-        sigma_plane = self.sigma.expand(B, 1, H, W).type(input2.dtype)
+        # (the reference concatenates the EXPANDED scalar, resample2d.py:51-52; torch.cat with a stride-0 operand leaves its fast
+        # path: 49 us for this 1 MB tensor in the step's kernel trace, profiles/r5_final_bench_kernel_stats.csv -- so the plane
+        # is materialised first: a 3 us fill, then the contiguous cat)
+        sigma_plane = self.sigma.expand(B, 1, H, W).type(input2.dtype).contiguous()
         return Resample2dFunction.apply(input1.contiguous(), torch.cat((input2, sigma_plane), 1),
                                         self.kernel_size, self.dilation)
