@@ -57,6 +57,8 @@ _SINGLE = {
     "gfla_aggregate_fwd_workspace_bytes": [_i64] * 3 + [_int],
     "gfla_aggregate_fwd_geometry": [_i64] * 6 + [_int, _ptr],
     "gfla_aggregate_bwd_supported": [_i64, _i64, _int],
+    "gfla_big_plane_geometry": [_int] + [_i64] * 6 + [_int, _int, _ptr],
+    "gfla_xcd_swizzle": [_i64, _i64],
     "gfla_local_attn_aggregate_fwd_ws_f32": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_fwd_ws_bf16": [_ptr] * 6 + [_i64] * 6 + [_int, _int, _ptr],
     "gfla_local_attn_aggregate_bwd_ws_f32": [_ptr] * 8 + [_i64] * 6 + [_int, _int, _ptr],
@@ -116,7 +118,7 @@ def lib():
         for name, args in _SINGLE.items():
             fn = getattr(handle, name)
             fn.argtypes = args
-            fn.restype = _i64 if name.endswith("_bytes") else _int
+            fn.restype = _i64 if (name.endswith("_bytes") or name == "gfla_xcd_swizzle") else _int
         _lib = handle
     return _lib
 

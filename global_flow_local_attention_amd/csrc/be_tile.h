@@ -280,14 +280,6 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
   }
 }
 
-// channels per workgroup of a tile kernel: `dflt` unless that leaves the launch under three workgroups per CU
-inline int tile_channels(int key, int dflt, int64_t tiles, int64_t C) {
-  int G = tuning(key) > 0 ? tuning(key) : dflt;
-  if (tuning(key) <= 0)
-    while (G > 1 && tiles * ceil_div(C, G) < 3 * kNumCU) G /= 2;
-  return G > C ? (int)C : G;
-}
-
 template <typename T, int K>
 static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
                           int64_t Wf, hipStream_t stream, bool *done) {
@@ -306,11 +298,12 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
     *done = true;
     return launch_status();
   }
-  const TileGeo tg = row_tile_geometry(Hf, Wf);
-  const int G = tile_channels(37, 8, B * tg.nty * tg.ntx, C);
-  const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+  const BigGeo bg = big_geometry(0, B, C, Hf, Wf, K + 1, (int)sizeof(A));
+  const TileGeo tg = bg.tg;
+  const int G = bg.G;
+  const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
   if (nwg > 0x7fffffffLL) return GFLA_OK;
-  const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, K + 1, G, (int)sizeof(A), lds_budget());
+  const unsigned lds_bytes = bg.lds_bytes;
 #define GFLA_BE_FWD_TILE(CH_)                                                                                                       \
   launch_lds(be_fwd_tile_kernel<T, K, CH_>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C, \
              (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg)
@@ -552,12 +545,12 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
     return GFLA_OK;  // bf16 storage has no atomics: the planes-in-LDS kernels only
   } else {
     if (Hs * Ws > 0x3fffffffLL || (int64_t)K * Hf * K * Wf > 0x7fffffffLL) return GFLA_OK;
-    const TileGeo tg = tile_geometry(Hf, Wf);
-    const int G = tile_channels(34, 8, B * tg.nty * tg.ntx, C);
-    const int64_t ngroups = ceil_div(C, G);
-    const int64_t nwg = B * tg.nty * tg.ntx * ngroups;
+    const BigGeo bg = big_geometry(1, B, C, Hf, Wf, K + 1, (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(typename Num<T>::acc) : 0));
+    const TileGeo tg = bg.tg;
+    const int G = bg.G;
+    const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
     if (nwg > 0x7fffffffLL) return GFLA_OK;
-    const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, K + 1, G, (gsrc ? (int)sizeof(lds_acc_t) : 0) + (gflow ? (int)sizeof(typename Num<T>::acc) : 0), lds_budget());
+    const unsigned lds_bytes = bg.lds_bytes;
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \

@@ -856,15 +856,6 @@ static Geo geometry(int64_t B, int64_t C, int64_t H, int64_t W, int max_cpt, int
   return g;
 }
 
-// channels per workgroup of a tile kernel: `dflt` (tuning key `key` overrides) unless that leaves the launch under three
-// workgroups per CU
-static int rs_tile_channels(int key, int dflt, int64_t tiles, int64_t C) {
-  int G = tuning(key) > 0 ? tuning(key) : dflt;
-  if (tuning(key) <= 0)
-    while (G > 1 && tiles * ceil_div(C, G) < 3 * kNumCU) G /= 2;
-  return G > C ? (int)C : G;
-}
-
 // big-plane gathers: channels per thread -- all of them unless that leaves fewer than `want` waves (tuning key 33)
 static int big_cpt(int64_t B, int64_t C, int64_t nsp, int64_t want) {
   if (tuning(33) > 0) return tuning(33) < C ? tuning(33) : (int)C;
@@ -902,11 +893,12 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   if (tuning(6) != 1 && big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(A), lds_budget())) {
     // few planes far beyond the LDS budget (BASELINE configs[1]): one tap setup per pixel and chunk of channels, global gathers
     if (tuning(38) != 1 && sizeof(T) >= 4 && Hi * Wi <= 0x3fffffffLL) {   // planes staged into bounding-box windows
-      const TileGeo tg = tile_geometry(H, W);
-      const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
-      const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+      const BigGeo bg = big_geometry(2, B, C, H, W, (k - 1) * dil + 1, (int)sizeof(A));
+      const TileGeo tg = bg.tg;
+      const int G = bg.G;
+      const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
       if (nwg <= 0x7fffffffLL) {
-        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
+        const unsigned lds_bytes = bg.lds_bytes;
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_FWD_BIG);
         return launch_status();
@@ -958,11 +950,12 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
           if (hipMemsetAsync(gin1, 0, (size_t)(B * C * Hi * Wi) * sizeof(T), stream) != hipSuccess) return GFLA_ERR_LAUNCH;
           trunc &= ~2;
         }
-        const TileGeo tg = tile_geometry(H, W);
-        const int G = rs_tile_channels(34, 8, B * tg.nty * tg.ntx, C);
-        const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+        const BigGeo bg = big_geometry(3, B, C, H, W, (k - 1) * dil + 1, 8);
+        const TileGeo tg = bg.tg;
+        const int G = bg.G;
+        const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, 8, lds_budget());
+        const unsigned lds_bytes = bg.lds_bytes;
         constexpr bool FIX = std::is_same<A, float>::value;
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_BWD1_TILE);
@@ -970,11 +963,12 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         if (st != GFLA_OK) return st;
       }
       if (gin2 && tuning(38) != 1) {
-        const TileGeo tg = tile_geometry(H, W);
-        const int G = rs_tile_channels(37, 16, B * tg.nty * tg.ntx, C);
-        const int64_t ngroups = ceil_div(C, G), nwg = B * tg.nty * tg.ntx * ngroups;
+        const BigGeo bg = big_geometry(2, B, C, H, W, (k - 1) * dil + 1, (int)sizeof(A));
+        const TileGeo tg = bg.tg;
+        const int G = bg.G;
+        const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-        const unsigned lds_bytes = tile_lds_request(tg.th, tg.tw, (k - 1) * dil + 1, G, (int)sizeof(A), lds_budget());
+        const unsigned lds_bytes = bg.lds_bytes;
         GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
         note_path(GFLA_PATH_RS_BWD2_BIG);
         st = launch_status();
@@ -1140,6 +1134,30 @@ int gfla_resample2d_bwd_bf16(const uint16_t *a, const uint16_t *b, const uint16_
   return gfla::resample2d_bwd<bf16_t>(reinterpret_cast<const bf16_t *>(a), reinterpret_cast<const bf16_t *>(b),
                                       reinterpret_cast<const bf16_t *>(go), reinterpret_cast<bf16_t *>(g1), g2, B, C, Hi,
                                       Wi, H, W, k, d, trunc, st);
+}
+/* Host-side launch geometry of the big-plane tile kernels (csrc/tile_map.h; no GPU needed: the CPU tests sweep it).
+ * op: 0 block_extractor forward, 1 block_extractor backward (both gradients), 2 resample2d forward / d/d input2,
+ * 3 resample2d d/d input1.  (H, W) = the flow / output grid, (Hs, Ws) = the source plane, span = taps per axis (kernel_size
+ * + 1 for block_extractor, (kernel_size - 1) * dilation + 1 for resample2d), elem_size 4 / 8.
+ * out[10] = in the regime by default (0 / 1), tile rows, tile columns, tiles along x, tiles along y, threads per workgroup,
+ * channels per workgroup, channel groups, dynamic LDS bytes requested, workgroups. */
+int gfla_big_plane_geometry(int op, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int span,
+                            int elem_size, int64_t *out) {
+  if (!out) return GFLA_ERR_NULL_POINTER;
+  if (op < 0 || op > 3 || B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || span < 1 || (elem_size != 4 && elem_size != 8))
+    return GFLA_ERR_BAD_SHAPE;
+  const int per = op == 0 || op == 2 ? elem_size : op == 3 ? 8 : 8 + elem_size;
+  const int64_t plane_bytes = Hs * Ws * (int64_t)(op == 1 ? 8 + elem_size : op == 3 ? 8 : elem_size);
+  const gfla::BigGeo g = gfla::big_geometry(op, B, C, H, W, span, per);
+  const int64_t v[10] = {gfla::big_plane_regime(B, C, plane_bytes, gfla::lds_budget()) ? 1 : 0, g.tg.th, g.tg.tw, g.tg.ntx, g.tg.nty,
+                         g.tg.threads, g.G, g.ngroups, g.lds_bytes, g.nwg};
+  for (int i = 0; i < 10; ++i) out[i] = v[i];
+  return GFLA_OK;
+}
+/* The workgroup -> work-item remap of those kernels (a bijection of [0, nwg) that hands the blocks of each of the 8 XCDs a
+ * contiguous range); -1 outside [0, nwg). */
+int64_t gfla_xcd_swizzle(int64_t block, int64_t nwg) {
+  return (block < 0 || block >= nwg) ? -1 : gfla::xcd_swizzle(block, nwg);
 }
 int gfla_resample2d_bwd_f64(const double *a, const double *b, const double *go, double *g1, double *g2,
                             int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int k,

@@ -13,13 +13,13 @@
 //     one float atomic per window element; a box too large for a single channel takes global atomics for that tile only.
 #pragma once
 
-#include "gfla_common.h"
+#include "lds_plane.h"
 
 namespace gfla {
 
 // Bijective XCD remap (cdna_hip_programming.md T1): the blocks that land on XCD x get the x-th contiguous share of
 // [0, nwg).  Correct for any nwg; a wrong placement guess only costs speed.
-__device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
+__host__ __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
   const int64_t q = nwg / kNumXCD, r = nwg % kNumXCD, xcd = bid % kNumXCD;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / kNumXCD;
 }
@@ -235,6 +235,36 @@ inline TileGeo row_tile_geometry(int64_t H, int64_t W) {
   g.ntx = ntx;
   g.nty = (int)ceil_div(H, th);
   g.threads = (int)ceil_div((int64_t)th * tw, 64) * 64;
+  return g;
+}
+
+// channels per workgroup of a tile kernel: `dflt` (tuning key `key` overrides) unless that leaves the launch under three
+// workgroups per CU
+inline int tile_channels(int key, int dflt, int64_t tiles, int64_t C) {
+  int G = tuning(key) > 0 ? tuning(key) : dflt;
+  if (tuning(key) <= 0)
+    while (G > 1 && tiles * ceil_div(C, G) < 3 * kNumCU) G /= 2;
+  return G > C ? (int)C : G;
+}
+
+// The whole launch geometry of one tile kernel, in one place (the launchers use it; gfla_big_plane_geometry hands it to the
+// CPU tests).  op: 0 block_extractor forward, 1 block_extractor backward, 2 resample2d forward / d/d input2 (gather),
+// 3 resample2d d/d input1 (scatter).  span = taps per axis (K + 1, or (k - 1) * dilation + 1); bytes_per_elem = LDS bytes one
+// window element needs per channel.
+struct BigGeo {
+  TileGeo tg;
+  int G, ngroups;
+  unsigned lds_bytes;
+  int64_t nwg;
+};
+inline BigGeo big_geometry(int op, int64_t B, int64_t C, int64_t H, int64_t W, int span, int bytes_per_elem) {
+  BigGeo g;
+  g.tg = op == 0 ? row_tile_geometry(H, W) : tile_geometry(H, W);
+  const int64_t tiles = B * g.tg.nty * g.tg.ntx;
+  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 ? tile_channels(37, 16, tiles, C) : tile_channels(34, 8, tiles, C);
+  g.ngroups = (int)ceil_div(C, g.G);
+  g.nwg = tiles * g.ngroups;
+  g.lds_bytes = tile_lds_request(g.tg.th, g.tg.tw, span, g.G, bytes_per_elem, lds_budget());
   return g;
 }
 

@@ -54,7 +54,8 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
  *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX)
  *   6: round 4 (gfla_convert_multi)
- *   7: round 5 (path ids 13-17, tuning keys 30-34: the big-plane kernels of csrc/tile_map.h) */
+ *   7: round 5 (path ids 13-17, tuning keys 30-40: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
+ *      gfla_xcd_swizzle) */
 #define GFLA_ABI_VERSION 7
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
@@ -115,6 +116,16 @@ enum gfla_path {
   GFLA_PATH_COUNT = 18
 };
 int64_t gfla_path_count(int path);
+
+/* Round 5, host logic of the big-plane tile kernels (csrc/tile_map.h), for tests -- no GPU needed.
+ * gfla_big_plane_geometry: op 0 block_extractor forward, 1 block_extractor backward, 2 resample2d forward / d/d input2,
+ *   3 resample2d d/d input1; (H, W) the flow / output grid, (Hs, Ws) the source plane, span = taps per axis; out[10] = in the
+ *   regime by default, tile rows, tile columns, tiles along x, tiles along y, threads per workgroup, channels per workgroup,
+ *   channel groups, dynamic LDS bytes requested, workgroups.
+ * gfla_xcd_swizzle: the block -> work item remap of those kernels (a bijection of [0, nwg)); -1 outside the range. */
+int gfla_big_plane_geometry(int op, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int span,
+                            int elem_size, int64_t *out);
+int64_t gfla_xcd_swizzle(int64_t block, int64_t nwg);
 
 /* ---- block_extractor ---------------------------------------------------------------------
  * forward : replaces block_extractor_cuda.forward(source, flow_field, output, kernel_size)

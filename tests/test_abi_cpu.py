@@ -152,3 +152,46 @@ def test_host_helpers_of_the_launch_merges(gfla):
     assert out[1] is None and out[2].dtype == torch.float32 and torch.equal(out[2], x16.float())
     back = _lib.convert_many([x32], torch.bfloat16)
     assert back[0].dtype == torch.bfloat16 and torch.equal(back[0], x32.to(torch.bfloat16))
+
+
+def test_big_plane_tile_geometry_and_xcd_remap_invariants(gfla):
+    """Host logic of round 5's tile kernels (csrc/tile_map.h) without a GPU.  Geometry: whatever it picks must fit the
+    hardware (<= 512 threads in whole waves, one pixel per thread, LDS request within the budget and at least 16 KB), cover
+    the map with its tiles and the channels with its groups, start tiles on 32-column boundaries, and leave at least three
+    workgroups per CU when the problem has them.  Regime: BASELINE configs[1] is in, the bench shapes (planes in LDS) and
+    many-plane problems are out.  Remap: a bijection of [0, nwg) for any nwg, and the blocks of one XCD (block % 8) get one
+    contiguous range."""
+    from global_flow_local_attention_amd import _lib
+    L = _lib.lib()
+    out = (ctypes.c_int64 * 10)()
+    po = ctypes.cast(out, ctypes.c_void_p)
+    seen = 0
+    for op in (0, 1, 2, 3):
+        for B in (1, 2, 32):
+            for C in (1, 3, 64, 256):
+                for (H, W) in ((256, 176), (7, 5), (64, 44), (33, 600), (1, 1), (500, 31)):
+                    for span in (3, 4, 6, 9):
+                        assert L.gfla_big_plane_geometry(op, B, C, H, W, H, W, span, 4, po) == 0
+                        regime, th, tw, ntx, nty, threads, G, ngroups, lds, nwg = list(out)
+                        seen += 1
+                        assert threads % 64 == 0 and th * tw <= threads <= 512 and th >= 1 and tw >= 1
+                        assert ntx * tw >= W and (ntx - 1) * tw < W and nty * th >= H and (nty - 1) * th < H
+                        assert tw == min(32, W)                                 # tiles start on 128-byte lines
+                        assert 1 <= G <= C and ngroups * G >= C and (ngroups - 1) * G < C
+                        assert nwg == B * ntx * nty * ngroups
+                        assert 16 * 1024 <= lds <= 64 * 1024 and lds % 256 == 0
+                        if B * ntx * nty * C >= 3 * 256:                        # enough work: at least three workgroups per CU
+                            assert nwg >= 3 * 256 or G == 1, (op, B, C, H, W, G, nwg)
+    assert seen > 1000
+    assert L.gfla_big_plane_geometry(0, 1, 64, 256, 176, 256, 176, 4, 4, po) == 0 and out[0] == 1     # configs[1]
+    assert L.gfla_big_plane_geometry(3, 1, 64, 256, 176, 256, 176, 4, 4, po) == 0 and out[0] == 1
+    assert L.gfla_big_plane_geometry(0, 32, 128, 64, 44, 64, 44, 6, 4, po) == 0 and out[0] == 0      # bench shape: planes in LDS
+    assert L.gfla_big_plane_geometry(2, 32, 64, 256, 176, 256, 176, 4, 4, po) == 0 and out[0] == 0   # many planes: row windows
+    assert L.gfla_big_plane_geometry(5, 1, 1, 1, 1, 1, 1, 1, 4, po) == -2 and L.gfla_big_plane_geometry(0, 1, 1, 1, 1, 1, 1, 1, 4, None) == -1
+    for nwg in (1, 7, 8, 9, 63, 64, 65, 1536, 1537, 2815, 4099):
+        img = [L.gfla_xcd_swizzle(b, nwg) for b in range(nwg)]
+        assert sorted(img) == list(range(nwg)), nwg
+        for x in range(min(8, nwg)):
+            mine = [img[b] for b in range(x, nwg, 8)]
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (nwg, x)      # contiguous, in launch order
+        assert L.gfla_xcd_swizzle(nwg, nwg) == -1 and L.gfla_xcd_swizzle(-1, nwg) == -1
