@@ -21,6 +21,8 @@
 //          second (float) window staged next to the accumulators.
 #pragma once
 
+#include <type_traits>
+
 #include "be_fwd_pix.h"
 #include "pin_regs.h"
 #include "tile_map.h"
@@ -30,10 +32,23 @@ namespace gfla {
 // ---- forward: per-pixel bodies shared by the window kernel (P = arithmetic type, LDS) and the global one (P = storage) ----
 // row(cc, r): pointer p such that p[c] is the source value at plane column c of the CLAMPED patch row r (0..K) of chunk
 // channel cc.  Output rows go to oc0 + cc * oplane + i * Wo.
+// Staged stores (an experiment, off by default: see launch_fwd_big).  K = 5, float, tiles of 32 columns: a lane's 5 outputs of
+// an output row are 20 bytes at a 20-byte stride --
+// a 16-byte and a 4-byte store instruction, i.e. TWO partial writes of every 128-byte line.  With `st` set, the wave parks the
+// row of all CH channels in its private LDS tile ([channel][tile row of the wave][32 * K]) and writes it out as whole 16-byte
+// pieces, consecutive lanes: one write per line (what be_fwd_wrow.h does per piece of a plane, here per output row of a tile).
+// seg0 = this wave's first tile row, output row 0, chunk channel 0; the wave's second tile row is K * Wo further down.
+template <typename T>
+struct BeStage {
+  T *tile;        // per-wave LDS, CH * 2 * 32 * K elements
+  T *seg0;        // global
+  int seg_len;    // elements of a segment (valid pixels of the tile row x K), a multiple of 4
+  bool row1;      // the wave's second tile row exists
+};
 template <typename T, typename P, int K, int CH, typename RowFn>
 __device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const int (&col)[K + 1], const typename Num<T>::acc (&ax)[K],
                                                    const typename Num<T>::acc (&ay)[K], T *__restrict__ oc0, int64_t oplane, int Wo,
-                                                   bool active) {
+                                                   bool active, const BeStage<T> *st = nullptr) {
   using A = typename Num<T>::acc;
   // no lane of the wave has a patch column clamped at the border: a patch row is base + 0..K (immediate offsets, pairs)
   const bool contiguous = __all(col[K] - col[0] == K);
@@ -71,14 +86,43 @@ __device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const int
     const A yB_P = ay[i], yT_P = 1 - yB_P;
     A hB[CH][K];
     hrows(i + 1, hB);
+    if (st) {   // (wave-uniform)
+      const int lane = threadIdx.x & 63;
+      T *mine = st->tile + (lane >> 5) * (32 * K) + (lane & 31) * K;
 #pragma unroll
-    for (int cc = 0; cc < CH; ++cc) {
-      T o[K];
+      for (int cc = 0; cc < CH; ++cc) {
 #pragma unroll
-      for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
-      if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
+        for (int j = 0; j < K; ++j) mine[cc * (2 * 32 * K) + j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
 #pragma unroll
-      for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
+        for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
+      }
+      // (LDS operations of one wave execute in order; the compiler only has to keep the program order)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      constexpr int VS = 32 * K / 4;   // 16-byte pieces of a full segment
+      typedef T V4 __attribute__((ext_vector_type(4)));
+      const int nv = st->seg_len >> 2;
+#pragma unroll
+      for (int e0 = 0; e0 < CH * 2 * VS; e0 += 64) {
+        const int e = e0 + lane;
+        const int seg = e / VS, v = e - seg * VS, cc = seg >> 1, r1 = seg & 1;
+        if (e < CH * 2 * VS && v < nv && cc < ncc && (!r1 || st->row1)) {
+          const V4 val = *reinterpret_cast<const V4 *>(st->tile + seg * (32 * K) + 4 * v);
+          *reinterpret_cast<V4 *>(st->seg0 + cc * oplane + (int64_t)(r1 * K + i) * Wo + 4 * v) = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        T o[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
+        if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
+#pragma unroll
+        for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
+      }
     }
   }
 }
@@ -202,14 +246,17 @@ inline int big_channels_per_wave(int64_t B, int64_t C, int64_t nblk, int ch, int
 }
 
 // ---- forward: the window kernel ------------------------------------------------------------------------------------------
-template <typename T, int K, int CH>
+// STAGE: staged stores (BeStage) -- the launcher picks it for K = 5, float, 32-column tiles and 16-byte-aligned rows; the
+// first CH * 2 * 32 * K elements per wave of the dynamic LDS are then the waves' tiles, the windows follow.
+template <typename T, int K, int CH, bool STAGE = false>
 __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ src, const T *__restrict__ flow,
                                                          T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf, int th,
                                                          int tw, int ntx, int nty, int G, int ngroups, int lds_elems,
                                                          int64_t nwg) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  A *planes = reinterpret_cast<A *>(gfla_smem);
+  constexpr int kStageElems = STAGE ? CH * 2 * 32 * K : 0;   // per wave
+  A *planes = reinterpret_cast<A *>(gfla_smem) + (STAGE ? (int)(blockDim.x >> 6) * kStageElems : 0);
   __shared__ int s_box[4];
   const int64_t v = xcd_swizzle(blockIdx.x, nwg);
   const int g = (int)(v % ngroups);
@@ -256,17 +303,30 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
     return;
   }
   const A *win0 = planes - (w.ymin * w.cols + w.xmin);   // (plane row, plane column) -> win0[row * cols + column]
+  // staged stores: whole wave or not at all (a lane off the dense path stores tap by tap, directly)
+  BeStage<T> stage{};
+  bool staged = false;
+  if constexpr (STAGE) {
+    const int wv = threadIdx.x >> 6, row0 = ty * th + 2 * wv;          // tw == 32: a wave = tile rows 2 wv, 2 wv + 1
+    staged = __all(px.dense || !active) && row0 < Hf;
+    stage.tile = reinterpret_cast<T *>(gfla_smem) + wv * kStageElems;
+    stage.seg_len = min(32, Wf - tx * tw) * K;
+    stage.row1 = 2 * wv + 1 < th && row0 + 1 < Hf;
+    stage.seg0 = out + ((int64_t)b * C + c0) * oplane + (int64_t)(K * row0) * Wo + K * (tx * tw);
+  }
   for (int cb = 0; cb < gc; cb += g_fit) {
     const int n = min(g_fit, gc - cb);
     stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, planes, w, n, vec);
     __syncthreads();
-    if (px.dense) {
+    if (staged || px.dense) {
       for (int cc0 = 0; cc0 < n; cc0 += CH) {
         const A *wc = win0 + (size_t)cc0 * w.size;
         const int y0c = px.y0c, cols = w.cols, wsz = w.size;
         auto row = [=](int cc, int r) { return wc + cc * wsz + clampi(y0c + r, 0, Hs - 1) * cols; };
+        BeStage<T> st_c = stage;
+        st_c.seg0 = stage.seg0 + (int64_t)(cb + cc0) * oplane;
         be_fwd_dense_chunk<T, A, K, CH>(row, min(CH, n - cc0), px.col, px.ax, px.ay, out0 + (int64_t)(cb + cc0) * oplane, oplane, Wo,
-                                        active);
+                                        active, staged ? &st_c : nullptr);
       }
     } else if (active) {
       for (int c = 0; c < n; ++c) {
@@ -307,6 +367,23 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
 #define GFLA_BE_FWD_TILE(CH_)                                                                                                       \
   launch_lds(be_fwd_tile_kernel<T, K, CH_>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C, \
              (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg)
+  if constexpr (std::is_same<T, float>::value && K == 5) {
+    // staged stores (BeStage): 32-column tiles, every output row and every tile's segment on 16-byte boundaries.  MEASURED AND
+    // NOT TAKEN (tuning key 41 = 1 turns it on): 71.7 -> 167.8 us at (1,64,256,176) -- an LDS round trip per output row and
+    // chunk costs far more than the second partial write of a line (profiles/r5_config2_sweeps.txt, session s13)
+    const bool ok = tuning(41) == 1 && tg.tw == 32 && ((K * Wf) & 3) == 0 && (((Wf % 32) * K) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((int64_t)K * Hf * K * Wf) % 4 == 0 && tuning(40) == 0;
+    if (ok) {
+      constexpr int CHS = 1;   // (two channels per pixel chunk + the staging spill registers: 256 VGPRs, 168 bytes of scratch)
+      const unsigned stage_bytes = (unsigned)(tg.threads / 64) * CHS * 2 * 32 * K * (unsigned)sizeof(T);
+      const unsigned total = lds_bytes + stage_bytes;
+      launch_lds(be_fwd_tile_kernel<T, K, CHS, true>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), total, stream, src, flow, out,
+                 (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups,
+                 (int)(lds_bytes / sizeof(A)), nwg);
+      *done = true;
+      return launch_status();
+    }
+  }
   if constexpr (sizeof(A) == 4) {   // tuning key 40: channels evaluated together per pixel (registers against requests in flight)
     if (tuning(40) == 1) GFLA_BE_FWD_TILE(1);
     else if (tuning(40) == 2) GFLA_BE_FWD_TILE(2);
