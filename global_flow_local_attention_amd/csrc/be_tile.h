@@ -631,7 +631,7 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \
-             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg, tuning(39))
+             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg, tile_probe_bits())
     if (gsrc && gflow) GFLA_BE_TILE_LAUNCH(true, true);
     else if (gsrc) GFLA_BE_TILE_LAUNCH(true, false);
     else GFLA_BE_TILE_LAUNCH(false, true);

@@ -899,7 +899,7 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
       const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
       if (nwg <= 0x7fffffffLL) {
         const unsigned lds_bytes = bg.lds_bytes;
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 0>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, static_cast<const T *>(nullptr), out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tile_probe_bits()));
         note_path(GFLA_PATH_RS_FWD_BIG);
         return launch_status();
       }
@@ -957,7 +957,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
         const unsigned lds_bytes = bg.lds_bytes;
         constexpr bool FIX = std::is_same<A, float>::value;
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg, tuning(39)));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_bwd1_tile_kernel<T, KH, FIX>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in2, gout, gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, trunc, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / 8), nwg, tile_probe_bits()));
         note_path(GFLA_PATH_RS_BWD1_TILE);
         st = launch_status();
         if (st != GFLA_OK) return st;
@@ -969,7 +969,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
         if (nwg > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
         const unsigned lds_bytes = bg.lds_bytes;
-        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tuning(39)));
+        GFLA_KH_SWITCH(k / 2, launch_lds(rs_gather_tile_kernel<T, KH, 2>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, in1, in2, gout, gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg, tile_probe_bits()));
         note_path(GFLA_PATH_RS_BWD2_BIG);
         st = launch_status();
       } else if (gin2) {

@@ -183,6 +183,16 @@ inline unsigned tile_lds_request(int th, int tw, int span, int G, int bytes_per_
   return (unsigned)((want + 255) & ~(int64_t)255);
 }
 
+// Timing-ablation bits of the tile kernels (tuning key 39; results are garbage): honoured only in `make PROBES=1` builds, a
+// default build ignores the key -- no user-reachable path that computes wrong results.
+inline int tile_probe_bits() {
+#ifdef GFLA_PROBES
+  return tuning(39);
+#else
+  return 0;
+#endif
+}
+
 // Host side: is this the regime of the big-plane kernels?  Few planes (the planes-in-LDS / windowed kernels get fewer
 // than ~4 workgroups per CU out of batch x channel groups) AND planes beyond the LDS budget.  tuning key 30: 1 = never
 // (round 1's windowed kernels), 2 = always (tests drive the kernels at small shapes).
