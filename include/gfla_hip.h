@@ -87,10 +87,11 @@ const char *gfla_status_string(int status);
  *   key 30: big-plane kernels (few planes, each beyond the LDS budget: csrc/tile_map.h)   0 auto, 1 never (round 1's
  *           row-window kernels), 2 always (tests drive them at small shapes)
  *   key 31 / 32: rows / columns of a tile (0 auto: 16 x 32)   key 35 / 36: the same for block_extractor's forward (0 auto:
- *           whole flow rows)   key 34 / 37: channels per workgroup of the scatter / gather tiles (0 auto: 8 / 8-16)
- *   key 39: timing ablations of the tile kernels -- only in `make PROBES=1` builds (results are garbage); a default build ignores it
- *     key 40: channels per pixel chunk of block_extractor's
- *           forward tiles   key 41: 1 = staged stores of its k = 5 form (measured 2.3x slower; off)
+ *           8 x 32)   key 34 / 37: channels per workgroup of the scatter / gather tiles (0 auto: 8 / 8-16)
+ *   key 39: timing ablations of the tile kernels -- only in `make PROBES=1` builds (results are garbage); a default build
+ *           ignores the key
+ *   key 40: channels per pixel chunk of block_extractor's forward tiles (0 auto)
+ *   key 41: 1 = staged stores of their k = 5 form (measured 2.3x slower; off by default, kept correct)
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
