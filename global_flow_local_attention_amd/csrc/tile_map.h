@@ -102,18 +102,19 @@ __device__ __forceinline__ void stage_windows_vec(const float *__restrict__ src0
     return c;
   };
   for (int f0 = threadIdx.x; f0 < total; f0 += blockDim.x * U) {
-    float4 v[U];
+    typedef float v4_t __attribute__((ext_vector_type(4)));   // (an array of HIP's float4 struct can end up in scratch)
+    v4_t v[U];
     int lo[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int f = min(f0 + u * (int)blockDim.x, total - 1);
       int go;
       const int c = locate(f, go, lo[u]);
-      v[u] = *reinterpret_cast<const float4 *>(src0 + (int64_t)c * plane + go);
+      v[u] = *reinterpret_cast<const v4_t *>(src0 + (int64_t)c * plane + go);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (f0 + u * (int)blockDim.x < total) *reinterpret_cast<float4 *>(lds + lo[u]) = v[u];
+      if (f0 + u * (int)blockDim.x < total) *reinterpret_cast<v4_t *>(lds + lo[u]) = v[u];
   }
 }
 
