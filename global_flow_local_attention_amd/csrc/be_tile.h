@@ -10,6 +10,9 @@
 //          evaluated separably exactly as be_fwd_pix.h does; the K outputs of an output row leave as one 16-byte + one
 //          4-byte store (k = 5).  Default tiles are WHOLE flow rows (tile_map.h: row_tile_geometry): the K*th output rows
 //          of a channel are then one contiguous piece of the output plane per workgroup -- the op is 96 % writes.
+//          (Measured and removed, round 5: staged stores for k = 5 -- the 20 bytes a lane writes per output row are a 16-byte
+//          and a 4-byte store, two partial writes of every line; parking a row in a per-wave LDS tile and writing whole
+//          16-byte pieces with consecutive lanes ran 71.7 -> 167.8 us: an LDS round trip per output row costs far more.)
 //          (First version, measured and replaced: lane = pixel with the patch read from GLOBAL memory -- be_fwd_gpix_kernel,
 //          kept as the per-tile fallback and under tuning key 38 = 1.  At (1,64,256,176) it ran at the store stream's rate
 //          on a zero flow, 23 us = 0.62 of HBM, but at 47 us on a smooth one whatever the channels per wave: every per-tap
@@ -28,130 +31,6 @@
 #include "tile_map.h"
 
 namespace gfla {
-
-// ---- forward: per-pixel bodies shared by the window kernel (P = arithmetic type, LDS) and the global one (P = storage) ----
-// row(cc, r): pointer p such that p[c] is the source value at plane column c of the CLAMPED patch row r (0..K) of chunk
-// channel cc.  Output rows go to oc0 + cc * oplane + i * Wo.
-// Staged stores (an experiment, off by default: see launch_fwd_big).  K = 5, float, tiles of 32 columns: a lane's 5 outputs of
-// an output row are 20 bytes at a 20-byte stride --
-// a 16-byte and a 4-byte store instruction, i.e. TWO partial writes of every 128-byte line.  With `st` set, the wave parks the
-// row of all CH channels in its private LDS tile ([channel][tile row of the wave][32 * K]) and writes it out as whole 16-byte
-// pieces, consecutive lanes: one write per line (what be_fwd_wrow.h does per piece of a plane, here per output row of a tile).
-// seg0 = this wave's first tile row, output row 0, chunk channel 0; the wave's second tile row is K * Wo further down.
-template <typename T>
-struct BeStage {
-  T *tile;        // per-wave LDS, CH * 2 * 32 * K elements
-  T *seg0;        // global
-  int seg_len;    // elements of a segment (valid pixels of the tile row x K), a multiple of 4
-  bool row1;      // the wave's second tile row exists
-};
-template <typename T, typename P, int K, int CH, typename RowFn>
-__device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const int (&col)[K + 1], const typename Num<T>::acc (&ax)[K],
-                                                   const typename Num<T>::acc (&ay)[K], T *__restrict__ oc0, int64_t oplane, int Wo,
-                                                   bool active, const BeStage<T> *st = nullptr) {
-  using A = typename Num<T>::acc;
-  // no lane of the wave has a patch column clamped at the border: a patch row is base + 0..K (immediate offsets, pairs)
-  const bool contiguous = __all(col[K] - col[0] == K);
-  // the bilinear form separated (be_fwd_wrow.h has the derivation): patch rows interpolated along x once, output row i = the
-  // blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand.  A patch row of ALL CH
-  // channels is requested at once (pin_regs.h), then interpolated.
-  auto hrows = [&](int r, A (&h)[CH][K]) {
-    A vv[CH * (K + 1)];
-    if (contiguous) {
-#pragma unroll
-      for (int cc = 0; cc < CH; ++cc) {
-        const P *p0 = row(min(cc, ncc - 1), r) + col[0];
-#pragma unroll
-        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(p0 + q);
-      }
-    } else {
-#pragma unroll
-      for (int cc = 0; cc < CH; ++cc) {
-        const P *pc = row(min(cc, ncc - 1), r);
-#pragma unroll
-        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(pc + col[q]);
-      }
-    }
-    pin_regs(vv);
-#pragma unroll
-    for (int cc = 0; cc < CH; ++cc)
-#pragma unroll
-      for (int j = 0; j < K; ++j)
-        h[cc][j] = fma_t(ax[j], vv[cc * (K + 1) + j + 1], (1 - ax[j]) * vv[cc * (K + 1) + j]);
-  };
-  A hA[CH][K];
-  hrows(0, hA);
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const A yB_P = ay[i], yT_P = 1 - yB_P;
-    A hB[CH][K];
-    hrows(i + 1, hB);
-    if (st) {   // (wave-uniform)
-      const int lane = threadIdx.x & 63;
-      T *mine = st->tile + (lane >> 5) * (32 * K) + (lane & 31) * K;
-#pragma unroll
-      for (int cc = 0; cc < CH; ++cc) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) mine[cc * (2 * 32 * K) + j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
-#pragma unroll
-        for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
-      }
-      // (LDS operations of one wave execute in order; the compiler only has to keep the program order)
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      constexpr int VS = 32 * K / 4;   // 16-byte pieces of a full segment
-      typedef T V4 __attribute__((ext_vector_type(4)));
-      const int nv = st->seg_len >> 2;
-#pragma unroll
-      for (int e0 = 0; e0 < CH * 2 * VS; e0 += 64) {
-        const int e = e0 + lane;
-        const int seg = e / VS, v = e - seg * VS, cc = seg >> 1, r1 = seg & 1;
-        if (e < CH * 2 * VS && v < nv && cc < ncc && (!r1 || st->row1)) {
-          const V4 val = *reinterpret_cast<const V4 *>(st->tile + seg * (32 * K) + 4 * v);
-          *reinterpret_cast<V4 *>(st->seg0 + cc * oplane + (int64_t)(r1 * K + i) * Wo + 4 * v) = val;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-    } else {
-#pragma unroll
-      for (int cc = 0; cc < CH; ++cc) {
-        T o[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
-        if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
-#pragma unroll
-        for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
-      }
-    }
-  }
-}
-// a coordinate within rounding of an integer: tap by tap, as the reference does (:69-84).  at(yrow) -> pointer to plane row
-// yrow (clamped) of this channel, indexed by clamped plane columns.
-template <typename T, typename P, int K, typename RowAt>
-__device__ __forceinline__ void be_fwd_taps_channel(RowAt at, int Hs, const int (&xL)[K], const int (&xR)[K],
-                                                    const typename Num<T>::acc (&ax)[K], typename Num<T>::acc fy0, int yf,
-                                                    T *__restrict__ oc, int Wo) {
-  using A = typename Num<T>::acc;
-#pragma unroll 1
-  for (int i = 0; i < K; ++i) {
-    const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
-    const A fdy = floor_t<A>(dy);
-    const P *rT = at(clampi((int)fdy, 0, Hs - 1)), *rB = at(clampi((int)(fdy + 1), 0, Hs - 1));
-    const A yB_P = dy - fdy, yT_P = 1 - yB_P;
-    T o[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const A xR_P = ax[j], xL_P = 1 - xR_P;
-      A s = (xL_P * yT_P) * Num<P>::ld(rT + xL[j]);
-      s = fma_t(xR_P * yT_P, Num<P>::ld(rT + xR[j]), s);
-      s = fma_t(xL_P * yB_P, Num<P>::ld(rB + xL[j]), s);
-      s = fma_t(xR_P * yB_P, Num<P>::ld(rB + xR[j]), s);
-      o[j] = Num<T>::from(s);
-    }
-    store_row<T, K, false>(oc + (int64_t)i * Wo, o);
-  }
-}
 
 // Per-pixel setup of both directions: flow pair, K fractions per axis, patch origin, dense flag, clamped columns.
 template <typename T, int K>
@@ -195,6 +74,105 @@ struct BePixel {
   }
 };
 
+// ---- forward: per-pixel bodies shared by the window kernel (P = arithmetic type, LDS) and the global one (P = storage) ----
+// row(cc, r): pointer p such that p[c] is the source value at plane column c of the CLAMPED patch row r (0..K) of chunk
+// channel cc.  Output rows go to oc0 + cc * oplane + i * Wo.
+#ifndef GFLA_BE_ROLL_FROM
+#define GFLA_BE_ROLL_FROM 5
+#endif
+constexpr int kBeRollFrom = GFLA_BE_ROLL_FROM;   // output-row loop rolled from this kernel size on
+template <typename T, typename P, int K, int CH, typename RowFn>
+__device__ __forceinline__ void be_fwd_dense_chunk(RowFn row, int ncc, const BePixel<T, K> &px, int yf, T *__restrict__ oc0,
+                                                   int64_t oplane, int Wo, bool active) {
+  using A = typename Num<T>::acc;
+  const int (&col)[K + 1] = px.col;
+  const A (&ax)[K] = px.ax;
+  // no lane of the wave has a patch column clamped at the border: a patch row is base + 0..K (immediate offsets, pairs)
+  const bool contiguous = __all(col[K] - col[0] == K);
+  // the bilinear form separated (be_fwd_wrow.h has the derivation): patch rows interpolated along x once, output row i = the
+  // blend of interpolated rows i and i + 1 -- the expressions of be_fwd_pix.h, operand for operand.  A patch row of ALL CH
+  // channels is requested at once (pin_regs.h), then interpolated.
+  auto hrows = [&](int r, A (&h)[CH][K]) {
+    A vv[CH * (K + 1)];
+    if (contiguous) {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const P *p0 = row(min(cc, ncc - 1), r) + col[0];
+#pragma unroll
+        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(p0 + q);
+      }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const P *pc = row(min(cc, ncc - 1), r);
+#pragma unroll
+        for (int q = 0; q <= K; ++q) vv[cc * (K + 1) + q] = Num<P>::ld(pc + col[q]);
+      }
+    }
+    pin_regs(vv);
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        h[cc][j] = fma_t(ax[j], vv[cc * (K + 1) + j + 1], (1 - ax[j]) * vv[cc * (K + 1) + j]);
+  };
+  A hA[CH][K];
+  hrows(0, hA);
+  auto out_row = [&](int i, A yB_P) {
+    const A yT_P = 1 - yB_P;
+    A hB[CH][K];
+    hrows(i + 1, hB);
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      T o[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) o[j] = Num<T>::from(fma_t(yB_P, hB[cc][j], yT_P * hA[cc][j]));
+      if (active && cc < ncc) store_row<T, K, false>(oc0 + cc * oplane + (int64_t)i * Wo, o);
+#pragma unroll
+      for (int j = 0; j < K; ++j) hA[cc][j] = hB[cc][j];
+    }
+  };
+  if constexpr (K >= kBeRollFrom) {
+    // rolled: five unrolled output rows cost ~200 registers (two waves per SIMD: k = 5 ran 70.4 us unrolled, 60.8 rolled at
+    // (1,64,256,176)); the row's fraction is re-derived with the expression that filled px.ay
+    // (block_extractor_kernel.cu:62-67): the same bits
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const A dy = (px.fy0 + (A)(i - K / 2)) + (A)yf;
+      out_row(i, dy - floor_t<A>(dy));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; ++i) out_row(i, px.ay[i]);
+  }
+}
+// a coordinate within rounding of an integer: tap by tap, as the reference does (:69-84).  at(yrow) -> pointer to plane row
+// yrow (clamped) of this channel, indexed by clamped plane columns.
+template <typename T, typename P, int K, typename RowAt>
+__device__ __forceinline__ void be_fwd_taps_channel(RowAt at, int Hs, const int (&xL)[K], const int (&xR)[K],
+                                                    const typename Num<T>::acc (&ax)[K], typename Num<T>::acc fy0, int yf,
+                                                    T *__restrict__ oc, int Wo) {
+  using A = typename Num<T>::acc;
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    const A dy = (fy0 + (A)(i - K / 2)) + (A)yf;
+    const A fdy = floor_t<A>(dy);
+    const P *rT = at(clampi((int)fdy, 0, Hs - 1)), *rB = at(clampi((int)(fdy + 1), 0, Hs - 1));
+    const A yB_P = dy - fdy, yT_P = 1 - yB_P;
+    T o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const A xR_P = ax[j], xL_P = 1 - xR_P;
+      A s = (xL_P * yT_P) * Num<P>::ld(rT + xL[j]);
+      s = fma_t(xR_P * yT_P, Num<P>::ld(rT + xR[j]), s);
+      s = fma_t(xL_P * yB_P, Num<P>::ld(rB + xL[j]), s);
+      s = fma_t(xR_P * yB_P, Num<P>::ld(rB + xR[j]), s);
+      o[j] = Num<T>::from(s);
+    }
+    store_row<T, K, false>(oc + (int64_t)i * Wo, o);
+  }
+}
+
 // ---- forward, first version: patch read from global memory (the per-tile fallback of the window kernel; key 38 = 1) --------
 template <typename T, int K, int CH>
 __global__ __launch_bounds__(256) void be_fwd_gpix_kernel(const T *__restrict__ src, const T *__restrict__ flow,
@@ -224,8 +202,7 @@ __global__ __launch_bounds__(256) void be_fwd_gpix_kernel(const T *__restrict__ 
       const T *plc = src_b + (int64_t)cb * plane;
       const int y0c = px.y0c;
       auto row = [=](int cc, int r) { return plc + (int64_t)cc * plane + clampi(y0c + r, 0, Hs - 1) * Ws; };
-      be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, c_end - cb), px.col, px.ax, px.ay, out_b + (int64_t)cb * oplane + ooff, oplane,
-                                      Wo, active);
+      be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, c_end - cb), px, yf, out_b + (int64_t)cb * oplane + ooff, oplane, Wo, active);
     }
   } else if (active) {
     for (int c = c_begin; c < c_end; ++c) {
@@ -246,17 +223,14 @@ inline int big_channels_per_wave(int64_t B, int64_t C, int64_t nblk, int ch, int
 }
 
 // ---- forward: the window kernel ------------------------------------------------------------------------------------------
-// STAGE: staged stores (BeStage) -- the launcher picks it for K = 5, float, 32-column tiles and 16-byte-aligned rows; the
-// first CH * 2 * 32 * K elements per wave of the dynamic LDS are then the waves' tiles, the windows follow.
-template <typename T, int K, int CH, bool STAGE = false>
+template <typename T, int K, int CH>
 __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ src, const T *__restrict__ flow,
                                                          T *__restrict__ out, int C, int Hs, int Ws, int Hf, int Wf, int th,
                                                          int tw, int ntx, int nty, int G, int ngroups, int lds_elems,
                                                          int64_t nwg) {
   using A = typename Num<T>::acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  constexpr int kStageElems = STAGE ? CH * 2 * 32 * K : 0;   // per wave
-  A *planes = reinterpret_cast<A *>(gfla_smem) + (STAGE ? (int)(blockDim.x >> 6) * kStageElems : 0);
+  A *planes = reinterpret_cast<A *>(gfla_smem);
   __shared__ int s_box[4];
   const int64_t v = xcd_swizzle(blockIdx.x, nwg);
   const int g = (int)(v % ngroups);
@@ -291,7 +265,7 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
         const T *plc = src0 + (int64_t)cb * plane;
         const int y0c = px.y0c;
         auto row = [=](int cc, int r) { return plc + (int64_t)cc * plane + clampi(y0c + r, 0, Hs - 1) * Ws; };
-        be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, gc - cb), px.col, px.ax, px.ay, out0 + (int64_t)cb * oplane, oplane, Wo, active);
+        be_fwd_dense_chunk<T, T, K, CH>(row, min(CH, gc - cb), px, yf, out0 + (int64_t)cb * oplane, oplane, Wo, active);
       }
     } else if (active) {
       for (int c = 0; c < gc; ++c) {
@@ -303,30 +277,16 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
     return;
   }
   const A *win0 = planes - (w.ymin * w.cols + w.xmin);   // (plane row, plane column) -> win0[row * cols + column]
-  // staged stores: whole wave or not at all (a lane off the dense path stores tap by tap, directly)
-  BeStage<T> stage{};
-  bool staged = false;
-  if constexpr (STAGE) {
-    const int wv = threadIdx.x >> 6, row0 = ty * th + 2 * wv;          // tw == 32: a wave = tile rows 2 wv, 2 wv + 1
-    staged = __all(px.dense || !active) && row0 < Hf;
-    stage.tile = reinterpret_cast<T *>(gfla_smem) + wv * kStageElems;
-    stage.seg_len = min(32, Wf - tx * tw) * K;
-    stage.row1 = 2 * wv + 1 < th && row0 + 1 < Hf;
-    stage.seg0 = out + ((int64_t)b * C + c0) * oplane + (int64_t)(K * row0) * Wo + K * (tx * tw);
-  }
   for (int cb = 0; cb < gc; cb += g_fit) {
     const int n = min(g_fit, gc - cb);
     stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, planes, w, n, vec);
     __syncthreads();
-    if (staged || px.dense) {
+    if (px.dense) {
       for (int cc0 = 0; cc0 < n; cc0 += CH) {
         const A *wc = win0 + (size_t)cc0 * w.size;
         const int y0c = px.y0c, cols = w.cols, wsz = w.size;
         auto row = [=](int cc, int r) { return wc + cc * wsz + clampi(y0c + r, 0, Hs - 1) * cols; };
-        BeStage<T> st_c = stage;
-        st_c.seg0 = stage.seg0 + (int64_t)(cb + cc0) * oplane;
-        be_fwd_dense_chunk<T, A, K, CH>(row, min(CH, n - cc0), px.col, px.ax, px.ay, out0 + (int64_t)(cb + cc0) * oplane, oplane, Wo,
-                                        active, staged ? &st_c : nullptr);
+        be_fwd_dense_chunk<T, A, K, CH>(row, min(CH, n - cc0), px, yf, out0 + (int64_t)(cb + cc0) * oplane, oplane, Wo, active);
       }
     } else if (active) {
       for (int c = 0; c < n; ++c) {
@@ -367,27 +327,10 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
 #define GFLA_BE_FWD_TILE(CH_)                                                                                                       \
   launch_lds(be_fwd_tile_kernel<T, K, CH_>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), lds_bytes, stream, src, flow, out, (int)C, \
              (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)(lds_bytes / sizeof(A)), nwg)
-  if constexpr (std::is_same<T, float>::value && K == 5) {
-    // staged stores (BeStage): 32-column tiles, every output row and every tile's segment on 16-byte boundaries.  MEASURED AND
-    // NOT TAKEN (tuning key 41 = 1 turns it on): 71.7 -> 167.8 us at (1,64,256,176) -- an LDS round trip per output row and
-    // chunk costs far more than the second partial write of a line (profiles/r5_config2_sweeps.txt, session s13)
-    const bool ok = tuning(41) == 1 && tg.tw == 32 && ((K * Wf) & 3) == 0 && (((Wf % 32) * K) & 3) == 0 &&
-                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((int64_t)K * Hf * K * Wf) % 4 == 0 && tuning(40) == 0;
-    if (ok) {
-      constexpr int CHS = 1;   // (two channels per pixel chunk + the staging spill registers: 256 VGPRs, 168 bytes of scratch)
-      const unsigned stage_bytes = (unsigned)(tg.threads / 64) * CHS * 2 * 32 * K * (unsigned)sizeof(T);
-      const unsigned total = lds_bytes + stage_bytes;
-      launch_lds(be_fwd_tile_kernel<T, K, CHS, true>, dim3((unsigned)nwg), dim3((unsigned)tg.threads), total, stream, src, flow, out,
-                 (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups,
-                 (int)(lds_bytes / sizeof(A)), nwg);
-      *done = true;
-      return launch_status();
-    }
-  }
   if constexpr (sizeof(A) == 4) {   // tuning key 40: channels evaluated together per pixel (registers against requests in flight)
     if (tuning(40) == 1) GFLA_BE_FWD_TILE(1);
     else if (tuning(40) == 2) GFLA_BE_FWD_TILE(2);
-    else if (tuning(40) == 4 && K <= 4) GFLA_BE_FWD_TILE(4);
+    else if (tuning(40) == 4) GFLA_BE_FWD_TILE(4);
     else GFLA_BE_FWD_TILE(CH);
   } else {
     GFLA_BE_FWD_TILE(CH);

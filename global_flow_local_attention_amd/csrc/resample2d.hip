@@ -731,116 +731,11 @@ __global__ __launch_bounds__(512) void rs_gather_tile_kernel(const T *__restrict
   }
 }
 
-// Forward, third version -- an experiment that lost (see the launcher), kept correct behind tuning key 42 -- (float, 16-byte-
-// aligned planes): ONE workgroup per tile for ALL channels, the windows streamed through two LDS buffers.  rs_gather_tile_kernel pays its per-pixel setup once per channel group (4-8 groups), and its workgroups move
-// in lockstep -- everybody sets up, then everybody stages, then everybody computes: of its 20 us at (1,64,256,176), 8.7 are
-// launch + setup, 3 staging, 8.5 the channel loop, and nothing overlaps (profiles/r5_rs_fwd_tile_ablations.txt).  Here:
-//   workgroup = (tile of 8 x 32 pixels) x 2 halves of 256 threads; both halves set up the same 256 pixels (2x instead of
-//   4-8x), a stage = `ns` channels' windows, half h computes the h-th half of a stage's channels;
-//   the NEXT stage's windows are requested (global -> registers, 16 bytes per lane) before this stage is computed and
-//   written to the other buffer after it: one barrier per stage, the loads' latency under the channel loop.
-// (one workgroup of 8 waves per CU -- the LDS buffers take most of it --, i.e. two waves per SIMD: the register budget is 256,
-// said explicitly, else hipcc aims at four waves and spills the prefetch registers)
-template <int KH>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) void rs_fwd_stream_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
-                                                           float *__restrict__ outp, int C, int Hi, int Wi, int H, int W, int dil,
-                                                           int th, int ntx, int nty, int lds_elems, int64_t nwg) {
-  constexpr int N = 2 * KH, U = 8, TW = 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
-  float *lds = reinterpret_cast<float *>(gfla_smem);
-  __shared__ int s_box[4];
-  const int64_t v = xcd_swizzle(blockIdx.x, nwg);
-  const int tile = (int)(v % ((int64_t)ntx * nty)), b = (int)(v / ((int64_t)ntx * nty));
-  const int ty = tile / ntx, tx = tile - ty * ntx;
-  const int half = threadIdx.x >> 8, tp = threadIdx.x & 255;
-  const int ly = tp >> 5, lx = tp & 31;
-  const int y = ty * th + ly, x = tx * TW + lx;
-  const bool active = ly < th && y < H && x < W;
-  const int HW = H * W, plane_sz = Hi * Wi;
-  const int p = active ? y * W + x : 0;
-  box_init(s_box);
-  __syncthreads();
-  Taps<float, KH> t;
-  {
-    const float *i2 = in2 + (int64_t)b * 3 * HW + p;
-    t.template init<2>(i2[0], i2[HW], i2[2 * HW], x, y, Hi, Wi, dil, false, 1);
-  }
-  box_reduce(s_box, active ? t.row_off(0) : 0x7fffffff, active ? t.col_off(0) : 0x7fffffff, active ? t.row_off(N - 1) : -1,
-             active ? t.col_off(N - 1) : -1);
-  __syncthreads();
-  const TileWin w = tile_window_vec(s_box, Wi, true);
-  // channels per stage: what two buffers hold, at most 16, even (two halves); 0 = the tile reads global memory
-  int ns = window_worth_staging(w, th, TW) ? min(16, lds_elems / max(2 * w.size, 1)) & ~1 : 0;
-  if (ns > C) ns = C;
-  const float *in1_b = in1 + (int64_t)b * C * plane_sz;
-  float *out_p = outp + (int64_t)b * C * HW + p;
-  if (ns < 1) {
-#pragma unroll
-    for (int f = 0; f < KH; ++f) t.yT[f] *= Wi, t.yB[f] *= Wi;
-    const int c_lo = half * ((C + 1) / 2), c_hi = half ? C : (C + 1) / 2;
-    if (active && c_hi > c_lo) rs_fwd_pixel<float, float, KH, float>(t, in1_b + (int64_t)c_lo * plane_sz, plane_sz, out_p + (int64_t)c_lo * HW, HW, c_hi - c_lo);
-    return;
-  }
-#pragma unroll
-  for (int f = 0; f < KH; ++f) t.yT[f] *= w.cols, t.yB[f] *= w.cols;
-  // staging map of this thread: up to U 16-byte pieces of a stage (the same for every stage)
-  const int c4 = w.cols >> 2, per = w.rows * c4, total = ns * per;
-  int goff[U], loff[U];
-  {
-    const float inv_per = 1.0f / (float)per, inv_c4 = 1.0f / (float)c4;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int f = min((int)threadIdx.x + u * 512, total - 1);
-      int c = (int)(((float)f + 0.5f) * inv_per);
-      c -= (c * per > f);
-      c += ((c + 1) * per <= f);
-      const int e = f - c * per;
-      int r = (int)(((float)e + 0.5f) * inv_c4);
-      r -= (r * c4 > e);
-      r += ((r + 1) * c4 <= e);
-      const int q = (e - r * c4) << 2;
-      goff[u] = c * plane_sz + (w.ymin + r) * Wi + w.xmin + q;
-      loff[u] = c * w.size + r * w.cols + q;
-    }
-  }
-  const int buf_elems = ns * w.size;
-  const int shift = w.ymin * w.cols + w.xmin;
-  // (a stage is at most U * 512 pieces: ns * size <= lds_elems / 2 <= 16384 elements, the launcher caps lds_elems)
-  typedef float pf4_t __attribute__((ext_vector_type(4)));   // (HIP's float4 struct kept this array in scratch)
-  pf4_t pf[U];
-#define GFLA_RS_REQUEST(C0, NCH)                                                                         \
-  {                                                                                                      \
-    const float *base_ = in1_b + (int64_t)(C0) * plane_sz;                                               \
-    const int lim_ = (NCH) * per;                                                                        \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                      \
-      const int f_ = (int)threadIdx.x + u * 512;                                                         \
-      pf[u] = *reinterpret_cast<const pf4_t *>(base_ + (f_ < lim_ ? goff[u] : goff[0]));                \
-    }                                                                                                    \
-  }
-#define GFLA_RS_COMMIT(BUF, NCH)                                                                         \
-  {                                                                                                      \
-    const int lim_ = (NCH) * per;                                                                        \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                        \
-      if ((int)threadIdx.x + u * 512 < lim_) *reinterpret_cast<pf4_t *>((BUF) + loff[u]) = pf[u];       \
-  }
-  const int nstages = (C + ns - 1) / ns;
-  GFLA_RS_REQUEST(0, min(ns, C));
-  GFLA_RS_COMMIT(lds, min(ns, C));
-  __syncthreads();
-  for (int s_ = 0; s_ < nstages; ++s_) {
-    const int c0 = s_ * ns, n = min(ns, C - c0);
-    const bool more = s_ + 1 < nstages;
-    if (more) GFLA_RS_REQUEST(c0 + ns, min(ns, C - c0 - ns));
-    const float *buf = lds + (s_ & 1) * buf_elems;
-    const int n0 = (n + 1) >> 1, cl = half ? n0 : 0, cn = half ? n - n0 : n0;
-    if (active && cn > 0)
-      rs_fwd_pixel<float, float, KH, float>(t, buf + cl * w.size - shift, w.size, out_p + (int64_t)(c0 + cl) * HW, HW, cn);
-    if (more) GFLA_RS_COMMIT(lds + ((s_ + 1) & 1) * buf_elems, min(ns, C - c0 - ns));
-    __syncthreads();
-  }
-#undef GFLA_RS_REQUEST
-#undef GFLA_RS_COMMIT
-}
+// (Measured and removed, round 5: the forward as ONE workgroup per 8 x 32 tile for all channels, two halves of 256 threads,
+// the windows streamed through two LDS buffers with the next stage's 16-byte requests in flight under the channel loop --
+// setup 2x instead of 4-8x, staging overlapped.  22.8 us against this kernel's 19.7 at (1,64,256,176), 73 against 31 on a wild
+// flow: 192 workgroups of two waves per SIMD leave a quarter of the CUs idle and hide less latency than the extra setups
+// cost.  profiles/r5_config2_sweeps.txt, session s15; the kernel is in the history of this file.)
 
 // d/d input1 is a SCATTER: workgroup = (tile of th x tw pixels, G channels), one pixel per thread with its taps kept in
 // registers.  The gradient planes are accumulated in an LDS window = the bounding box of the tile's taps (from the flow, on
@@ -1003,27 +898,6 @@ static int resample2d_fwd(const T *in1, const T *in2, T *out, int64_t B, int64_t
   using A = typename Num<T>::acc;
   if (tuning(6) != 1 && big_plane_regime(B, C, Hi * Wi * (int64_t)sizeof(A), lds_budget())) {
     // few planes far beyond the LDS budget (BASELINE configs[1]): one tap setup per pixel and chunk of channels, global gathers
-    if constexpr (std::is_same<T, float>::value) {
-      // one workgroup per tile for all channels, windows streamed through two LDS buffers (rs_fwd_stream_kernel).  MEASURED
-      // AND NOT TAKEN (tuning key 42 = 1 turns it on; key 43: its LDS bytes in KB, 0 = 120): 22.8 us against the channel-group
-      // tiles' 19.7 at (1,64,256,176), 73 against 31 on a wild flow -- 192 workgroups of two waves per SIMD leave a quarter of
-      // the CUs idle and hide less latency than four to eight times the setup costs (profiles/r5_config2_sweeps.txt, s15)
-      const bool vec_ok = (Wi & 3) == 0 && ((Hi * Wi) & 3) == 0 && (reinterpret_cast<uintptr_t>(in1) & 15) == 0;
-      if (tuning(38) != 1 && tuning(42) == 1 && vec_ok && Hi * Wi <= 0x3fffffffLL && W >= 32) {
-        const int th = tuning(31) > 0 && tuning(31) <= 8 ? tuning(31) : 8;
-        const int ntx = (int)ceil_div(W, 32), nty = (int)ceil_div(H, th);
-        const int64_t nwg = B * ntx * nty;
-        // a stage of 16 channels must fit U = 8 pieces per thread: window size <= 8 * 512 * 4 / 16 = 1024 elements ... the
-        // kernel takes fewer channels per stage for larger boxes through lds_elems: cap it accordingly
-        unsigned lds_bytes = (unsigned)((tuning(43) > 0 ? tuning(43) : 120) * 1024);
-        if (lds_bytes > 2u * 8 * 512 * 16) lds_bytes = 2u * 8 * 512 * 16;   // two buffers of at most U * 512 pieces
-        if (nwg <= 0x7fffffffLL) {
-          GFLA_KH_SWITCH(k / 2, launch_lds(rs_fwd_stream_kernel<KH>, dim3((unsigned)nwg), dim3(512), lds_bytes, stream, in1, in2, out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, th, ntx, nty, (int)(lds_bytes / 4), nwg));
-          note_path(GFLA_PATH_RS_FWD_BIG);
-          return launch_status();
-        }
-      }
-    }
     if (tuning(38) != 1 && sizeof(T) >= 4 && Hi * Wi <= 0x3fffffffLL) {   // planes staged into bounding-box windows
       const BigGeo bg = big_geometry(2, B, C, H, W, (k - 1) * dil + 1, (int)sizeof(A));
       const TileGeo tg = bg.tg;

@@ -91,9 +91,6 @@ const char *gfla_status_string(int status);
  *   key 39: timing ablations of the tile kernels -- only in `make PROBES=1` builds (results are garbage); a default build
  *           ignores the key
  *   key 40: channels per pixel chunk of block_extractor's forward tiles (0 auto)
- *   key 41: 1 = staged stores of their k = 5 form (measured 2.3x slower; off by default, kept correct)
- *   key 42: 1 = resample2d forward tiles as one workgroup per tile streaming all channels (measured 15 % slower; off), key 43
- *           its LDS KB
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
