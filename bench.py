@@ -725,6 +725,11 @@ def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "n
         if kind == "near_integer":
             sign = torch.where(torch.randn(B, 2, H, W, device=device, generator=g) > 0, 1.0, -1.0)
             return (torch.round(n * 3) + sign * 2.0 ** -22).contiguous()
+        if kind in ("expand", "compress"):   # probes (tools/bench_config2.py): a flow that spreads / squeezes the sample points
+            sgn = 0.2 if kind == "expand" else -0.2
+            xs = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, 1, W) - W / 2
+            ys = torch.arange(H, device=device, dtype=torch.float32).view(1, 1, H, 1) - H / 2
+            return torch.cat((sgn * xs.expand(B, 1, H, W), sgn * ys.expand(B, 1, H, W)), 1).contiguous() + 0.37
         f = n * 2                      # oob: every sample far outside the map, through all four sides
         f[:, 0] += 1000.0
         f[:, 1] -= 1000.0
