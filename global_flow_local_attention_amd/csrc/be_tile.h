@@ -361,11 +361,70 @@ struct BeGlobalSink {
 
 // One channel of one flow pixel: fold the K x K gradients into the dense patch and hand its rows to `sink`; accumulate
 // d/dflow.  spl[row * spitch + col] = this channel's source value (a window or the plane), gblk = &grad_out[b, c, yf*K, xf*K].
-template <typename T, typename P, int K, bool NEED_SRC, bool NEED_FLOW, typename Sink>
+// Neighbouring lanes of a wave whose patches are the same rows shifted by ONE column (the usual case: consecutive flow
+// pixels, a flow that changes by less than a pixel between them) send K of their K + 1 patch-row values to the same
+// addresses.  With FOLD those are summed across the lanes first -- K `v_add_f32_dpp wave_shr:1` per patch row -- so that a row
+// leaves through ONE atomic per lane plus K sparse ones issued only by the lanes at the end of a run (nobody to hand the
+// partial sums to).  An LDS atomic instruction costs the CU ~6-9 clocks conflict-free whatever the number of active lanes
+// (tools/ubench/lds_atomics_sparse.hip) and 20-40 with the conflicts of real patch rows: the full-wave ones are what is saved.
+// prev: the lane below holds the patch one column to the left (its column q + 1 = this lane's column q, same rows, both
+// dense and inside the image); next: the lane above is linked to this one.
+#ifndef GFLA_BE_BOTH_MAX
+#define GFLA_BE_BOTH_MAX 16   // largest K*K whose both-gradient kernel takes the fold and the batched requests
+#endif
+struct BeLinks {
+  bool prev, next;
+};
+template <typename T, int K>
+__device__ __forceinline__ BeLinks be_links(const BePixel<T, K> &px, bool active, bool enable) {
+  const int ok = (active && px.dense) ? 1 : 0;
+  int same = __builtin_amdgcn_update_dpp(0, ok, 0x138, 0xf, 0xf, false) & ok;   // wave_shr:1 -- lane i reads lane i - 1
+  same &= __builtin_amdgcn_update_dpp(0x7fffffff, px.y0c, 0x138, 0xf, 0xf, false) == px.y0c ? 1 : 0;
+#pragma unroll
+  for (int q = 0; q < K; ++q) same &= __builtin_amdgcn_update_dpp(-7, px.col[q + 1], 0x138, 0xf, 0xf, false) == px.col[q] ? 1 : 0;
+  if ((threadIdx.x & 63) == 0 || !enable) same = 0;
+  BeLinks l;
+  l.prev = same != 0;
+  l.next = __builtin_amdgcn_update_dpp(0, same, 0x130, 0xf, 0xf, false) != 0;   // wave_shl:1 -- lane i reads lane i + 1
+  return l;
+}
+
+// gall[i * K + j] = grad_out[b, c, yf*K + i, xf*K + j]: the caller requests a channel's (or two channels') K x K block in ONE
+// batch (be_load_gblock + pin_regs).  With a row's K values requested per row, as the first version did, a wave has 12-20 bytes
+// per lane in flight, a CU 12 KB, the chip 3 MB -- a quarter of what 8 TB/s x ~1.5 us of latency needs: d/dflow alone ran at
+// 2.3 TB/s of gradient reads whatever the tile shape (profiles/r5_config2_sweeps.txt).
+template <typename T, int K>
+__device__ __forceinline__ void be_load_gblock(const T *__restrict__ gblk, int Wo, typename Num<T>::acc *g) {
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) g[i * K + j] = Num<T>::ld(gblk + i * Wo + j);
+}
+// BATCH false: gall == nullptr, a row's K gradients are requested per row from gblk (what the k = 5 kernel with BOTH gradients
+// keeps: the block in registers costs it 169 registers, or 128 and spills -- measured 166 against 160 us).
+template <typename T, typename P, int K, bool NEED_SRC, bool NEED_FLOW, bool FOLD = false, bool BATCH = true, typename Sink>
 __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__restrict__ spl, int spitch,
-                                                   const T *__restrict__ gblk, int Wo, int Hs, const BePixel<T, K> &px, int yf,
-                                                   typename Num<T>::acc &gx_acc, typename Num<T>::acc &gy_acc) {
+                                                   const typename Num<T>::acc *gall, const T *__restrict__ gblk, int Wo, int Hs,
+                                                   const BePixel<T, K> &px, int yf, typename Num<T>::acc &gx_acc,
+                                                   typename Num<T>::acc &gy_acc, BeLinks lk = BeLinks{false, false}) {
   using A = typename Num<T>::acc;
+  // one patch row out: plain, or folded across linked lanes (see BeLinks)
+  auto emit = [&](int r, const A (&rw)[K + 1]) {
+    if constexpr (FOLD) {
+      A t = rw[K];
+#pragma unroll
+      for (int q = K - 1; q >= 0; --q) {
+        if (!lk.next && t != 0) sink.add(r, px.col[q + 1], t);
+        const A from_prev = __builtin_amdgcn_update_dpp((A)0, t, 0x138, 0xf, 0xf, false);
+        t = rw[q] + (lk.prev ? from_prev : (A)0);
+      }
+      if (t != 0) sink.add(r, px.col[0], t);
+    } else {
+#pragma unroll
+      for (int q = 0; q <= K; ++q)
+        if (rw[q] != 0) sink.add(r, px.col[q], rw[q]);
+    }
+  };
   A rowA[K + 1], vA[K + 1];
   int rA = clampi(px.y0c, 0, Hs - 1);
 #pragma unroll
@@ -373,28 +432,49 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__
     rowA[q] = 0;
     vA[q] = NEED_FLOW ? (A)Num<P>::ld(spl + rA * spitch + px.col[q]) : (A)0;
   }
+  // The row loop stays rolled (unrolled it costs 146 / 256+ registers at k = 3 / 5 against 100 / 122): the block is kept in
+  // registers and ROTATED by one row per iteration -- K (K - 1) moves per row against the ~30 K operations of a row.
+  A gq[BATCH ? K * K : 1];
+  if constexpr (BATCH) {
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) gq[e] = gall[e];
+  }
 #pragma unroll 1
   for (int i = 0; i < K; ++i) {
     const A dy = (px.fy0 + (A)(i - K / 2)) + (A)yf;  // block_extractor_kernel.cu:132-136
     const A yB_P = dy - floor_t<A>(dy), yT_P = 1 - yB_P;
     const int rB = clampi(px.y0c + i + 1, 0, Hs - 1);
-    // this row's K incoming gradients and (for d/dflow) the next patch row, requested together (pin_regs.h)
-    A ld_[NEED_FLOW ? 2 * K + 1 : K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) ld_[j] = Num<T>::ld(gblk + i * Wo + j);
-    if constexpr (NEED_FLOW) {
-#pragma unroll
-      for (int q = 0; q <= K; ++q) ld_[K + q] = (A)Num<P>::ld(spl + rB * spitch + px.col[q]);
-    }
-    pin_regs(ld_);
     A gv[K], rowB[K + 1], vB[K + 1];
+    if constexpr (BATCH) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) gv[j] = ld_[j];
+      for (int j = 0; j < K; ++j) gv[j] = gq[j];
+#pragma unroll
+      for (int e = 0; e + K < K * K; ++e) gq[e] = gq[e + K];
+      if constexpr (NEED_FLOW) {   // the next patch row of the source, requested together (pin_regs.h)
+#pragma unroll
+        for (int q = 0; q <= K; ++q) vB[q] = (A)Num<P>::ld(spl + rB * spitch + px.col[q]);
+        pin_regs(vB);
+      }
+    } else {   // this row's K incoming gradients and (for d/dflow) the next patch row, requested together
+      A ld_[NEED_FLOW ? 2 * K + 1 : K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) ld_[j] = Num<T>::ld(gblk + i * Wo + j);
+      if constexpr (NEED_FLOW) {
+#pragma unroll
+        for (int q = 0; q <= K; ++q) ld_[K + q] = (A)Num<P>::ld(spl + rB * spitch + px.col[q]);
+      }
+      pin_regs(ld_);
+#pragma unroll
+      for (int j = 0; j < K; ++j) gv[j] = ld_[j];
+      if constexpr (NEED_FLOW) {
+#pragma unroll
+        for (int q = 0; q <= K; ++q) vB[q] = ld_[K + q];
+      }
+    }
 #pragma unroll
     for (int q = 0; q <= K; ++q) {
       rowB[q] = 0;
-      if constexpr (NEED_FLOW) vB[q] = ld_[K + q];
-      else vB[q] = 0;
+      if constexpr (!NEED_FLOW) vB[q] = 0;
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -412,11 +492,7 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__
     }
     // (the test for zero stays: dropping it -- an exec-mask round trip per atomic -- measured 67 -> 66 us (k = 3) on a smooth
     // flow and costs integer flows 16 atomics instead of 9)
-    if (NEED_SRC) {
-#pragma unroll
-      for (int q = 0; q <= K; ++q)
-        if (rowA[q] != 0) sink.add(rA, px.col[q], rowA[q]);
-    }
+    if (NEED_SRC) emit(rA, rowA);
 #pragma unroll
     for (int q = 0; q <= K; ++q) {
       rowA[q] = rowB[q];
@@ -424,11 +500,7 @@ __device__ __forceinline__ void be_bwd_pixel_dense(const Sink &sink, const P *__
     }
     rA = rB;
   }
-  if (NEED_SRC) {
-#pragma unroll
-    for (int q = 0; q <= K; ++q)
-      if (rowA[q] != 0) sink.add(rA, px.col[q], rowA[q]);
-  }
+  if (NEED_SRC) emit(rA, rowA);
 }
 
 // the reference's own tap-by-tap form (a tap's floor() landed one off the dense patch)
@@ -465,11 +537,12 @@ __device__ __forceinline__ void be_bwd_pixel_taps(const Sink &sink, const P *__r
 }
 
 template <typename T, int K, bool NEED_SRC, bool NEED_FLOW>
-__global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ src, const T *__restrict__ flow,
+__global__ __launch_bounds__(512, (sizeof(T) == 4 ? 4 : 2)) void be_bwd_tile_kernel(const T *__restrict__ src, const T *__restrict__ flow,
                                                          const T *__restrict__ gout, T *__restrict__ gsrc,
                                                          typename Num<T>::acc *__restrict__ gflow, int C, int Hs, int Ws,
                                                          int Hf, int Wf, int th, int tw, int ntx, int nty, int G, int ngroups,
-                                                         int lds_bytes, int64_t nwg, int abl) {
+                                                         int lds_bytes, int64_t nwg, int abl, int fold) {
+  // fold: patch rows summed across linked lanes before the atomics (BeLinks; tuning key 41 = 1 turns it off)
   // abl (tuning key 39, timing ablations, results garbage): 1 = stop after setup / box, 2 = no pixel loop, 4 = no flush,
   // 8 = no staging of the source window
   using A = typename Num<T>::acc;
@@ -500,6 +573,11 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
   __syncthreads();
   const bool vec = NEED_FLOW && window_vec_ok(src + ((int64_t)b * C + g * G) * plane, plane, Ws);
   const TileWin w = tile_window_vec(s_box, Ws, vec);
+  // float patch rows (one DPP add per fold); not where both gradients at k >= 5 share the registers: that kernel measured
+  // slower with either change (zero flow 111 -> 123 us with the fold, -> 169 with the fold at 168 registers) and keeps the first form
+  constexpr bool kFold = NEED_SRC && std::is_same<A, float>::value && !(NEED_FLOW && K * K > GFLA_BE_BOTH_MAX);
+  BeLinks lk{false, false};
+  if constexpr (kFold) lk = be_links<T, K>(px, active, fold != 0);
   constexpr int kPerElem = (NEED_SRC ? (int)sizeof(lds_acc_t) : 0) + (NEED_FLOW ? (int)sizeof(A) : 0);
   const int g_fit = min(gc, lds_bytes / max(w.size * kPerElem, 1));
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
@@ -515,9 +593,9 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
     if (active) {
       for (int c = 0; c < gc; ++c) {
         BeGlobalSink<T> sink{gsrc0 + (int64_t)c * plane, Ws};
-        if (px.dense)
-          be_bwd_pixel_dense<T, T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, Ws, gblk0 + (int64_t)c * oplane, Wo, Hs,
-                                                           px, yf, gx_acc, gy_acc);
+        if (px.dense)   // (requests per row: this rare path must not set the kernel's register count)
+          be_bwd_pixel_dense<T, T, K, NEED_SRC, NEED_FLOW, false, false>(sink, src0 + (int64_t)c * plane, Ws, nullptr,
+                                                                         gblk0 + (int64_t)c * oplane, Wo, Hs, px, yf, gx_acc, gy_acc);
         else
           be_bwd_pixel_taps<T, T, K, NEED_SRC, NEED_FLOW>(sink, src0 + (int64_t)c * plane, Ws, gblk0 + (int64_t)c * oplane, Wo, Hs,
                                                           px, yf, gx_acc, gy_acc);
@@ -534,12 +612,20 @@ __global__ __launch_bounds__(512) void be_bwd_tile_kernel(const T *__restrict__ 
       if (NEED_FLOW && !(abl & 8)) stage_windows<T, A>(src0 + (int64_t)cb * plane, plane, Ws, splanes, w, n, vec);
       __syncthreads();
       if (active && !(abl & 2)) {
+        // a channel's K x K gradient block in ONE batch of requests (be_load_gblock), except where both gradients at k >= 5
+        // leave no registers for it
+        constexpr bool kBatch = !(NEED_SRC && NEED_FLOW && K * K > GFLA_BE_BOTH_MAX);
         for (int c = 0; c < n; ++c) {
+          const T *gb = gblk0 + (int64_t)(cb + c) * oplane;
+          A gl[kBatch ? K * K : 1];
+          if constexpr (kBatch) {
+            be_load_gblock<T, K>(gb, Wo, gl);
+            pin_regs(gl);
+          }
           BeWinSink sink{gplanes + (size_t)c * w.size - shift, w.cols};
           const A *spl = splanes + (size_t)c * w.size - shift;
-          const T *gb = gblk0 + (int64_t)(cb + c) * oplane;
           if (px.dense)
-            be_bwd_pixel_dense<T, A, K, NEED_SRC, NEED_FLOW>(sink, spl, w.cols, gb, Wo, Hs, px, yf, gx_acc, gy_acc);
+            be_bwd_pixel_dense<T, A, K, NEED_SRC, NEED_FLOW, kFold, kBatch>(sink, spl, w.cols, gl, gb, Wo, Hs, px, yf, gx_acc, gy_acc, lk);
           else
             be_bwd_pixel_taps<T, A, K, NEED_SRC, NEED_FLOW>(sink, spl, w.cols, gb, Wo, Hs, px, yf, gx_acc, gy_acc);
         }
@@ -574,7 +660,8 @@ static int launch_be_bwd_tile(const T *src, const T *flow, const T *gout, T *gsr
     const dim3 grid((unsigned)nwg), blk((unsigned)tg.threads);
 #define GFLA_BE_TILE_LAUNCH(S, F)                                                                                          \
   launch_lds(be_bwd_tile_kernel<T, K, S, F>, grid, blk, lds_bytes, stream, src, flow, gout, gsrc, gflow, (int)C, (int)Hs,  \
-             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg, tile_probe_bits())
+             (int)Ws, (int)Hf, (int)Wf, tg.th, tg.tw, tg.ntx, tg.nty, G, (int)ngroups, (int)lds_bytes, nwg, tile_probe_bits(),     \
+             tuning(41) != 1 ? 1 : 0)
     if (gsrc && gflow) GFLA_BE_TILE_LAUNCH(true, true);
     else if (gsrc) GFLA_BE_TILE_LAUNCH(true, false);
     else GFLA_BE_TILE_LAUNCH(false, true);

@@ -54,7 +54,7 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   4: round 3 (gfla_fc_kernel_f32 which = 6 / 7; the scatter workspace also carries resample2d's tap records)
  *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX)
  *   6: round 4 (gfla_convert_multi)
- *   7: round 5 (path ids 13-17, tuning keys 30-40: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
+ *   7: round 5 (path ids 13-17, tuning keys 30-41: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
  *      gfla_xcd_swizzle) */
 #define GFLA_ABI_VERSION 7
 int gfla_abi_version(void);
@@ -91,6 +91,7 @@ const char *gfla_status_string(int status);
  *   key 39: timing ablations of the tile kernels -- only in `make PROBES=1` builds (results are garbage); a default build
  *           ignores the key
  *   key 40: channels per pixel chunk of block_extractor's forward tiles (0 auto)
+ *   key 41: 1 = block_extractor's backward tiles without the cross-lane fold of the patch rows (csrc/be_tile.h: BeLinks)
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);

@@ -109,9 +109,10 @@ def test_config2_resample2d_all_flows_vs_reference_kernels(gfla, kind):
 # tuning keys: 30 = 2 force the family; 31 / 32 tile rows / columns; 33 channels per wave / thread of the first-version gathers;
 # 34 channels per workgroup of the scatter tiles; 10 LDS budget in KB (16 KB: several channel rounds, tiles on global memory)
 # 35 / 36 tile of block_extractor's forward; 37 channels per workgroup of the gather tiles; 38 = 1 the first version of the
-# gathers (taps read from global memory: the bodies every window kernel falls back to per tile); 40 channels per pixel chunk
-GEOS = [{}, {31: 3, 32: 5, 34: 1, 33: 1, 35: 3, 36: 5, 37: 1}, {31: 16, 32: 32, 34: 7, 33: 3, 35: 2, 36: 48, 37: 7, 40: 1},
-        {31: 4, 32: 64, 34: 3, 10: 16, 33: 2, 35: 16, 36: 32, 37: 5}, {31: 32, 32: 16, 34: 5, 10: 16, 38: 1},
+# gathers (taps read from global memory: the bodies every window kernel falls back to per tile); 40 channels per pixel chunk;
+# 41 = 1 block_extractor's source scatter without the cross-lane fold of the patch rows (be_tile.h: BeLinks)
+GEOS = [{}, {31: 3, 32: 5, 34: 1, 33: 1, 35: 3, 36: 5, 37: 1}, {31: 16, 32: 32, 34: 7, 33: 3, 35: 2, 36: 48, 37: 7, 40: 1, 41: 1},
+        {31: 4, 32: 64, 34: 3, 10: 16, 33: 2, 35: 16, 36: 32, 37: 5}, {31: 32, 32: 16, 34: 5, 10: 16, 38: 1, 41: 1},
         {31: 1, 32: 512, 34: 2, 35: 1, 36: 512, 37: 2, 40: 2}, {38: 1, 33: 2}]
 SHAPES = [  # B, C, Hs, Ws, Hf, Wf
     (2, 5, 21, 17, 21, 17), (1, 9, 40, 60, 40, 60), (2, 3, 12, 20, 9, 14), (1, 6, 7, 5, 11, 3), (1, 4, 64, 48, 64, 48)]

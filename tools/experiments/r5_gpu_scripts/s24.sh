@@ -1,0 +1,21 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r5_s24; mkdir -p $O
+V=$GRAFT_REPO_ROOT/global_flow_local_attention_amd/variants
+timeout 900 python -m pytest tests/test_big_plane_gpu.py -x -q -k "block_extractor or reproducible" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+GFLA_HIP_LIBRARY=$V/libgfla_hip_chb2.so timeout 900 python -m pytest tests/test_big_plane_gpu.py -x -q -k "block_extractor_big" > $O/pytest_chb2.log 2>&1; tail -3 $O/pytest_chb2.log
+run() { GFLA_HIP_LIBRARY=$2 python tools/bench_config2.py --tag "$1" ${3:+--tuning $3} --no-ref --split --flows smooth,zero,wild,expand --out $O/config2.jsonl > /dev/null 2>$O/err_$1.log; }
+run chb1 "" ""
+run chb2 $V/libgfla_hip_chb2.so ""
+run chb1_nofold "" "41=1"
+run chb1 "" ""
+run chb2 $V/libgfla_hip_chb2.so ""
+python - <<'PY'
+import json
+rows=[json.loads(l) for l in open("gpurun_out/r5_s24/config2.jsonl")]
+tags=[]
+for r in rows:
+    if r["tag"] not in tags: tags.append(r["tag"])
+for op in sorted({r["op"] for r in rows if "block_extractor_bwd" in r["op"]}):
+    for fl in ("smooth","zero","wild","expand"):
+        print("%-40s %-8s"%(op,fl)+"  ".join("%s %s"%(t,[r["us"] for r in rows if r["op"]==op and r["flow"]==fl and r["tag"]==t]) for t in tags))
+PY

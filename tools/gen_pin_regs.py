@@ -7,17 +7,17 @@ HEAD = '''// pin_regs(x): an empty asm statement that takes the M elements of x 
 // values are needed HERE".  hipcc otherwise sinks each LDS / global load down to its first use, and a loop that requests M
 // values and then combines them becomes M dependent round trips (seen in the ISA of the resample2d forward: ds_read ->
 // s_waitcnt lgkmcnt(0) -> fma, sixteen times per channel; round 5).  With the pin the requests are issued back to back
-// and waited for once.  An asm statement takes at most 30 operands; M up to 24 here (generated: tools/gen_pin_regs.py).
+// and waited for once.  An asm statement takes at most 30 operands; M up to 30 here (generated: tools/gen_pin_regs.py).
 #pragma once
 
 namespace gfla {
 
 template <typename A, int M>
 __device__ __forceinline__ void pin_regs(A (&x)[M]) {
-  static_assert(M >= 1 && M <= 24, "pin_regs: 1..24 values");
+  static_assert(M >= 1 && M <= 30, "pin_regs: 1..30 values");
 '''
 out = [HEAD]
-for m in range(1, 25):
+for m in range(1, 31):
     ops = ", ".join('"+v"(x[%d])' % i for i in range(m))
     out.append('  %sif constexpr (M == %d) asm volatile("" : %s);\n' % ("" if m == 1 else "else ", m, ops))
 out.append("}\n\n}  // namespace gfla\n")
