@@ -272,7 +272,10 @@ inline BigGeo big_geometry(int op, int64_t B, int64_t C, int64_t H, int64_t W, i
   BigGeo g;
   g.tg = op == 0 ? row_tile_geometry(H, W) : tile_geometry(H, W);
   const int64_t tiles = B * g.tg.nty * g.tg.ntx;
-  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 ? tile_channels(37, 16, tiles, C) : tile_channels(34, 8, tiles, C);
+  // (block_extractor's backward at k >= 5 -- span 6: windows of ~13 KB per channel -- measured 168 -> 153 us with 4 channels
+  // per workgroup instead of 8: twice the workgroups, each with one channel round instead of two; profiles/r5_config2_sweeps.txt)
+  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 ? tile_channels(37, 16, tiles, C)
+                                                            : tile_channels(34, op == 1 && span >= 6 ? 4 : 8, tiles, C);
   g.ngroups = (int)ceil_div(C, g.G);
   g.nwg = tiles * g.ngroups;
   g.lds_bytes = tile_lds_request(g.tg.th, g.tg.tw, span, g.G, bytes_per_elem, lds_budget());
