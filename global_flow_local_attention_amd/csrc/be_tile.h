@@ -304,7 +304,10 @@ template <typename T, int K>
 static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
                           int64_t Wf, hipStream_t stream, bool *done) {
   using A = typename Num<T>::acc;
-  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 3 ? 2 : 4);   // (K = 3: 4 -> 2 measured 28.4 -> 27.2 us)
+  // (K = 3: 4 -> 2 measured 28.4 -> 27.2 us; 2 -> 1 in the tile kernel 28.1 -> 26.7 on a smooth flow, k = 5 on a wild flow 143 ->
+  // 120, the other flows within 3 % either way: session s32)
+  constexpr int CH = sizeof(A) == 8 ? (K >= 4 ? 1 : 2) : (K >= 3 ? 2 : 4);
+  constexpr int CH_TILE = sizeof(A) == 8 ? CH : (K >= 3 ? 1 : 4);
   *done = false;
   if (Hs * Ws > 0x3fffffffLL) return GFLA_OK;
   if (tuning(38) == 1) {   // first version: global gathers, lane = pixel, four channel ranges per workgroup
@@ -331,9 +334,9 @@ static int launch_fwd_big(const T *src, const T *flow, T *out, int64_t B, int64_
     if (tuning(40) == 1) GFLA_BE_FWD_TILE(1);
     else if (tuning(40) == 2) GFLA_BE_FWD_TILE(2);
     else if (tuning(40) == 4) GFLA_BE_FWD_TILE(4);
-    else GFLA_BE_FWD_TILE(CH);
+    else GFLA_BE_FWD_TILE(CH_TILE);
   } else {
-    GFLA_BE_FWD_TILE(CH);
+    GFLA_BE_FWD_TILE(CH_TILE);
   }
 #undef GFLA_BE_FWD_TILE
   *done = true;
