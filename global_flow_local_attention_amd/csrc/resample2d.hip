@@ -969,7 +969,7 @@ static int resample2d_bwd(const T *in1, const T *in2, const T *gout, T *gin1, ty
         if (st != GFLA_OK) return st;
       }
       if (gin2 && tuning(38) != 1) {
-        const BigGeo bg = big_geometry(2, B, C, H, W, (k - 1) * dil + 1, (int)sizeof(A));
+        const BigGeo bg = big_geometry(4, B, C, H, W, (k - 1) * dil + 1, (int)sizeof(A));
         const TileGeo tg = bg.tg;
         const int G = bg.G;
         const int64_t ngroups = bg.ngroups, nwg = bg.nwg;
@@ -1150,9 +1150,9 @@ int gfla_resample2d_bwd_bf16(const uint16_t *a, const uint16_t *b, const uint16_
 int gfla_big_plane_geometry(int op, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t H, int64_t W, int span,
                             int elem_size, int64_t *out) {
   if (!out) return GFLA_ERR_NULL_POINTER;
-  if (op < 0 || op > 3 || B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || span < 1 || (elem_size != 4 && elem_size != 8))
+  if (op < 0 || op > 4 || B <= 0 || C <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || span < 1 || (elem_size != 4 && elem_size != 8))
     return GFLA_ERR_BAD_SHAPE;
-  const int per = op == 0 || op == 2 ? elem_size : op == 3 ? 8 : 8 + elem_size;
+  const int per = op == 0 || op == 2 || op == 4 ? elem_size : op == 3 ? 8 : 8 + elem_size;
   const int64_t plane_bytes = Hs * Ws * (int64_t)(op == 1 ? 8 + elem_size : op == 3 ? 8 : elem_size);
   const gfla::BigGeo g = gfla::big_geometry(op, B, C, H, W, span, per);
   const int64_t v[10] = {gfla::big_plane_regime(B, C, plane_bytes, gfla::lds_budget()) ? 1 : 0, g.tg.th, g.tg.tw, g.tg.ntx, g.tg.nty,

@@ -208,7 +208,7 @@ inline bool big_plane_regime(int64_t B, int64_t C, int64_t plane_bytes, int64_t 
 struct TileGeo {
   int th, tw, nty, ntx, threads;
 };
-inline TileGeo tile_geometry(int64_t H, int64_t W) {
+inline TileGeo tile_geometry(int64_t H, int64_t W, int dflt_th = 16) {
   TileGeo g;
   int tw = tuning(32) > 0 ? tuning(32) : 32;
   if (tw > W) tw = (int)W;
@@ -216,7 +216,7 @@ inline TileGeo tile_geometry(int64_t H, int64_t W) {
   // NOT split evenly (176 -> 6 tiles of 30): tiles of 32 columns start on 128-byte lines of every per-pixel tensor, and what a
   // wave writes per row is then a whole line, not the tail of one and the head of the next (5 tiles of 32 and one of 16)
   const int ntx = (int)ceil_div(W, tw);
-  int th = tuning(31) > 0 ? tuning(31) : 16;
+  int th = tuning(31) > 0 ? tuning(31) : dflt_th;
   if (th * tw > 512) th = 512 / tw;
   if (th > H) th = (int)H;
   if (th < 1) th = 1;
@@ -270,11 +270,13 @@ struct BigGeo {
 };
 inline BigGeo big_geometry(int op, int64_t B, int64_t C, int64_t H, int64_t W, int span, int bytes_per_elem) {
   BigGeo g;
-  g.tg = op == 0 ? row_tile_geometry(H, W) : tile_geometry(H, W);
+  // op: 0 block_extractor forward, 1 its backward, 2 resample2d forward, 3 its d/d input1 scatter, 4 its d/d input2 gather
+  // (8 x 32 tiles: 29.5 -> 25.9 us against 16 x 32, session s33; the scatter and the forward measured best at 16 x 32)
+  g.tg = op == 0 ? row_tile_geometry(H, W) : tile_geometry(H, W, op == 4 ? 8 : 16);
   const int64_t tiles = B * g.tg.nty * g.tg.ntx;
   // (block_extractor's backward at k >= 5 -- span 6: windows of ~13 KB per channel -- measured 168 -> 153 us with 4 channels
   // per workgroup instead of 8: twice the workgroups, each with one channel round instead of two; profiles/r5_config2_sweeps.txt)
-  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 ? tile_channels(37, 16, tiles, C)
+  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 || op == 4 ? tile_channels(37, 16, tiles, C)
                                                             : tile_channels(34, op == 1 && span >= 6 ? 4 : 8, tiles, C);
   g.ngroups = (int)ceil_div(C, g.G);
   g.nwg = tiles * g.ngroups;

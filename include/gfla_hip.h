@@ -122,7 +122,7 @@ enum gfla_path {
 int64_t gfla_path_count(int path);
 
 /* Round 5, host logic of the big-plane tile kernels (csrc/tile_map.h), for tests -- no GPU needed.
- * gfla_big_plane_geometry: op 0 block_extractor forward, 1 block_extractor backward, 2 resample2d forward / d/d input2,
+ * gfla_big_plane_geometry: op 0 block_extractor forward, 1 block_extractor backward, 2 resample2d forward, 4 resample2d d/d input2,
  *   3 resample2d d/d input1; (H, W) the flow / output grid, (Hs, Ws) the source plane, span = taps per axis; out[10] = in the
  *   regime by default, tile rows, tile columns, tiles along x, tiles along y, threads per workgroup, channels per workgroup,
  *   channel groups, dynamic LDS bytes requested, workgroups.

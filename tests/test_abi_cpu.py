@@ -166,7 +166,7 @@ def test_big_plane_tile_geometry_and_xcd_remap_invariants(gfla):
     out = (ctypes.c_int64 * 10)()
     po = ctypes.cast(out, ctypes.c_void_p)
     seen = 0
-    for op in (0, 1, 2, 3):
+    for op in (0, 1, 2, 3, 4):
         for B in (1, 2, 32):
             for C in (1, 3, 64, 256):
                 for (H, W) in ((256, 176), (7, 5), (64, 44), (33, 600), (1, 1), (500, 31)):
