@@ -208,9 +208,9 @@ inline bool big_plane_regime(int64_t B, int64_t C, int64_t plane_bytes, int64_t 
 struct TileGeo {
   int th, tw, nty, ntx, threads;
 };
-inline TileGeo tile_geometry(int64_t H, int64_t W, int dflt_th = 16) {
+inline TileGeo tile_geometry(int64_t H, int64_t W, int dflt_th = 16, int dflt_tw = 32) {
   TileGeo g;
-  int tw = tuning(32) > 0 ? tuning(32) : 32;
+  int tw = tuning(32) > 0 ? tuning(32) : dflt_tw;
   if (tw > W) tw = (int)W;
   if (tw > 512) tw = 512;
   // NOT split evenly (176 -> 6 tiles of 30): tiles of 32 columns start on 128-byte lines of every per-pixel tensor, and what a
@@ -272,11 +272,13 @@ inline BigGeo big_geometry(int op, int64_t B, int64_t C, int64_t H, int64_t W, i
   BigGeo g;
   // op: 0 block_extractor forward, 1 its backward, 2 resample2d forward, 3 its d/d input1 scatter, 4 its d/d input2 gather
   // (8 x 32 tiles: 29.5 -> 25.9 us against 16 x 32, session s33; the scatter and the forward measured best at 16 x 32)
-  g.tg = op == 0 ? row_tile_geometry(H, W) : tile_geometry(H, W, op == 4 ? 8 : 16);
+  // resample2d's forward: 16 x 16 tiles of 8 channels (19.7 -> 17.5 us against 16 x 32 tiles of 16: a squarer tile has the
+  // smaller bounding box per pixel; rows of 16 pixels still start on 64-byte boundaries; sessions s38 / s39)
+  g.tg = op == 0 ? row_tile_geometry(H, W) : op == 2 ? tile_geometry(H, W, 16, 16) : tile_geometry(H, W, op == 4 ? 8 : 16);
   const int64_t tiles = B * g.tg.nty * g.tg.ntx;
   // (block_extractor's backward at k >= 5 -- span 6: windows of ~13 KB per channel -- measured 168 -> 153 us with 4 channels
   // per workgroup instead of 8: twice the workgroups, each with one channel round instead of two; profiles/r5_config2_sweeps.txt)
-  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 || op == 4 ? tile_channels(37, 16, tiles, C)
+  g.G = op == 0 ? tile_channels(37, 8, tiles, C) : op == 2 ? tile_channels(37, 8, tiles, C) : op == 4 ? tile_channels(37, 16, tiles, C)
                                                             : tile_channels(34, op == 1 && span >= 6 ? 4 : 8, tiles, C);
   g.ngroups = (int)ceil_div(C, g.G);
   g.nwg = tiles * g.ngroups;

@@ -176,7 +176,7 @@ def test_big_plane_tile_geometry_and_xcd_remap_invariants(gfla):
                         seen += 1
                         assert threads % 64 == 0 and th * tw <= threads <= 512 and th >= 1 and tw >= 1
                         assert ntx * tw >= W and (ntx - 1) * tw < W and nty * th >= H and (nty - 1) * th < H
-                        assert tw == min(32, W)                                 # tiles start on 128-byte lines
+                        assert tw == min(16 if op == 2 else 32, W)              # tiles start on 128-byte lines (resample2d forward: 64)
                         assert 1 <= G <= C and ngroups * G >= C and (ngroups - 1) * G < C
                         assert nwg == B * ntx * nty * ngroups
                         assert 16 * 1024 <= lds <= 64 * 1024 and lds % 256 == 0
