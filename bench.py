@@ -545,8 +545,10 @@ class KernelTimer:
                    "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
             if ent["flops"]:
                 tf = ent["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-                row.update({"alg_GFLOP": round(ent["flops"] / 1e9, 2), "TFLOPs": round(tf, 1),
-                            "frac_mfma_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
+                # reference-formulation flops / time of a whole C-ABI call: what the caller gets, NOT a pipe fraction (the
+                # Winograd-domain kernels execute fewer multiplies than the reference formulation, so this can pass 1)
+                row.update({"effective_GFLOP": round(ent["flops"] / 1e9, 2), "effective_TFLOPs": round(tf, 1),
+                            "effective_frac_vs_f32_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
             rows.append(row)
         rows.sort(key=lambda r: -r["total_ms"])
         return rows
@@ -758,8 +760,21 @@ def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "n
             row["ref_us"] = round(ref_us, 1)
             row["speedup_vs_ref"] = round(ref_us / us, 2)
         if err is not None:
-            row["max_abs_vs_ref"] = float("%.3g" % err)
+            # err = (max |got - ref|, that / max |ref|) over the call's outputs: the north star's 1e-4 is a bar on O(1) forward
+            # values; gradients here have magnitudes of 40-100, so the RELATIVE figure is the one gated (tests: 2e-5)
+            row["max_abs_vs_ref"], row["max_rel_vs_ref"] = float("%.3g" % err[0]), float("%.3g" % err[1])
         rows.append(row)
+
+    def diff(pairs):
+        """(max-abs, max-abs / max |reference|), the worse of each over (got, want[, mask]) pairs"""
+        worst_abs = worst_rel = 0.0
+        for got, want, *mask in pairs:
+            d = (got.double() - want).abs()
+            if mask:
+                d = d * mask[0]
+            a = d.max().item()
+            worst_abs, worst_rel = max(worst_abs, a), max(worst_rel, a / max(1e-30, want.abs().max().item()))
+        return worst_abs, worst_rel
 
     gen = torch.Generator(device=device).manual_seed(42)
     src = torch.randn(B, C, H, W, device=device, generator=gen)
@@ -781,12 +796,12 @@ def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "n
                 r_b = timed(lambda: m.backward(src, flow, gout, rgs, rgf, k), 2)
                 if kind == "smooth":
                     sd, fd = src.double(), flow.double()
-                    e_f = (out.double() - ref.block_extractor_fwd(sd, fd, k)).abs().max().item()
+                    e_f = diff([(out, ref.block_extractor_fwd(sd, fd, k))])
                     gs.zero_(), gf.zero_()
                     bwd()
                     ws, wf = ref.block_extractor_bwd(sd, fd, gout.double(), k)
                     keep = floors_agree(flow, k)
-                    e_b = max((gs.double() - ws).abs().max().item(), ((gf.double() - wf) * keep).abs().max().item())
+                    e_b = diff([(gs, ws), (gf, wf, keep)])
                     del sd, fd, ws, wf
                 del ro, rgs, rgf
             emit("block_extractor_fwd k%d" % k, kind, "gfla_block_extractor_fwd_f32", (1, 1, 1, B, C, H, W, H, W, k), t_f, r_f, e_f)
@@ -816,11 +831,11 @@ def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "n
             r_f = timed(lambda: m.forward(src, i2, ro, 4, 1), 5)
             r_b = timed(lambda: m.backward(src, i2, gout, r1, r2, 4, 1), 2)
             if kind == "smooth":
-                e_f = (out.double() - ref.resample2d_fwd(src.double(), i2.double(), 4, 1)).abs().max().item()
+                e_f = diff([(out, ref.resample2d_fwd(src.double(), i2.double(), 4, 1))])
                 g1.zero_(), g2.zero_()
                 bwd()
                 w1, w2 = ref.resample2d_bwd(src.double(), i2.double(), gout.double(), 4, 1)
-                e_b = max((g1.double() - w1).abs().max().item(), (g2.double() - w2).abs().max().item())
+                e_b = diff([(g1, w1), (g2, w2)])
                 del w1, w2
             del ro, r1, r2
         emit("resample2d_fwd k4", kind, "gfla_resample2d_fwd_f32", (1, 1, 1, B, C, H, W, H, W, 4, 1), t_f, r_f, e_f)
@@ -834,7 +849,14 @@ def config2_ops(device, iters=20, flows=("smooth", "zero", "wild", "integer", "n
             emit("resample2d_bwd k4 (input2 only)", kind, "gfla_resample2d_bwd_f32", (1, 1, 1, None, 1, B, C, H, W, H, W, 4, 1, 1), t_2, None, None)
     torch.cuda.empty_cache()
     slower = [r for r in rows if "ref_us" in r and r["us"] > r["ref_us"]]
-    return {"what": "BASELINE configs[1]: block_extractor (k 3 / 5) + resample2d(4,1) forward and backward (both gradients) on one "
+    rels = [r["max_rel_vs_ref"] for r in rows if "max_rel_vs_ref" in r]
+    bad = [(r["op"], r["max_abs_vs_ref"], r["max_rel_vs_ref"]) for r in rows
+           if r.get("max_rel_vs_ref", 0.0) > 1e-4 or ("fwd" in r["op"] and r.get("max_abs_vs_ref", 0.0) > 1e-4)]
+    if bad:   # the leg is gated like oracle_check: forward max-abs and every tensor's relative error <= 1e-4
+        raise SystemExit("bench.py config2_ops: differs from the reference's kernels beyond 1e-4: %r" % (bad,))
+    return {"gate": "vs the reference's kernels on the smooth flow: forward max_abs <= 1e-4, every output max_abs / max|ref| <= 1e-4",
+            "worst_rel_vs_ref": max(rels) if rels else None,
+            "what": "BASELINE configs[1]: block_extractor (k 3 / 5) + resample2d(4,1) forward and backward (both gradients) on one "
                     "(1,64,256,176) fp32 map through the C ABI; HIP events; algorithmic bytes (SURVEY 8d) / time / 8 TB/s; ref_us = the "
                     "reference's own kernels (oracle/_ref) on the same inputs in the same process" + ("" if ref is not None else
                                                                                                    " -- not built on this box"),
@@ -1238,11 +1260,11 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         line["roofline"] = {"bound": "hbm", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["GBps"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_hbm_peak"], "avg_us": dom["avg_us"],
                             "alg_MB_per_launch": dom["alg_MB"], "traffic": pmc_traffic(dom["entry"], dom["dims"], dom["ptrs"])}
-        if "alg_GFLOP" in dom:  # an FC-layer entry: several kernels (packing, MFMA contraction, sampling tails) per call
+        if "effective_GFLOP" in dom:  # an FC-layer entry: several kernels (packing, MFMA contraction, sampling tails) per call
             peak = MFMA_F16_PEAK_TFLOPS if face else MFMA_F32_PEAK_TFLOPS
-            line["roofline"] = {"bound": "mfma", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["TFLOPs"],
-                                "peak": peak, "unit": "TFLOP/s", "frac": round(dom["TFLOPs"] / peak, 4),
-                                "avg_us": dom["avg_us"], "alg_GFLOP_per_call": dom["alg_GFLOP"], "traffic": None,
+            line["roofline"] = {"bound": "mfma", "kernel": dom["entry"], "dims": dom["dims"], "achieved": dom["effective_TFLOPs"],
+                                "peak": peak, "unit": "TFLOP/s", "frac": round(dom["effective_TFLOPs"] / peak, 4),
+                                "avg_us": dom["avg_us"], "alg_GFLOP_per_call": dom["effective_GFLOP"], "traffic": None,
                                 "hbm_GBps_of_call": dom["GBps"],
                                 "note": "whole C-ABI call (packing, MFMA contraction, sampling / reduction kernels), HIP "
                                         "events around the call; peak = dense matrix-core rate of the operand type"}
@@ -1267,8 +1289,110 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
     if rank == 0:
         if world == 1 and on_gpu and not args.no_cpu_baseline and not custom:
             line["cpu_baseline"] = cpu_baseline(args.cpu_budget)
-        print(json.dumps(line), flush=True)
+        print(compact_line(line, write_detail(line))[1], flush=True)
     return line
+
+
+FINAL_LINE_LIMIT = 4096   # bytes: the driver keeps a bounded tail of stdout; the last line must fit it whole
+
+
+def compact_line(line, detail_file):
+    """The LAST stdout line: the contract's keys + roofline + north_star + oracle_check + cpu_baseline in < 4 KB (one short
+    line per run, like the reference's own report, train.py:46-48).  Everything else -- per-call / per-kernel rows, variants,
+    the legs of the other BASELINE configs -- is in `detail_file` (and on stderr)."""
+    def cut(text, n):
+        text = str(text)
+        return text if len(text) <= n else text[:n - 3] + "..."
+
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in line}
+    out["metric"], out["dtype"], out["data"] = cut(out["metric"], 160), cut(out["dtype"], 80), cut(out["data"], 100)
+    cfg = line.get("config", {})
+    out["config"] = {"workload": cut(cfg.get("workload", ""), 330)}
+    for k in ("batch_per_gpu", "global_batch", "clips_per_gpu", "frames_per_clip"):
+        if k in cfg:
+            out["config"][k] = cfg[k]
+    out["config"]["parallelism"] = cut(cfg.get("parallelism", ""), 60).split(" (")[0]
+    rf = line.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf[k] for k in ("bound", "kernel", "dims", "achieved", "peak", "unit", "frac", "useful_frac",
+                                              "avg_us", "traffic") if k in rf}
+        out["roofline"]["kernel"] = cut(rf["kernel"], 110)
+        for k in ("alg_GFLOP_per_launch", "alg_MB_per_launch"):
+            if k in rf:
+                out["roofline"][k] = rf[k]
+        if rf.get("traffic") and "alg_MB_read_write_per_launch" in rf:
+            out["roofline"]["alg_MB_read_write_per_launch"] = rf["alg_MB_read_write_per_launch"]
+    ns = line.get("north_star")
+    if ns:
+        out["north_star"] = {"what": "block_extractor fwd + local-attn fwd, alg. bytes / HIP-event us / 8 TB/s",
+                             "layers": {name: {"be_fwd": [lay["block_extractor_fwd"]["us"], lay["block_extractor_fwd"]["frac"]],
+                                               "attn_fwd": [lay["local_attn_fwd"]["us"], lay["local_attn_fwd"]["frac"]],
+                                               "pair": [lay["pair"]["us"], lay["pair"]["frac"]]}
+                                        for name, lay in ns["layers"].items()}, "cols": ["us", "frac_of_hbm_peak"]}
+    oc = line.get("oracle_check")
+    if oc:
+        fw = [v for k, v in oc["max_abs"].items() if k.endswith(" out") or k.endswith(" warp")]
+        out["oracle_check"] = {"tolerance": oc["tolerance"], "passed": True, "worst_abs_forward": max(fw) if fw else None,
+                               "worst_abs": max(oc["max_abs"].values()), "worst_rel": max(oc["max_rel"].values()),
+                               "tensors": len(oc["max_abs"])}
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        out["cpu_baseline"]["sample"] = cut(cb.get("sample", ""), 220)
+    legs = line.get("legs")
+    if legs:   # one number per leg (the rows are in the detail file)
+        brief = {}
+        for name, leg in legs.items():
+            if not isinstance(leg, dict):
+                continue
+            if "error" in leg:
+                brief[name] = "error"
+            elif name == "config2_ops":
+                smooth = {r["op"]: r["frac"] for r in leg.get("rows", []) if r.get("flow") == "smooth"}
+                brief[name] = {"frac_hbm_smooth_flow": smooth, "worst_rel_vs_ref": leg.get("worst_rel_vs_ref"),
+                               "slower_than_reference_on": leg.get("slower_than_reference_on")}
+            else:
+                ms = leg.get("ms_per_step", leg.get("ms"))
+                if ms is not None:
+                    brief[name] = {"ms": ms}
+        out["legs"] = brief
+    if "dist" in line:
+        d = line["dist"]
+        out["dist"] = {k: d[k] for k in ("backend", "world_size_seen_by_group", "rccl_version", "gpus_visible",
+                                         "allreduce_of_rank_ids", "allreduce_expected") if k in d}
+        ag = d.get("all_gather_tiles")
+        if ag:
+            out["dist"]["all_gather_tiles"] = {k: ag[k] for k in ("correct", "us", "GBps_received_per_rank") if k in ag}
+    for k in ("vendor_fallback_calls", "streams"):
+        if k in line:
+            out[k] = line[k]
+    out["detail_file"] = detail_file
+    text = json.dumps(out)
+    # belt and braces: shed the optional objects, least important first, until the line fits
+    for k in ("legs", "streams", "dist", "north_star"):
+        if len(text) < FINAL_LINE_LIMIT:
+            break
+        out.pop(k, None)
+        text = json.dumps(out)
+    assert len(text) < FINAL_LINE_LIMIT, len(text)
+    return out, text
+
+
+def write_detail(line):
+    """The full record (kernels, fc_kernels, variants, legs, the long notes) -> gpurun_out/bench_detail.json (the directory
+    that travels back from a gpurun box; BENCH_DETAIL overrides) and stderr.  Never stdout: the last stdout line is the
+    short one, and there is exactly one JSON line on stdout."""
+    path = os.environ.get("BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    text = json.dumps(line)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            fh.write(text + "\n")
+    except OSError as exc:
+        path = "unwritable (%s); see stderr" % type(exc).__name__
+    print("bench_detail " + text, file=sys.stderr, flush=True)
+    return os.path.relpath(path, ROOT) if os.path.isabs(path) and path.startswith(ROOT) else path
 
 
 def parse_args(argv=None):

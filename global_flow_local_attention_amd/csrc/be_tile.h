@@ -65,6 +65,16 @@ struct BePixel {
 #pragma unroll
     for (int q = 0; q <= K; ++q) col[q] = clampi(x0c + q, 0, Ws - 1);
   }
+  // A lane outside the tile (tile padding, or beyond the map) still walks the dense path's loads -- only its stores are masked.
+  // Park its patch INSIDE the tile's bounding box (box = ymin, xmin, ymax, xmax of what the active lanes reach), so that its
+  // window reads stay inside the staged window whatever the tile's flow is: a box shorter than K + 1 rows / columns was cut by
+  // the plane's border on that side, where the index clamp of the patch rows / columns does the rest.
+  __device__ __forceinline__ void park(const int *box, int Ws) {
+    y0c = box[0] == 0 ? box[2] - K : box[0];
+    x0c = box[1] == 0 ? box[3] - K : box[1];
+#pragma unroll
+    for (int q = 0; q <= K; ++q) col[q] = clampi(x0c + q, 0, Ws - 1);
+  }
   // what the pixel can reach, one row / column of slack for the taps of the non-dense case
   __device__ __forceinline__ void reach(int Hs, int Ws, bool active, int &ylo, int &xlo, int &yhi, int &xhi) const {
     ylo = active ? clampi(y0c - 1, 0, Hs - 1) : 0x7fffffff;
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(512) void be_fwd_tile_kernel(const T *__restrict__ 
     box_reduce(s_box, ylo, xlo, yhi, xhi);
   }
   __syncthreads();
+  if (!active) px.park(s_box, Ws);
   const T *src0 = src + ((int64_t)b * C + c0) * plane;
   const bool vec = window_vec_ok(src0, plane, Ws);
   const TileWin w = tile_window_vec(s_box, Ws, vec);

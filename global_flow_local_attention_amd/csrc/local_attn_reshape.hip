@@ -46,7 +46,8 @@ static int reshape(bool fwd, const T *a, T *bptr, int64_t B, int64_t H, int64_t 
                    gfla_stream_t stream_) {
   if (!a || !bptr) return GFLA_ERR_NULL_POINTER;
   if (B <= 0 || H <= 0 || W <= 0 || k < 1) return GFLA_ERR_BAD_SHAPE;
-  if ((k * H) * (k * W) > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
+  // 32-bit element index in the kernels: blockIdx.x * kBlock + threadIdx.x must not wrap in the last (partial) block
+  if ((k * H) * (k * W) > 0x7fffff00LL) return GFLA_ERR_UNSUPPORTED;
   const int64_t n1 = (int64_t)k * k * H * W;
   const int64_t blocks = ceil_div(n1, kBlock);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
