@@ -73,7 +73,10 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
     wx[r] = t.col_w(r);
     consecutive = consecutive && co[r] == co[0] + r;
   }
-  const A inv = (t.sum == 0) ? (A)(1.0 / kEps) : (A)1 / t.sum;
+  // a float32 weight sum below the normal range (sigma ~ 0.05 with fractions near 0.5) has no float32 reciprocal: those
+  // pixels divide, as the reference does (resample2d_kernel.cu:93); everything else multiplies by 1 / sum
+  const bool tiny = t.sum != 0 && t.sum < (A)1.1754944e-38;
+  const A inv = (t.sum == 0) ? (A)(1.0 / kEps) : (tiny ? (A)1 : (A)1 / t.sum);
   auto combine = [&](const A (&v)[N][N]) {
     A val = 0;  // resample2d_kernel.cu:85-88: sum_r wy[r] * sum_q wx[q] * v[r][q]
 #pragma unroll
@@ -83,7 +86,7 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
       for (int q = 0; q < N; ++q) rowacc += wx[q] * v[r][q];
       val += wy[r] * rowacc;
     }
-    return val * inv;
+    return tiny ? val / t.sum : val * inv;
   };
   if constexpr (std::is_same<A, float>::value && std::is_same<PT, float>::value && N == 4) {
     // kernel_size 4 / 5 in float, no clamped column in the wave: the sixteen normalised weights wy[r] wx[q] / sum once per
@@ -94,7 +97,7 @@ __device__ __forceinline__ void rs_fwd_pixel(const Taps<A, KH> &t, const PT *__r
       v2f w2[N][2];
 #pragma unroll
       for (int r = 0; r < N; ++r) {
-        const float qy = wy[r] * inv;
+        const float qy = tiny ? wy[r] / t.sum : wy[r] * inv;
         w2[r][0] = v2f{qy * wx[0], qy * wx[1]};
         w2[r][1] = v2f{qy * wx[2], qy * wx[3]};
       }

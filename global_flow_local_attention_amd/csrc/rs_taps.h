@@ -92,7 +92,9 @@ struct Taps {
     }
     if constexpr (FAST == 2 && std::is_same<A, float>::value) {
       const float den = 2 * sg * sg;
-      if (den == 0) {
+      // den == 0: the reference's SAFE_DIV; a denormal den has no finite -log2(e) / den (an integer flow would give
+      // 0 * -inf = NaN): both take the division form of the exponent
+      if (!(den >= 1.1754944e-38f)) {
 #pragma unroll
         for (int f = 0; f < KH; ++f) {
           xLp[f] = gauss_fast<A>(xLd[f], sg), xRp[f] = gauss_fast<A>(xRd[f], sg);

@@ -584,29 +584,39 @@ def _fused_attention(self, source, target, flow_field):
     return _aggregate(source_c, flow_c, logits, last, k, link)
 
 
-# float32 twins of a bf16 module's convolutions, built once per module ON THE META DEVICE (no initialisation: the global RNG
-# is not consumed, nothing is allocated) and holding NO tensors between calls.  Kept outside the module (weakly keyed) so
-# that deepcopy / pickle / state_dict / DataParallel.replicate of the module never see them.
-import weakref
-_F32_TWINS = weakref.WeakKeyDictionary()
+# float32 twins of a bf16 module's convolutions: prototypes built once per convolution shape ON THE META DEVICE (no
+# initialisation: the global RNG is not consumed, nothing is allocated) and holding NO tensors, ever.  Kept outside the
+# module so that deepcopy / pickle / state_dict / DataParallel.replicate of the module never see them.
+import threading
+_F32_TWINS = {}                 # conv hyper-parameters -> prototype twin; never mutated after creation
+_F32_TWINS_LOCK = threading.Lock()
 _STICKY_FLAGS = ("_library_warned", "_attn_warned")
 
 
 def _f32_twins(fc):
-    twins = _F32_TWINS.get(fc)
-    if twins is None:
-        twins = []
-        for m in fc:
-            if isinstance(m, nn.Conv2d):
-                m32 = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
-                                bias=m.bias is not None, padding_mode=m.padding_mode, device="meta")
-                del m32.weight
-                if m.bias is not None:
-                    del m32.bias
-                twins.append(m32)
-            else:
-                twins.append(None)
-        _F32_TWINS[fc] = twins
+    """One PRIVATE set of twins per call: shallow copies of prototypes cached by the convolutions' hyper-parameters -- a key that
+    is the same for every DataParallel replica of a module (replicate() re-creates the Sequential on every forward, so a cache
+    keyed by the module object never hit there) and for two threads driving one module (which never share a twin now)."""
+    import copy
+    twins = []
+    for m in fc:
+        if not isinstance(m, nn.Conv2d):
+            twins.append(None)
+            continue
+        key = (m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups, m.bias is not None,
+               m.padding_mode)
+        proto = _F32_TWINS.get(key)
+        if proto is None:
+            with _F32_TWINS_LOCK:
+                proto = _F32_TWINS.get(key)
+                if proto is None:
+                    proto = nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, m.groups,
+                                      bias=m.bias is not None, padding_mode=m.padding_mode, device="meta")
+                    del proto.weight
+                    if m.bias is not None:
+                        del proto.bias
+                    _F32_TWINS[key] = proto
+        twins.append(copy.copy(proto))   # own __dict__: the float32 views set on it below are this call's alone
     return twins
 
 
@@ -621,11 +631,6 @@ def _fused_attention_f32_module(self, source, target, flow_field):
         return _fused_attention(self, source, target, flow_field)
     import copy
     twins = _f32_twins(fc)
-    # twins are shared by every call on this module: calls from two threads (DataParallel replicas are distinct modules,
-    # so this is two threads driving ONE module) would swap each other's views -- give such a caller private twins
-    private = any(t is not None and "weight" in t.__dict__ for t in twins)
-    if private:
-        twins = [copy.copy(t) if t is not None else None for t in twins]
     shadow = copy.copy(self)
     shadow.__dict__ = dict(self.__dict__)
     shadow._modules = dict(self._modules)
@@ -643,10 +648,6 @@ def _fused_attention_f32_module(self, source, target, flow_field):
         shadow._modules["fully_connect_layer"] = nn.Sequential(*layers)
         return _fused_attention(shadow, source, target, flow_field)
     finally:
-        for m32 in twins:
-            if m32 is not None:
-                m32.__dict__.pop("weight", None)
-                m32.__dict__.pop("bias", None)
         for flag in _STICKY_FLAGS:                # "warned once" must survive the per-call shadow
             if shadow.__dict__.get(flag) and not self.__dict__.get(flag):
                 self.__dict__[flag] = True

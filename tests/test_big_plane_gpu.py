@@ -197,6 +197,28 @@ def test_resample2d_big_plane_kernels_forced(gfla, oracle, k, dil, geo):
                     assert_close(i2d.grad.cpu(), g2_w, tg, "grad (dx, dy, sigma) " + what)
 
 
+@pytest.mark.parametrize("geo", (0, len(GEOS) - 1))
+def test_resample2d_big_plane_forward_bf16_forced(gfla, oracle, geo):
+    """bf16 storage through the big-plane forward kernel (rs_fwd_big_kernel<bf16>, the dispatch a bf16 map beyond the LDS budget
+    takes; forced here by tuning key 30 = 2 -- advisor finding, round 5: no test reached it): bf16-rounded inputs through the
+    float32 oracle, 2^-7 of the largest entry (the bf16 bar of tests/test_gpu_parity.py)."""
+    from global_flow_local_attention_amd import _lib
+    keys = dict(GEOS[geo])
+    keys[30] = 2
+    with _Tuning(gfla, keys):
+        for (B, C, Hi, Wi, H, W) in SHAPES:
+            for kind, scale in (("wild", 3.0), ("smooth", 1.0)):
+                i1 = randn((B, C, Hi, Wi), seed=13).bfloat16()
+                i2 = torch.cat((make_flow(kind, B, H, W, seed=14) * scale, rand((B, 1, H, W), seed=15) * 3 + 0.3), 1).bfloat16().contiguous()
+                want = oracle.resample2d_fwd(i1.float(), i2.float(), 4, 1)
+                before = _lib.path_count(_lib.PATH_RS_FWD_BIG)
+                out = gfla.Resample2dFunction.apply(i1.to(DEV), i2.to(DEV), 4, 1)
+                assert _lib.path_count(_lib.PATH_RS_FWD_BIG) == before + 1
+                assert out.dtype == torch.bfloat16
+                err = (out.float().cpu() - want).abs().max().item()
+                assert err <= 2 ** -7 * max(1.0, want.abs().max().item()), "bf16 fwd %s x%.1f %s: %.3e" % (kind, scale, (B, C, Hi, Wi, H, W), err)
+
+
 def test_resample2d_tile_scatter_trunc_compat_both_ways(gfla, oracle):
     """resample2d_kernel.cu:137-138 -- int() instead of floor() in d/d input1 -- matters where x + dx < 0: wild flows near the
     left / top border.  The tile scatter reproduces it by default and gives the forward's true gradient with it off."""

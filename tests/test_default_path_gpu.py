@@ -294,6 +294,31 @@ def test_resample2d_tiny_sigma_fixed_point_planes(gfla, oracle):
         gfla.set_tuning(14, o14)
 
 
+def test_resample2d_forward_small_sigma_stays_finite(gfla, oracle):
+    """Forward with sigmas at which the Gaussian weight sum leaves float32's normal range (advisor finding, round 5: the
+    reciprocal 1 / sum of the fast tap setup overflowed where the reference's val / sum is finite), and an integer flow with
+    a sigma whose 2 sigma^2 is denormal / zero (0 * -inf in the exp2 form).  Wherever the float32 oracle is finite the kernel
+    must be, and agree with it while the sum is a normal float (below, host denormals vs the GPU's flushes differ)."""
+    B, C, H, W = 2, 5, 24, 20
+    i1 = randn((B, C, H, W), seed=11)
+    for sigma in (0.5, 0.09, 0.06, 0.05, 0.045, 1e-20, 0.0):
+        for kind in ("smooth", "integer"):
+            flow = make_flow(kind, B, H, W, seed=3) * (0.3 if kind == "smooth" else 1.0)
+            i2 = torch.cat((flow, torch.full((B, 1, H, W), sigma)), 1).contiguous()
+            want = oracle.resample2d_fwd(i1, i2, 4, 1)
+            out = torch.full((B, C, H, W), float("nan"), device=DEV)
+            i1d, i2d = i1.to(DEV), i2.to(DEV)
+            from global_flow_local_attention_amd import _lib
+            _lib.call("gfla_resample2d_fwd_f32", out, _lib.ptr(i1d), _lib.ptr(i2d), _lib.ptr(out), B, C, H, W, H, W, 4, 1)
+            torch.cuda.synchronize()
+            got = out.cpu()
+            ok = torch.isfinite(want)
+            assert torch.isfinite(got[ok]).all(), "sigma %g %s flow: %d non-finite outputs where the reference is finite" % (
+                sigma, kind, int((~torch.isfinite(got[ok])).sum()))
+            if sigma >= 0.06:
+                assert (got - want)[ok].abs().max().item() <= 1e-4 * max(1.0, want[ok].abs().max().item()), (sigma, kind)
+
+
 # ----------------------------------------------------------------- matrix-core scatter: on / off / across the switch
 SCATTER_MODES = {           # tuning key 14 (0 auto, 1 never, 2 wherever supported), key 15 (rows per tile; >= 100000 = no limit)
     "auto": (0, 0),

@@ -43,8 +43,8 @@ def test_bf16_module_shadow_leaves_nothing_behind(gfla, monkeypatch):
     assert m.fully_connect_layer[0].weight.grad is not None            # gradients reach the bf16 parameters
     assert m.__dict__.get("_library_warned") is True
     assert "_f32_shadow" not in m.__dict__
-    twins = ea._F32_TWINS[m.fully_connect_layer]
-    assert all(t is None or ("weight" not in t.__dict__ and "bias" not in t.__dict__) for t in twins)
+    # the cached prototypes (keyed by conv hyper-parameters, shared by replicas) never carry a view: calls use private copies
+    assert ea._F32_TWINS and all("weight" not in t.__dict__ and "bias" not in t.__dict__ for t in ea._F32_TWINS.values())
     clone = copy.deepcopy(m)                                           # raised "Only Tensors created explicitly..." in round 4
     assert torch.equal(clone.fully_connect_layer[0].weight, m.fully_connect_layer[0].weight)
     assert list(clone.state_dict().keys()) == list(m.state_dict().keys())
@@ -55,8 +55,14 @@ def test_bf16_module_shadow_leaves_nothing_behind(gfla, monkeypatch):
     monkeypatch.setattr(ea, "_fused_attention", lambda *a: (_ for _ in ()).throw(RuntimeError("boom")))
     with pytest.raises(RuntimeError):
         ea._fused_attention_f32_module(m, x, x, torch.zeros(1, 2, 5, 5))
-    assert all(t is None or "weight" not in t.__dict__ for t in ea._F32_TWINS[m.fully_connect_layer])
+    assert all("weight" not in t.__dict__ for t in ea._F32_TWINS.values())
     copy.deepcopy(m)
+    # two modules with the same convolutions (DataParallel replicas) share the prototypes: no rebuild per replica / call
+    n = len(ea._F32_TWINS)
+    m2 = gfla.ExtractorAttn(4, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(torch.bfloat16)
+    monkeypatch.setattr(ea, "_fused_attention", fake)
+    ea._fused_attention_f32_module(m2, x, x, torch.zeros(1, 2, 5, 5))
+    assert len(ea._F32_TWINS) == n
 
 
 def test_install_policy_is_opt_in_and_sticky(gfla):
