@@ -589,7 +589,7 @@ def fc_kernel_probes(hp, iters=10):
             flops = 2.0 * B * H * W * C * k * k * 128
             layer_rows = []
             for which, nm in enumerate(names):
-                if which > 5 and mode != 4:
+                if which > 5 and mode not in (4, 5):
                     continue
                 for _ in range(2):
                     _lib.call("gfla_fc_kernel_f32", s, which, _lib.ptr(ws), _lib.ptr(sc), B, C, H, W, k, mode)
@@ -605,16 +605,16 @@ def fc_kernel_probes(hp, iters=10):
                     halves = layer_rows[0:2] if which == 6 else layer_rows[2:4]
                     done = sum(r["alg_GFLOP"] for r in halves) * 1e9
                     eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
-                    kern = "fc_wino_conv_kernel"
+                    kern = "fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel"
                     row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
                                 "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
                                 "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
                                 "in_step": True})
-                elif mode == 4:   # (the weight gradients of both layers run in the Winograd domain too: csrc/fc_block.hip)
+                elif mode in (4, 5):   # (the weight gradients of both layers run in the Winograd domain too: csrc/fc_block.hip)
                     # Winograd domain: the kernel EXECUTES 36 multiplies per (tile, c, n) -- F(2x2,5x5): 2x2 outputs per
                     # tile, F(4x4,3x3): 4x4.  `TFLOPs` / `frac` are these executed MFMA flops against the f32 peak (what the
                     # hardware does); `effective_TFLOPs` = the reference formulation's flops / time (what the caller gets).
-                    kern = "fc_wino_conv_kernel" if which < 4 else "fc_wino_wgrad_kernel"
+                    kern = ("fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel") if which < 4 else "fc_wino_wgrad_kernel"
                     m = 2 if k == 5 else 4
                     ext = {0: k - 1, 1: 0, 2: 2 * (k - 1), 3: k - 1, 4: k - 1, 5: 0}[which]
                     tiles = B * (-(-(H + ext) // m)) * (-(-(W + ext) // m))
@@ -1423,7 +1423,7 @@ def parse_args(argv=None):
                          "durations are not inflated by the second stream; the headline is the two-stream step)")
     ap.add_argument("--face-one-stream", action="store_true",
                     help="face_bf16: evaluate attn_p and attn_r of a layer one after the other on one stream (default: two streams)")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4), default=4,
+    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4, 5), default=4,
                     help="arithmetic of the FC contraction: 4 = float32, Winograd-domain convolutions and weight gradient "
                          "(the product default and the headline); 0 = float32, direct convolution; 3 / 2 = three / two f16 "
                          "terms per operand with f32 accumulation (labelled experiments)")

@@ -218,11 +218,19 @@ def set_tuning(key, value):
     return lib().gfla_set_tuning(int(key), int(value))
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # dispatch-trace ids (enum gfla_path in include/gfla_hip.h)
 PATH_BE_BWD_LDS, PATH_BE_BWD_GLOBAL, PATH_FC_FWD_MODE0, PATH_FC_BWD_MODE0, PATH_BE_FWD_PIX = 0, 1, 2, 7, 12
 # round 5: the big-plane kernels (few planes, each beyond the LDS budget; csrc/tile_map.h)
-PATH_BE_FWD_GPIX, PATH_BE_BWD_TILE, PATH_RS_FWD_BIG, PATH_RS_BWD1_TILE, PATH_RS_BWD2_BIG, PATH_COUNT = 13, 14, 15, 16, 17, 18
+PATH_BE_FWD_GPIX, PATH_BE_BWD_TILE, PATH_RS_FWD_BIG, PATH_RS_BWD1_TILE, PATH_RS_BWD2_BIG = 13, 14, 15, 16, 17
+PATH_FC_FWD_MODE5, PATH_FC_BWD_MODE5, PATH_COUNT = 18, 19, 20
+
+
+def fc_path(mode, backward=False):
+    """Dispatch-trace id of gfla_fc_forward_f32 / gfla_fc_backward_f32 in arithmetic mode `mode` (modes 0-4: ids 2-6 / 7-11)."""
+    if int(mode) == 5:
+        return PATH_FC_BWD_MODE5 if backward else PATH_FC_FWD_MODE5
+    return (PATH_FC_BWD_MODE0 if backward else PATH_FC_FWD_MODE0) + int(mode)
 
 
 def path_count(path):

@@ -23,7 +23,7 @@ struct FcLayout {
 };
 
 static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
-  const bool wino = mode_ == 4;
+  const bool wino = fc_is_wino(mode_);
   const int mode = fc_base_mode(mode_);
   FcLayout L;
   L.hs = fc_half(H, W, k, true);
@@ -106,6 +106,10 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
     if (!fc_wino_fits(hs.Mv, hs.Wo, hs.Wp, k) || !fc_wino_fits(hs.Md, hs.Wp, hs.Wp, k) ||
         !fc_wino_fits(ht.Mv, ht.Wo, ht.Wp, k) || !fc_wino_fits(ht.Md, ht.Wp, ht.Wp, k))
       return GFLA_ERR_UNSUPPORTED;
+  } else if (mode == 5) {
+    if (!fc_wino16_fits(hs.Mv, hs.Wo, hs.Wp, k) || !fc_wino16_fits(hs.Md, hs.Wp, hs.Wp, k) ||
+        !fc_wino16_fits(ht.Mv, ht.Wo, ht.Wp, k) || !fc_wino16_fits(ht.Md, ht.Wp, ht.Wp, k))
+      return GFLA_ERR_UNSUPPORTED;
   } else if (!fc_conv_fits(hs.Wo, hs.Wp, k, mode) || !fc_conv_fits(hs.Wp, hs.Wp, k, mode) ||
              !fc_conv_fits(ht.Wo, ht.Wp, k, mode) || !fc_conv_fits(ht.Wp, ht.Wp, k, mode))
     return GFLA_ERR_UNSUPPORTED;
@@ -119,10 +123,27 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
     if (rc_ != GFLA_OK) return rc_; \
   } while (0)
 
-// the four Winograd weight sets of one layer (mode 4)
-static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream) {
+// the four Winograd weight sets of one layer (mode 4; mode 5: two-term f16 words, scaled by the slot kAmaxW)
+static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream,
+                            bool w16 = false) {
+  if (w16)
+    return fc_wino16_pack_weights(w0, reinterpret_cast<const uint32_t *>(ws + L.amax) + kAmaxW, reinterpret_cast<float *>(ws + L.wu_ft),
+                                  reinterpret_cast<float *>(ws + L.wu_fs), reinterpret_cast<float *>(ws + L.wu_dt),
+                                  reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
   return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), reinterpret_cast<float *>(ws + L.wu_fs),
                               reinterpret_cast<float *>(ws + L.wu_dt), reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
+}
+
+// one or two Winograd-domain convolutions in mode 4 (float32 operands) or 5 (two-term f16 operands: amax[j] = the max |x| slot
+// of job j's input, amax_w the weights')
+static int fc_wino_jobs(const WnConvJob *jobs, int njobs, const uint32_t *const *amax, const uint32_t *amax_w, bool w16, int64_t B,
+                        int nch, int k, hipStream_t stream) {
+  if (!w16) return fc_wino_conv_jobs(jobs, njobs, B, nch, k, stream);
+  Wn16ConvJob j16[2];
+  for (int j = 0; j < njobs && j < 2; ++j)
+    j16[j] = Wn16ConvJob{jobs[j].X, reinterpret_cast<const uint32_t *>(jobs[j].U), amax[j], jobs[j].out, jobs[j].out_bs, jobs[j].ldo,
+                         jobs[j].n_valid, jobs[j].M, jobs[j].Wv, jobs[j].Wp, jobs[j].S};
+  return fc_wino16_conv_jobs(j16, njobs, B, nch, k, amax_w, stream);
 }
 
 static int fc_forward(const float *source, const float *target, const float *flow, const float *w0, const float *b0,
@@ -131,20 +152,20 @@ static int fc_forward(const float *source, const float *target, const float *flo
   if (!source || !target || !flow || !w0 || !w1 || !ws_ || !logits) return GFLA_ERR_NULL_POINTER;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode_));
   if (B == 0) return GFLA_OK;
-  note_path(GFLA_PATH_FC_FWD_MODE0 + mode_);
+  note_path(mode_ == 5 ? GFLA_PATH_FC_FWD_MODE5 : GFLA_PATH_FC_FWD_MODE0 + mode_);
   const FcLayout L = fc_layout(B, C, H, W, k, mode_);
-  const bool wino = mode_ == 4;
+  const bool wino = fc_is_wino(mode_), w16 = mode_ == 5;
   const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const uint32_t *a_src = mode ? amax + kAmaxSrc : nullptr, *a_tgt = mode ? amax + kAmaxTgt : nullptr;
   const uint32_t *a_w = mode ? amax + kAmaxW : nullptr;
-  if (mode) {   // the f16-split modes scale by max |x|; the float32 modes never read the slots
+  if (mode || w16) {   // the f16-split modes scale by max |x|; the float32 modes never read the slots
     if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
     GFLA_TRY(fc_maxabs_multi(source, B * (int64_t)C * H * W, amax + kAmaxSrc, target, B * (int64_t)C * H * W, amax + kAmaxTgt,
                              w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
   }
-  if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
+  if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16));
   GFLA_TRY(fc_pack_act2(source, a_src, ws + L.xs, L.hs, target, a_tgt, ws + L.xt, L.ht, B, C, H, W, mode, stream));
   float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
@@ -155,7 +176,8 @@ static int fc_forward(const float *source, const float *target, const float *flo
          L.hs.Wp, L.hs.Sx},
         {xt, reinterpret_cast<const float *>(ws + L.wu_ft), gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, L.ht.Mv, L.ht.Wo,
          L.ht.Wp, L.ht.Sx}};
-    GFLA_TRY(fc_wino_conv_jobs(jobs, 2, B, L.nch_c, k, stream));
+    const uint32_t *const am[2] = {amax + kAmaxSrc, amax + kAmaxTgt};
+    GFLA_TRY(fc_wino_jobs(jobs, 2, am, amax + kAmaxW, w16, B, L.nch_c, k, stream));
   } else {
     GFLA_TRY(fc_pack_weights(w0, a_w, ws + L.wf_t, ws + L.wf_s, ws + L.wd_t, ws + L.wd_s, C, k, mode, stream));
     const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, mode) / fc_nsplit(mode);
@@ -173,7 +195,7 @@ static int fc_forward(const float *source, const float *target, const float *flo
 // with units of whole tile rows and both halves in one grid it is 102 / 88 us against 151 / 129
 // (profiles/r4_wino_wgrad_k3_multirow.txt).
 static bool fc_wgrad_in_wino_domain(int mode_, int k) {
-  return mode_ == 4 && tuning(19) != 1 && (k == 5 || tuning(19) != 3);
+  return fc_is_wino(mode_) && tuning(19) != 1 && (k == 5 || tuning(19) != 3);
 }
 
 // data gradient (transposed convolution + replicate-pad fold) and weight gradient of one half, from its f32
@@ -185,7 +207,7 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   // z_ready: max |dz| and the packed gradient map already exist; defer_fold: fc_backward folds both halves in one launch
   // dgrad_done: convolution AND fold already enqueued; reduce_now = false: the weight-gradient partials stay in this half's
   // buffer (source: dwp, target: dwp2) and fc_backward reduces both halves together
-  const bool wino = mode_ == 4;
+  const bool wino = fc_is_wino(mode_), w16 = mode_ == 5;
   const int mode = fc_base_mode(mode_);
   const bool want_w = g_w0 != nullptr;
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
@@ -208,9 +230,14 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   if (g_x) {
     float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
     if (wino) {
-      if (!dgrad_done)
-        GFLA_TRY(fc_wino_conv(Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C,
-                              C, B, nch_h, g.Md, g.Wp, g.Wp, g.Sz, k, stream));
+      if (!dgrad_done) {
+        const WnConvJob job{Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C, C, g.Md,
+                            g.Wp, g.Wp, g.Sz};
+        uint32_t *a_z16 = amax + (source ? kAmaxZs : kAmaxZt);
+        if (w16) GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z16, stream));   // (the slot was zeroed by the caller)
+        const uint32_t *const am[1] = {a_z16};
+        GFLA_TRY(fc_wino_jobs(&job, 1, am, amax + kAmaxW, w16, B, nch_h, k, stream));
+      }
     } else {
       const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
       GFLA_TRY(fc_conv(Z, ws + (source ? L.wd_s : L.wd_t), wsplit_d, dx, g.Mdg * (int64_t)C, C, C, B, nch_h, g.Md, g.Wp,
@@ -258,7 +285,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   if (!ws_ || !flow || !w1 || !g_logits || !scratch_) return GFLA_ERR_NULL_POINTER;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode_));
   if (B == 0) return GFLA_OK;
-  note_path(GFLA_PATH_FC_BWD_MODE0 + mode_);
+  note_path(mode_ == 5 ? GFLA_PATH_FC_BWD_MODE5 : GFLA_PATH_FC_BWD_MODE0 + mode_);
   const FcLayout L = fc_layout(B, C, H, W, k, mode_);
   const int mode = fc_base_mode(mode_);
   unsigned char *ws = static_cast<unsigned char *>(ws_), *sc = static_cast<unsigned char *>(scratch_);
@@ -266,7 +293,8 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const float *hid = reinterpret_cast<const float *>(ws + L.hid);
   float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
   if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  if (mode && hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  const bool w16 = mode_ == 5;
+  if ((mode || w16) && hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
   const float *gs = reinterpret_cast<const float *>(ws + L.gs);
   const bool need_s = g_source || g_w0, need_t = g_target || g_w0;
   float *dzs = need_s ? reinterpret_cast<float *>(sc + L.dzs) : nullptr;
@@ -287,15 +315,19 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   // stream -- 4.449 ms per step against 4.460 on the caller's stream alone, profiles/r4_fc_small_kernels_side_stream.txt.)
   GFLA_TRY(fc_reduce_bias_w1(b0p, B * tiles, g_b0, dw1p, B * L.dw1_tiles, g_w1, g_b1, L.KK, red_tmp, stream));
   // mode 4: the data-gradient convolutions of both halves in one launch (fc_wino.hip)
-  const bool both_dgrads = mode_ == 4 && g_source && g_target;
+  const bool both_dgrads = fc_is_wino(mode_) && g_source && g_target;
   if (both_dgrads) {
     const int nch_h = kFcHidden / kFcChunk;
+    if (w16)   // max |dz| of both gradient maps: the scale of their two-term f16 split
+      GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
+                               0, nullptr, stream));
     const WnConvJob jobs[2] = {
         {fc_desc_nhwc(dzs, L.hs.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_ds),
          reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
         {fc_desc_nhwc(dzt, L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
-    GFLA_TRY(fc_wino_conv_jobs(jobs, 2, B, nch_h, k, stream));
+    const uint32_t *const am[2] = {amax + kAmaxZs, amax + kAmaxZt};
+    GFLA_TRY(fc_wino_jobs(jobs, 2, am, amax + kAmaxW, w16, B, nch_h, k, stream));
     // ... and their replicate-pad folds in one launch (fc_sample.hip)
     GFLA_TRY(fc_fold2(reinterpret_cast<const float *>(sc + L.dxs), g_source, L.hs, L.hs.Mdg * (int64_t)C,
                       (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, reinterpret_cast<const float *>(sc + L.dxt), g_target, L.ht,
@@ -412,12 +444,20 @@ int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *w
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   if (hipMemsetAsync(amax, 0, kAmaxSlots * 4, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
-  if (mode == 4) {
+  if (fc_is_wino(mode)) {
+    const bool w16 = mode == 5;
     unsigned char *xq = ws + (is_source ? L.xs : L.xt);
+    uint32_t *a_x16 = amax + (is_source ? kAmaxSrc : kAmaxTgt);
+    if (w16) {
+      GFLA_TRY(fc_maxabs(x, B * (int64_t)C * H * W, a_x16, stream));
+      GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
+    }
     GFLA_TRY(fc_pack_act(x, nullptr, xq, B, C, H, W, g, 0, stream));
-    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream));
-    return fc_wino_conv(fc_desc_packed(xq, B, L.nch_c, g.Sx, 0), reinterpret_cast<const float *>(ws + (is_source ? L.wu_fs : L.wu_ft)),
-                        out, g.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, g.Mv, g.Wo, g.Wp, g.Sx, k, stream);
+    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16));
+    const WnConvJob job{fc_desc_packed(xq, B, L.nch_c, g.Sx, 0), reinterpret_cast<const float *>(ws + (is_source ? L.wu_fs : L.wu_ft)),
+                        out, g.Mg * kFcHidden, kFcHidden, kFcHidden, g.Mv, g.Wo, g.Wp, g.Sx};
+    const uint32_t *const am[1] = {a_x16};
+    return fc_wino_jobs(&job, 1, am, amax + kAmaxW, w16, B, L.nch_c, k, stream);
   }
   uint32_t *a_x = mode ? amax + (is_source ? kAmaxSrc : kAmaxTgt) : nullptr, *a_w = mode ? amax + kAmaxW : nullptr;
   if (mode) {
@@ -473,7 +513,7 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
 int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C_, int64_t H_, int64_t W_,
                        int kernel_size, int mode, gfla_stream_t stream_) {
   if (!workspace || !scratch) return GFLA_ERR_NULL_POINTER;
-  if (which < 0 || which > 7 || (which > 5 && mode != 4)) return GFLA_ERR_BAD_SHAPE;
+  if (which < 0 || which > 7 || (which > 5 && !fc_is_wino(mode))) return GFLA_ERR_BAD_SHAPE;
   const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
   if (B == 0) return GFLA_OK;
@@ -482,13 +522,16 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
   const bool source = (which & 1) == 0;
   const FcHalf &g = source ? L.hs : L.ht;
   unsigned char *ws = static_cast<unsigned char *>(workspace), *sc = static_cast<unsigned char *>(scratch);
+  const bool w16 = mode == 5;
+  const uint32_t *amx = reinterpret_cast<const uint32_t *>(ws + L.amax);
+  const uint32_t *const am_f[2] = {amx + kAmaxSrc, amx + kAmaxTgt}, *const am_d[2] = {amx + kAmaxZs, amx + kAmaxZt};
   if (which == 6) {
     const WnConvJob jobs[2] = {
         {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, 0), reinterpret_cast<const float *>(ws + L.wu_fs),
          reinterpret_cast<float *>(ws + L.gs), L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, L.hs.Mv, L.hs.Wo, L.hs.Wp, L.hs.Sx},
         {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, 0), reinterpret_cast<const float *>(ws + L.wu_ft),
          reinterpret_cast<float *>(ws + L.gt), L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, L.ht.Mv, L.ht.Wo, L.ht.Wp, L.ht.Sx}};
-    return fc_wino_conv_jobs(jobs, 2, B, L.nch_c, k, stream);
+    return fc_wino_jobs(jobs, 2, am_f, amx + kAmaxW, w16, B, L.nch_c, k, stream);
   }
   if (which == 7) {
     const WnConvJob jobs[2] = {
@@ -496,19 +539,22 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
          reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
         {fc_desc_nhwc(reinterpret_cast<float *>(sc + L.dzt), L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
-    return fc_wino_conv_jobs(jobs, 2, B, kFcHidden / kFcChunk, k, stream);
+    return fc_wino_jobs(jobs, 2, am_d, amx + kAmaxW, w16, B, kFcHidden / kFcChunk, k, stream);
   }
-  if (mode == 4) {
+  if (fc_is_wino(mode)) {
     const PackedDesc X4 = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, 0);
     const PackedDesc Z4 = fc_desc_nhwc(reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz, kFcHidden);
-    if (which < 2)
-      return fc_wino_conv(X4, reinterpret_cast<const float *>(ws + (source ? L.wu_fs : L.wu_ft)),
-                          reinterpret_cast<float *>(ws + (source ? L.gs : L.gt)), g.Mg * kFcHidden, kFcHidden, kFcHidden, B,
-                          L.nch_c, g.Mv, g.Wo, g.Wp, g.Sx, k, stream);
-    if (which < 4)
-      return fc_wino_conv(Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
-                          reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, B,
-                          kFcHidden / kFcChunk, g.Md, g.Wp, g.Wp, g.Sz, k, stream);
+    if (which < 2) {
+      const WnConvJob job{X4, reinterpret_cast<const float *>(ws + (source ? L.wu_fs : L.wu_ft)),
+                          reinterpret_cast<float *>(ws + (source ? L.gs : L.gt)), g.Mg * kFcHidden, kFcHidden, kFcHidden, g.Mv, g.Wo,
+                          g.Wp, g.Sx};
+      return fc_wino_jobs(&job, 1, am_f + (source ? 0 : 1), amx + kAmaxW, w16, B, L.nch_c, k, stream);
+    }
+    if (which < 4) {
+      const WnConvJob job{Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
+                          reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, g.Md, g.Wp, g.Wp, g.Sz};
+      return fc_wino_jobs(&job, 1, am_d + (source ? 0 : 1), amx + kAmaxW, w16, B, kFcHidden / kFcChunk, k, stream);
+    }
     if (!fc_wgrad_in_wino_domain(mode, k))
       return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);
     return fc_wino_wgrad(X4, reinterpret_cast<float *>(sc + (source ? L.dzs : L.dzt)), g.Sz * kFcHidden, g.lead,

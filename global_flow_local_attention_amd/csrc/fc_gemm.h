@@ -48,10 +48,15 @@ struct Fc<3> {
 //   4: float32 throughout, Winograd domain (fc_wino.hip): F(2x2,5x5) / F(4x4,3x3) on the same 6 points, the 36 point-wise
 //      products as f32 MFMA GEMMs over the channels -- 2.78x / 4x fewer multiplies; operands, packing and every other
 //      kernel are mode 0's.
-inline int fc_base_mode(int mode) { return mode == 4 ? 0 : mode; }  // operand format / non-convolution kernels
+//   5: float32 tensors and transforms, Winograd domain as in 4, but the 36 point-wise GEMMs run on the f16 matrix cores: every
+//      transformed input / weight value is split into two f16 terms after a power-of-two scaling (hi + lo = the value to
+//      2^-24, a float32's own rounding) and all four cross products are accumulated in f32 (fc_wino16.hip): 4x less
+//      matrix-core time than mode 4, the same measured error.  The weight gradient is mode 4's.
+inline bool fc_is_wino(int mode) { return mode == 4 || mode == 5; }
+inline int fc_base_mode(int mode) { return fc_is_wino(mode) ? 0 : mode; }  // operand format / non-convolution kernels
 inline int fc_nsplit(int mode) { return mode == 0 ? 1 : mode; }
 inline int fc_esz(int mode) { return mode == 0 ? 4 : 2; }
-inline bool fc_mode_ok(int mode) { return mode >= 0 && mode <= 4; }
+inline bool fc_mode_ok(int mode) { return mode >= 0 && mode <= 5; }
 
 // An activation operand: 16-channel records, pixel-linear inside a sample (row pitch = the padded width, so a
 // k x k tap is a constant pixel offset), chunk-major.  Strides in bytes.
@@ -191,6 +196,22 @@ int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_l
 int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream);
 int fc_wino_wgrad_reduce2(float *part_s, int nsplit_s, float *part_t, int nsplit_t, float *grad_w0, int C, int cpad, int k,
                           hipStream_t stream);
+
+// fc_wino16.hip (arithmetic mode 5)
+struct Wn16ConvJob {   // WnConvJob with the two-term f16 weights of fc_wino16_pack_weights and the max |x| slot of the input
+  PackedDesc X;
+  const uint32_t *U;
+  const uint32_t *amax_x;
+  float *out;
+  int64_t out_bs;
+  int ldo, n_valid, M, Wv, Wp;
+  int64_t S;
+};
+int fc_wino16_pack_weights(const float *w0, const uint32_t *amax_w, float *u_ft, float *u_fs, float *u_dt, float *u_ds, int C,
+                           int k, hipStream_t stream);
+bool fc_wino16_fits(int M, int Wv, int Wp, int k);
+int fc_wino16_conv_jobs(const Wn16ConvJob *jobs, int njobs, int64_t B, int nch, int k, const uint32_t *amax_w,
+                        hipStream_t stream);
 
 // fc_sample.hip
 int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, const float *b0, const float *w1,

@@ -25,93 +25,10 @@
 //   transform's reads (8 tiles x 8 channels per wave) are spread over all banks;
 //   epilogue: A^T M A: each wave reduces its three point rows to an m x m partial per (tile, channel) in registers, the
 //   wave pairs swap partials through LDS, stores go to the same (pixel, channel) f32 map fc_conv writes.
-#include "fc_gemm.h"
-#include <algorithm>
+#include "fc_wino_shared.h"
 
 namespace gfla {
 
-constexpr int kWnXi = 36;       // 6 x 6 points
-constexpr int kWnTiles = 32;    // tiles per workgroup
-constexpr int kWnN = 64;        // output channels per workgroup
-constexpr int kWnVFloats = kWnXi * kWnTiles * 8;  // one V buffer: [point][tile][8 channels]
-constexpr int kWnThreads = 512;
-constexpr unsigned kWnLdsLimit = 160 * 1024;
-constexpr int kWnPF = 5;        // 16-byte pieces of the raw span a thread holds in registers across half a step
-
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-
-template <int KS>
-struct Wn {
-  static constexpr int M = KS == 5 ? 2 : 4;        // output tile edge
-  // LDS bytes per raw pixel (16 channels + pad).  k = 5: tiles are 2 pixels = 40 words apart (banks 8 t + channel: two tiles
-  // per bank among the 8 a wave reads).  k = 3: tiles are 4 pixels apart -- 80 words = 16 mod 32 with an 80-byte pitch (four
-  // tiles per bank), 72 words = 8 mod 32 with 72 bytes -- and the smaller pitch is what lets the 32x22 layer's span fit TWO
-  // raw buffers next to the V buffers (the single-buffer staging costs a barrier and an exposed copy per chunk).
-  static constexpr int PITCH = KS == 5 ? 80 : 72;
-};
-
-// ---- the three transforms (points 0, 1, -1, 2, -1/2, inf) -----------------------------------------------------
-// B^T (6 x 6)
-__device__ __forceinline__ void wn_bt(const float (&d)[6], float (&o)[6]) {
-  o[0] = d[0] + 1.5f * d[1] - 2.f * d[2] - 1.5f * d[3] + d[4];
-  o[1] = -d[1] - 2.5f * d[2] - 0.5f * d[3] + d[4];
-  o[2] = d[1] + 0.5f * d[2] - 2.5f * d[3] + d[4];
-  o[3] = -0.5f * d[1] - d[2] + 0.5f * d[3] + d[4];
-  o[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  o[5] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
-}
-// The same six outputs as three PAIRS -- (1, 2), (3, 4), (0, 5) -- of packed-f32 fma chains: coefficient pairs are scalar
-// constants, the inputs are broadcast by op_sel, so a row costs ~10 v_pk_fma_f32 (+ a few moves) instead of ~22 scalar ops
-__device__ __forceinline__ void wn_bt_pk(const float (&d)[6], float (&o)[6]) {
-  const f32x2v s1{d[1], d[1]}, s2{d[2], d[2]}, s3{d[3], d[3]}, s4{d[4], d[4]};
-  const f32x2v p12 = s4 + f32x2v{-1.f, 1.f} * s1 + f32x2v{-2.5f, 0.5f} * s2 + f32x2v{-0.5f, -2.5f} * s3;
-  const f32x2v p34 = s4 + f32x2v{-0.5f, 2.f} * s1 + f32x2v{-1.f, -1.f} * s2 + f32x2v{0.5f, -2.f} * s3;
-  const f32x2v p05 = f32x2v{d[0], d[5]} + f32x2v{1.5f, 1.f} * s1 + f32x2v{-2.f, 1.5f} * s2 + f32x2v{-1.5f, -2.f} * s3 +
-                     f32x2v{1.f, -1.5f} * s4;
-  o[0] = p05[0], o[5] = p05[1], o[1] = p12[0], o[2] = p12[1], o[3] = p34[0], o[4] = p34[1];
-}
-// rows 3*HALF .. 3*HALF + 2 of B^T d
-template <int HALF, typename T = float>
-__device__ __forceinline__ void wn_bt3(const T (&d)[6], T (&o)[3]) {
-  if constexpr (HALF == 0) {
-    o[0] = d[0] + 1.5f * d[1] - 2.f * d[2] - 1.5f * d[3] + d[4];
-    o[1] = -d[1] - 2.5f * d[2] - 0.5f * d[3] + d[4];
-    o[2] = d[1] + 0.5f * d[2] - 2.5f * d[3] + d[4];
-  } else {
-    o[0] = -0.5f * d[1] - d[2] + 0.5f * d[3] + d[4];
-    o[1] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-    o[2] = d[1] + 1.5f * d[2] - 2.f * d[3] - 1.5f * d[4] + d[5];
-  }
-}
-// A^T (m x 6)
-template <int M>
-__device__ __forceinline__ void wn_at(const float (&v)[6], float (&y)[M]) {
-  y[0] = v[0] + v[1] + v[2] + v[3] + v[4];
-  if constexpr (M == 2) {
-    y[1] = v[1] - v[2] + 2.f * v[3] - 0.5f * v[4] + v[5];
-  } else {
-    y[1] = v[1] - v[2] + 2.f * v[3] - 0.5f * v[4];
-    y[2] = v[1] + v[2] + 4.f * v[3] + 0.25f * v[4];
-    y[3] = v[1] - v[2] + 8.f * v[3] - 0.125f * v[4] + v[5];
-  }
-}
-// G (6 x r): G[i][j] = p_i^j / prod_{l != i} (p_i - p_l), last row = e_{r-1}
-template <int KS>
-__device__ __forceinline__ void wn_g(const float (&w)[KS], float (&o)[6]) {
-  o[0] = w[0];
-  o[5] = w[KS - 1];
-  if constexpr (KS == 5) {
-    o[1] = -(w[0] + w[1] + w[2] + w[3] + w[4]) * (1.f / 3.f);
-    o[2] = (w[0] - w[1] + w[2] - w[3] + w[4]) * (1.f / 3.f);
-    o[3] = (w[0] + 2.f * w[1] + 4.f * w[2] + 8.f * w[3] + 16.f * w[4]) * (1.f / 15.f);
-    o[4] = (-16.f * w[0] + 8.f * w[1] - 4.f * w[2] + 2.f * w[3] - w[4]) * (1.f / 15.f);
-  } else {
-    o[1] = -(w[0] + w[1] + w[2]) * (1.f / 3.f);
-    o[2] = (w[0] - w[1] + w[2]) * (1.f / 3.f);
-    o[3] = (w[0] + 2.f * w[1] + 4.f * w[2]) * (1.f / 15.f);
-    o[4] = (-16.f * w[0] + 8.f * w[1] - 4.f * w[2]) * (1.f / 15.f);
-  }
-}
 
 // ---- weights: conv0.weight (128, 2C, k, k) -> U = G w G^T in MFMA B-fragment order -------------------------------
 // U[ntile][chunk][half][point pair][nblock][lane][point & 1][2]: lane (kq = lane >> 4, n = lane & 15) holds input channels
@@ -119,13 +36,6 @@ __device__ __forceinline__ void wn_g(const float (&w)[KS], float (&o)[6]) {
 // load per point pair and step.
 // forward:        in = conv0 input channel c_off + ci, out = hidden n, taps as stored;
 // data gradient:  in = hidden n, out = conv0 input channel c_off + co, taps flipped (the transposed convolution).
-struct WnPackJob {
-  float *U;
-  int c_off, dgrad, n_in, n_out;
-};
-struct WnPackJobs {
-  WnPackJob j[4];
-};
 
 // grid (blocks, 4 jobs): forward / data-gradient sets of the target / source half in ONE launch.  Threads run along the
 // OUTPUT channel: the 36 stores of 16 neighbouring threads fill consecutive fragment slots.
@@ -202,58 +112,6 @@ int fc_wino_pack_weights(const float *w0, float *u_ft, float *u_fs, float *u_dt,
 }
 
 // ---- the convolution ---------------------------------------------------------------------------------------------
-struct WnGeo {
-  int TH, TW, ngroups, span;  // tile grid, groups of 32 tiles per sample, raw pixels a group stages per chunk
-};
-
-template <int KS>
-static WnGeo wn_geometry(int M, int Wv, int Wp) {
-  constexpr int m = Wn<KS>::M;
-  WnGeo g;
-  const int Ho = M / Wv;
-  g.TH = (Ho + m - 1) / m;
-  g.TW = (Wv + m - 1) / m;
-  g.ngroups = (g.TH * g.TW + kWnTiles - 1) / kWnTiles;
-  // tile rows a group of 32 consecutive tiles can touch
-  int rows = g.TW >= kWnTiles ? 2 : (kWnTiles + g.TW - 2) / g.TW + 1;
-  if (rows > g.TH) rows = g.TH;
-  g.span = ((rows - 1) * m + 6) * Wp + 6;
-  // ... and what the groups of THIS map actually reach: from the first pixel of a group's first tile row to the last pixel of
-  // its last tile's 6 x 6 window (groups start at multiples of 32 tiles, so few of them are the worst case)
-  const int ntiles = g.TH * g.TW;
-  int exact = 0;
-  for (int grp = 0; grp < g.ngroups; ++grp) {
-    const int t0 = grp * kWnTiles, t1 = std::min(t0 + kWnTiles, ntiles) - 1;
-    const int r0 = t0 / g.TW, r1 = t1 / g.TW;
-    int need = 0;
-    for (int r = std::max(r0, r1 - 1); r <= r1; ++r) {   // the last pixel is the last tile's, or the previous row's last tile's
-      const int c = r == r1 ? t1 - r1 * g.TW : g.TW - 1;
-      need = std::max(need, (m * r + 5) * Wp + m * c + 5 + 1 - m * r0 * Wp);
-    }
-    exact = std::max(exact, need);
-  }
-  if (exact < g.span) g.span = exact;
-  return g;
-}
-
-template <int KS>
-static unsigned wn_raw_bytes(const WnGeo &g) { return (unsigned)((g.span * Wn<KS>::PITCH + 15) & ~15); }
-
-// double_raw: two raw buffers (the next chunk's pixels land while this chunk is transformed: no extra barrier)
-template <int KS>
-static unsigned wn_lds_bytes(const WnGeo &g, bool double_raw) {
-  constexpr int m = Wn<KS>::M;
-  const unsigned main_loop = (unsigned)(2 * kWnVFloats * 4) + (double_raw ? 2u : 1u) * wn_raw_bytes<KS>(g);
-  const unsigned exchange = (unsigned)(kWnThreads * 4 * m * m * 4);  // epilogue: partial outputs of the wave pairs
-  return main_loop > exchange ? main_loop : exchange;
-}
-
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-struct Half0 { static constexpr int value = 0; };
-struct Half1 { static constexpr int value = 1; };
-typedef Half1 Yes;
-typedef Half0 No;
 
 // 8 waves.  Wave w: output channels 16*(w & 3) .. +15 of the workgroup's 64, points 18*(w >> 2) .. +17 (three rows of the
 // 6 x 6 point grid), both 16-tile blocks: 18 x 2 accumulators of 16x16 = 144 registers, two waves per SIMD.  Waves w and
@@ -361,8 +219,12 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
   auto commit = [&](int cc) {
 #pragma unroll
     for (int i = 0; i < kWnPF; ++i) {
-      const int q = t + kWnThreads * i;
-      if (q < npieces) piece_store(q, pf[i], cc);
+      // UNCONDITIONAL (threads behind the span rewrite its last piece with the same data, as they loaded it): with the store
+      // under `if (q < npieces)` the consumer of pf[i] sat in a divergent branch, hipcc kept the register "pending" on the
+      // skipped path and the NEXT prefetch -- which reuses pf[i]'s registers for its addresses right behind the multiply half
+      // -- opened with s_waitcnt vmcnt(4) .. vmcnt(0): a wait for the B words requested a moment earlier (seen in the ISA,
+      // round 6; the float32 kernel had carried it since round 3)
+      piece_store(min(t + kWnThreads * i, npieces - 1), pf[i], cc);
     }
     const unsigned char *base = xg + (int64_t)cc * X.chunk_stride;
     for (int q = t + kWnThreads * kWnPF; q < npieces; q += kWnThreads)
@@ -477,18 +339,30 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
     const bool stage_next = !(s & 1) && cc + 1 < nch;
     constexpr bool kT = !(DBG & 1), kM = !(DBG & 2);
     // (the transform of the step after the last one reads a stale raw buffer into the unused V buffer: harmless)
+    // request, transform and write of the next chunk's pixels in ONE branch: as two separate `if (stage_next)` around a shared
+    // transform hipcc cannot see that the write always follows the request, keeps the staging registers "pending" at the loop
+    // header and opens the next request with s_waitcnt vmcnt(4) .. vmcnt(0) -- a wait for the B fragments the multiply half
+    // requested a moment earlier (seen in the ISA in round 6; the kernel had carried it since round 3)
     if (xh == 0) {
       if constexpr (kM) multiply(s, sn);
       __builtin_amdgcn_sched_barrier(0);
       stamp(t_first);
-      if constexpr (kS) if (stage_next) prefetch(cc + 1);
-      if constexpr (kT) transform(Half0{}, s + 1);
-      if constexpr (kS && DB) if (stage_next) commit(cc + 1);
+      if (kS && stage_next) {
+        prefetch(cc + 1);
+        if constexpr (kT) transform(Half0{}, s + 1);
+        if constexpr (DB) commit(cc + 1);
+      } else {
+        if constexpr (kT) transform(Half0{}, s + 1);
+      }
       stamp(t_second);
     } else {
-      if constexpr (kS) if (stage_next) prefetch(cc + 1);
-      if constexpr (kT) transform(Half1{}, s + 1);
-      if constexpr (kS && DB) if (stage_next) commit(cc + 1);
+      if (kS && stage_next) {
+        prefetch(cc + 1);
+        if constexpr (kT) transform(Half1{}, s + 1);
+        if constexpr (DB) commit(cc + 1);
+      } else {
+        if constexpr (kT) transform(Half1{}, s + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       stamp(t_first);
       if constexpr (kM) multiply(s, sn);
@@ -838,14 +712,13 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   auto commit = [&](const WwUnit &un, int buf) {
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      const int q = t + kWnThreads * i;
-      if (q < npieces) {
-        int ldso;
-        (void)piece_addr(un, q, ldso);
-        uint2 *d = reinterpret_cast<uint2 *>(raw + buf * RAW + ldso);
-        d[0] = make_uint2(pf[i][0], pf[i][1]);
-        d[1] = make_uint2(pf[i][2], pf[i][3]);
-      }
+      // unconditional, like the convolution kernel's commit (threads behind the unit's pieces rewrite the last one)
+      const int q = min(t + kWnThreads * i, npieces - 1);
+      int ldso;
+      (void)piece_addr(un, q, ldso);
+      uint2 *d = reinterpret_cast<uint2 *>(raw + buf * RAW + ldso);
+      d[0] = make_uint2(pf[i][0], pf[i][1]);
+      d[1] = make_uint2(pf[i][2], pf[i][3]);
     }
   };
 

@@ -55,8 +55,10 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   5: round 4 (gfla_aggregate_bwd_supported, gfla_mask_blend_*; tuning keys 24-27; path id GFLA_PATH_BE_FWD_PIX)
  *   6: round 4 (gfla_convert_multi)
  *   7: round 5 (path ids 13-17, tuning keys 30-41: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
- *      gfla_xcd_swizzle) */
-#define GFLA_ABI_VERSION 7
+ *      gfla_xcd_swizzle)
+ *   8: round 6 (arithmetic mode 5 of gfla_fc_*: Winograd domain with two-term f16 operands on the f16 matrix cores,
+ *      csrc/fc_wino16.hip; path ids 18 / 19) */
+#define GFLA_ABI_VERSION 8
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
 
@@ -117,7 +119,9 @@ enum gfla_path {
   GFLA_PATH_RS_FWD_BIG = 15,   /*   resample2d forward */
   GFLA_PATH_RS_BWD1_TILE = 16, /*   resample2d d/d input1, tiles with bounding-box LDS windows */
   GFLA_PATH_RS_BWD2_BIG = 17,  /*   resample2d d/d input2 */
-  GFLA_PATH_COUNT = 18
+  GFLA_PATH_FC_FWD_MODE5 = 18, /* round 6: gfla_fc_forward_f32 / gfla_fc_backward_f32 in arithmetic mode 5 */
+  GFLA_PATH_FC_BWD_MODE5 = 19,
+  GFLA_PATH_COUNT = 20
 };
 int64_t gfla_path_count(int path);
 

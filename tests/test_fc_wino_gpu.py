@@ -1,4 +1,5 @@
-"""Winograd-domain FC kernels (arithmetic mode 4, csrc/fc_wino.hip) beyond the shapes test_fc_mfma_gpu.py /
+"""Winograd-domain FC kernels (arithmetic modes 4, csrc/fc_wino.hip, and 5, csrc/fc_wino16.hip: the same domain with two-term
+f16 operands on the f16 matrix cores, held to the same bars) beyond the shapes test_fc_mfma_gpu.py /
 test_bench_shapes_gpu.py already run in every mode: a sweep over ragged geometries (partial tiles in both directions,
 maps smaller than one tile group, channels that do not fill a chunk, single samples, maps that need the single-buffer
 staging) against float64 convolutions on the host, the mode-4 -> mode-0 fallback, and size-independent properties at the
@@ -56,10 +57,13 @@ SWEEP = [  # (k, B, C, H, W): ragged / tiny / odd / wide
 
 @pytest.mark.parametrize("k,B,C,H,W", SWEEP)
 @pytest.mark.parametrize("is_source", [0, 1])
-def test_winograd_half_on_ragged_shapes(gfla, k, B, C, H, W, is_source):
+@pytest.mark.parametrize("wmode", [4, 5])
+def test_winograd_half_on_ragged_shapes(gfla, k, B, C, H, W, is_source, wmode):
     from global_flow_local_attention_amd import fc_mfma
-    mode = fc_mfma.resolve_mode(C, H, W, k, 4)
-    assert mode in (4, 0)
+    mode = fc_mfma.resolve_mode(C, H, W, k, wmode)
+    assert mode in (wmode, 4, 0)
+    if wmode == 5 and mode != 5:
+        pytest.skip("shape falls back (covered by the mode-4 row)")
     x = (randn((B, C, H, W), seed=1) * 1.7).to(DEV)
     w0 = (randn((128, 2 * C, k, k), seed=2) * 0.05).to(DEV)
     g = fc_mfma.geometry(H, W, k, is_source)
@@ -93,8 +97,34 @@ def test_mode4_falls_back_to_the_direct_kernels_where_its_tiles_do_not_fit(gfla)
     assert rel_err(a.cpu(), m(s, t, f).cpu()) <= 2e-5
 
 
+@pytest.mark.parametrize("scale_x,scale_w,scale_g", [(1e-18, 1.0, 1.0), (3e12, 1e-9, 1e-25), (1.0, 7e7, 1e9), (2e-30, 3e-8, 1e-6)])
+@pytest.mark.parametrize("k,B,C,H,W", [(5, 2, 24, 11, 9), (3, 2, 40, 9, 14)])
+def test_two_term_f16_operands_over_the_float32_range(gfla, k, B, C, H, W, scale_x, scale_w, scale_g):
+    """Mode 5 splits every transformed value into two f16 terms after scaling by a power of two taken from the tensor's max |x|:
+    inputs, weights and gradients of any float32 magnitude must come out as accurately as O(1) ones (the scales are exact, the
+    inverse scales are applied as two power-of-two factors).  Magnitudes whose PRODUCTS leave the float32 range are not
+    float32 problems and are not tested."""
+    from global_flow_local_attention_amd import fc_mfma
+    assert fc_mfma.resolve_mode(C, H, W, k, 5) == 5
+    for is_source in (0, 1):
+        x = (randn((B, C, H, W), seed=1) * scale_x).to(DEV)
+        w0 = (randn((128, 2 * C, k, k), seed=2) * scale_w).to(DEV)
+        g = fc_mfma.geometry(H, W, k, is_source)
+        dG = (randn((B, 128, g["Ho"], g["Wo"]), seed=3) * scale_g).to(DEV)
+        fwd, gx, gw, _ = _run_half(B, C, H, W, k, is_source, 5, x, w0, dG)
+        x64 = x.cpu().double().requires_grad_()
+        wh = (w0[:, C:] if is_source else w0[:, :C]).cpu().double().clone().requires_grad_()
+        ref = F.conv2d(F.pad(x64, _pads(k, is_source), mode="replicate"), wh)
+        ref.backward(dG.cpu().double())
+        e_f, e_x = rel_err(fwd.cpu(), ref.detach()), rel_err(gx.cpu(), x64.grad)
+        e_w = rel_err((gw[:, C:] if is_source else gw[:, :C]).cpu(), wh.grad)
+        print("scales %g %g %g k %d half %d: map %.2e grad_x %.2e grad_w %.2e" % (scale_x, scale_w, scale_g, k, is_source, e_f, e_x, e_w))
+        assert e_f <= FWD_TOL and e_x <= GRAD_TOL and e_w <= GRAD_TOL, (e_f, e_x, e_w)
+
+
+@pytest.mark.parametrize("wmode", [4, 5])
 @pytest.mark.parametrize("k,C,H,W", [(5, 128, 64, 44), (3, 256, 32, 22)])
-def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W):
+def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W, wmode):
     """Properties that need no reference at B = 32: conv(a x1 + b x2) = a conv(x1) + b conv(x2);  <conv(x), dG> = <x, convT(dG)>
     (forward and data gradient are each other's adjoints);  <dW, W> = <conv_W(x), dG> (weight gradient)."""
     from global_flow_local_attention_amd import fc_mfma
@@ -103,9 +133,9 @@ def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W):
     x1, x2 = randn((B, C, H, W), seed=11).to(DEV), randn((B, C, H, W), seed=12).to(DEV)
     w0 = (randn((128, 2 * C, k, k), seed=13) / (2 * C * k * k) ** 0.5).to(DEV)
     dG = randn((B, 128, g["Ho"], g["Wo"]), seed=14).to(DEV)
-    f1, gx, gw, _ = _run_half(B, C, H, W, k, is_source, 4, x1, w0, dG)
-    f2, _, _, _ = _run_half(B, C, H, W, k, is_source, 4, x2, w0, dG)
-    f12, _, _, _ = _run_half(B, C, H, W, k, is_source, 4, 0.75 * x1 - 1.5 * x2, w0, dG)
+    f1, gx, gw, _ = _run_half(B, C, H, W, k, is_source, wmode, x1, w0, dG)
+    f2, _, _, _ = _run_half(B, C, H, W, k, is_source, wmode, x2, w0, dG)
+    f12, _, _, _ = _run_half(B, C, H, W, k, is_source, wmode, 0.75 * x1 - 1.5 * x2, w0, dG)
     assert rel_err(f12, 0.75 * f1 - 1.5 * f2) <= 2e-5
     lhs = (f1.double() * dG.double()).sum().item()
     rhs = (x1.double() * gx.double()).sum().item()
@@ -114,14 +144,14 @@ def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W):
     assert abs(wlhs - lhs) <= 2e-5 * max(abs(lhs), (f1.double().abs() * dG.double().abs()).sum().item() * 1e-3)
 
 
+@pytest.mark.parametrize("mode", [4, 5])
 @pytest.mark.parametrize("k,B,C,H,W", [(5, 3, 24, 11, 9), (3, 2, 40, 9, 14), (5, 2, 128, 64, 44)])
-def test_two_job_launch_equals_one_launch_per_half(gfla, k, B, C, H, W):
+def test_two_job_launch_equals_one_launch_per_half(gfla, k, B, C, H, W, mode):
     """gfla_fc_forward / gfla_fc_backward issue the convolutions of the target and the source half as ONE launch (workgroups
     [0, n0) = job 0, the rest job 1; csrc/fc_wino.hip).  Tuning key 21 = 2 launches them separately: every output must be
     bit-identical (the jobs share nothing but the grid)."""
     from global_flow_local_attention_amd import _lib, fc_mfma
-    mode = 4
-    if fc_mfma.resolve_mode(C, H, W, k, mode) != 4:
+    if fc_mfma.resolve_mode(C, H, W, k, mode) != mode:
         pytest.skip("shape falls back to the direct kernels")
     s, t = randn((B, C, H, W), seed=1).to(DEV), randn((B, C, H, W), seed=2).to(DEV)
     f = (randn((B, 2, H, W), seed=3) * 1.5).to(DEV)

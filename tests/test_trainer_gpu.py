@@ -29,7 +29,7 @@ def _compare_step(ngf, H, W, B):
     state = {k: v.clone() for k, v in cpu_net.state_dict().items()}
     gpu_shell, gpu_net = tu.build_shell(DEV, ngf=ngf, lr=LR, state=state)
     from global_flow_local_attention_amd import fc_mfma
-    fm, bm = _lib.PATH_FC_FWD_MODE0 + fc_mfma.DEFAULT_MODE, _lib.PATH_FC_BWD_MODE0 + fc_mfma.DEFAULT_MODE
+    fm, bm = _lib.fc_path(fc_mfma.DEFAULT_MODE), _lib.fc_path(fc_mfma.DEFAULT_MODE, backward=True)
     fwd0, bwd0 = _lib.path_count(fm), _lib.path_count(bm)
     want_losses, want_grads, before, want_after = tu.run_step(cpu_shell, cpu_net, batch, "cpu")
     losses, grads, _, after = tu.run_step(gpu_shell, gpu_net, batch, DEV)
