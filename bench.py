@@ -257,7 +257,7 @@ class TrainerPath:
     reducer's hooks over ALL parameters, Adam step.  GAN / style terms stubbed, as configs[3] prescribes.  The stock
     convolutions / InstanceNorms of the network run through torch (MIOpen), like the reference's own."""
 
-    def __init__(self, B, device, seed, fc_mode=4, ngf=64, size=(256, 176)):
+    def __init__(self, B, device, seed, fc_mode=5, ngf=64, size=(256, 176)):
         from global_flow_local_attention_amd.trainer import TrainerShell
         gen = torch.Generator(device=device).manual_seed(seed)
         self.B, self.device = B, device
@@ -629,8 +629,19 @@ def fc_kernel_probes(hp, iters=10):
                 else:
                     kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode in (0, 4) else "fc_wgrad_kernel")
                     row.update({"alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
+                # mode 5: which convolutions run on the two-term f16 kernel (csrc/fc_block.hip: fc_w16_dgrad)
+                w16 = mode == 5 and (which in (0, 1, 6) or (which in (2, 3, 7) and k == 5))
+                if mode == 5 and not w16 and kern == "fc_wino16_conv_kernel":
+                    kern = "fc_wino_conv_kernel"
                 row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
                 row["frac_mfma_f32_peak"] = round(row["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+                if w16:
+                    # every Winograd-domain multiply is formed from two f16 terms per operand, all four cross products: the
+                    # matrix cores execute 4 f16 MACs per f32-equivalent one (two v_mfma_f32_32x32x16_f16 per 8 channels)
+                    row["pipe"] = "f16"
+                    row["f16_pipe_TFLOPs"] = round(4.0 * row["alg_GFLOP"] * 1e9 / (us * 1e-6) / 1e12, 1)
+                    row["frac_mfma_f16_peak"] = round(row["f16_pipe_TFLOPs"] / MFMA_F16_PEAK_TFLOPS, 4)
+                    row["frac_mfma_f32_peak_note"] = "f32-EQUIVALENT Winograd-domain flops / time / f32 peak: not a pipe fraction in this mode"
                 rows.append(row)
                 layer_rows.append(row)
     return rows
@@ -987,7 +998,7 @@ def extra_legs(args, device):
         legs["config2_ops"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     # configs[2]: ExtractorAttn forward only (eval, no_grad) at the attention-layer shapes of a 256x256 image, batch 32
     from global_flow_local_attention_amd import fc_mfma
-    for mode in (4, 0):
+    for mode in (5, 4, 0):
         mods, ins = [], []
         gen = torch.Generator(device=device).manual_seed(7)
         torch.manual_seed(1234)
@@ -1160,7 +1171,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
     if on_gpu and args.fc_impl == "mfma" and not args.no_variants and not custom:
         notes = {0: "float32, DIRECT convolution kernels (a k-ordered fma chain per output): the same step without the "
                     "Winograd-domain formulation",
-                 4: "float32, Winograd-domain convolutions and weight gradient (the product default)"}
+                 4: "float32 operands on f32 MFMA, Winograd-domain convolutions and weight gradient (the default of rounds 3-5)",
+                 5: "Winograd domain, two-term f16 operands with all four cross products on f16 MFMA (the product default)"}
         # the same step with the loss-side warps on a side stream (HotPath.step)
         hv = make_hotpath(args.fc_mode)
         hv.two_streams = not getattr(hp, "two_streams", False)
@@ -1172,8 +1184,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
             "note": "the Resample2d sites (a branch of the training graph that shares only the flow fields with the attention "
                     "layers) issued on %s" % ("a second HIP stream" if hv.two_streams else "the same stream as the attention layers")}
         del hv
-        for mode, label in ((0, "fc_mode0_f32_direct"), (4, "fc_mode4_f32_winograd"), (3, "fc_mode3_f16x3_split"),
-                            (2, "fc_mode2_f16x2_split")):
+        for mode, label in ((0, "fc_mode0_f32_direct"), (4, "fc_mode4_f32_winograd"), (5, "fc_mode5_winograd_f16x2_exact"),
+                            (3, "fc_mode3_f16x3_split"), (2, "fc_mode2_f16x2_split")):
             if mode == args.fc_mode:
                 continue
             hv = make_hotpath(mode)
@@ -1195,7 +1207,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": data,
+        "dtype": "f32" if args.fc_mode in (0, 4) else
+                 ("f32 tensors / transforms / accumulation; FC products as two-term f16 splits (exact to 2^-24) on f16 MFMA"
+                  if args.fc_mode == 5 else "f32 tensors; FC operands split into f16 terms (mode %d)" % args.fc_mode),
+        "data": data,
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
                                "ExtractorAttn L3 (C256,32x22,k3) + L2 (C128,64x44,k5) fwd+bwd incl. both FC layers, "
                                "Resample2d(4,1,2) fwd+bwd at (C512,32x22) and (C256,64x44)"
@@ -1208,7 +1223,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                                   "from autograd hooks, overlapping backward)" % world,
                    "fc_layers": ("this library's MFMA kernels, arithmetic mode %d (%s); no vendor GEMM / convolution in the step"
                                  % (args.fc_mode, {0: "exact f32, direct convolution", 4: "f32, Winograd-domain convolutions F(2x2,5x5) / "
-                                                   "F(4x4,3x3)"}.get(args.fc_mode, "f16-split operands, f32 accumulate")))
+                                                   "F(4x4,3x3)", 5: "Winograd domain, f32 transforms, two-term f16 operands with all "
+                                                   "four cross products on f16 MFMA, f32 accumulate"}.get(args.fc_mode, "f16-split operands, f32 accumulate")))
                    if args.fc_impl == "mfma" else "round 1's vendor-library path (torch.mm / F.conv2d)"},
         "kernels": rows,
         "fc_kernels": probes,
@@ -1234,12 +1250,22 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                        avg_us=round(tus / len(step_rows), 1), alg_GFLOP=round(alg / len(step_rows), 2),
                        TFLOPs=round(alg * 1e9 / (tus * 1e-6) / 1e12, 1), effective_TFLOPs=round(eff * 1e9 / (tus * 1e-6) / 1e12, 1))
             dom["frac_mfma_f32_peak"] = round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
+            if dom.get("pipe") == "f16":
+                dom["f16_pipe_TFLOPs"] = round(4.0 * alg * 1e9 / (tus * 1e-6) / 1e12, 1)
+                dom["frac_mfma_f16_peak"] = round(dom["f16_pipe_TFLOPs"] / MFMA_F16_PEAK_TFLOPS, 4)
+        f16pipe = dom.get("pipe") == "f16"
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "dims": dom["dims"],
-                            "achieved": dom["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
+                            "achieved": dom["f16_pipe_TFLOPs"] if f16pipe else dom["TFLOPs"],
+                            "peak": MFMA_F16_PEAK_TFLOPS if f16pipe else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": dom["frac_mfma_f16_peak"] if f16pipe else dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
+                            **({"pipe": "f16 matrix cores, two f16 terms per operand: executed f16 MACs = 4 x the Winograd-domain "
+                                        "multiplies; the kernel is bound by its LDS / vector work (transforms, f16 split), not by "
+                                        "the matrix cores (DESIGN.md 4)",
+                                "f32_equivalent_TFLOPs": dom["TFLOPs"]} if f16pipe else {}),
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
                             **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
-                            **({"useful_frac": round(dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                            **({"useful_frac": round((4.0 if f16pipe else 1.0) * dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12
+                                                     / (MFMA_F16_PEAK_TFLOPS if f16pipe else MFMA_F32_PEAK_TFLOPS), 4),
                                 "useful_frac_note": "executed Winograd-domain flops over the UN-extended output domain only (the "
                                                     "tiles whose outputs the caller keeps) / time / peak"}
                                if "useful_GFLOP" in dom else {}),
@@ -1250,7 +1276,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                             "flops": ("Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "
                                       "(2*36*tiles*C*128; tiles = ceil(rows/m)*ceil(cols/m) of the output domain, m = 2 for "
                                       "F(2x2,5x5), 4 for F(4x4,3x3)) / time; effective_TFLOPs = the reference formulation's "
-                                      "2*B*H*W*C*k*k*128 / time" if args.fc_mode == 4 else
+                                      "2*B*H*W*C*k*k*128 / time" if args.fc_mode in (4, 5) else
                                       "reference formulation (2*B*H*W*C*k*k*128 per half and pass); work the kernel adds on "
                                       "top (extended / padded domains) is not counted"),
                             "timing": "HIP events around 10 back-to-back launches of the kernel alone "
@@ -1423,10 +1449,12 @@ def parse_args(argv=None):
                          "durations are not inflated by the second stream; the headline is the two-stream step)")
     ap.add_argument("--face-one-stream", action="store_true",
                     help="face_bf16: evaluate attn_p and attn_r of a layer one after the other on one stream (default: two streams)")
-    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4, 5), default=4,
-                    help="arithmetic of the FC contraction: 4 = float32, Winograd-domain convolutions and weight gradient "
-                         "(the product default and the headline); 0 = float32, direct convolution; 3 / 2 = three / two f16 "
-                         "terms per operand with f32 accumulation (labelled experiments)")
+    ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4, 5), default=5,
+                    help="arithmetic of the FC contraction: 5 = Winograd domain, float32 transforms, every transformed operand as "
+                         "two f16 terms (exact to 2^-24) with all four cross products on the f16 matrix cores, f32 accumulation "
+                         "(the product default and the headline, round 6); 4 = the same domain on f32 MFMA (the default of rounds "
+                         "3-5); 0 = float32, direct convolution; 3 / 2 = three / two f16 terms per operand in the direct "
+                         "convolution (labelled experiments)")
     ap.add_argument("--with-losses", action="store_true",
                     help="replace the bare Resample2d sites by the losses that contain them in training (BASELINE "
                          "config 4): PerceptualCorrectness.calculate_loss on synthetic VGG-shaped features + "

@@ -123,13 +123,23 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
     if (rc_ != GFLA_OK) return rc_; \
   } while (0)
 
+// Mode 5 runs a convolution on the two-term f16 kernel where that kernel measured faster than the float32 one: everywhere at
+// k = 5 and the forward at k = 3; the k = 3 data gradient (128 -> C channels on a 32x22 map: 4 x 4 outputs per tile make the
+// f16 kernel's epilogue its largest part) stays on fc_wino.hip: 141 against 166 us at (32,256,32,22).  Tuning key 43 = 1: f16
+// kernels everywhere (tests).
+static bool fc_w16_dgrad(int k) { return k == 5 || tuning(43) == 1; }
+
 // the four Winograd weight sets of one layer (mode 4; mode 5: two-term f16 words, scaled by the slot kAmaxW)
 static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream,
                             bool w16 = false) {
-  if (w16)
-    return fc_wino16_pack_weights(w0, reinterpret_cast<const uint32_t *>(ws + L.amax) + kAmaxW, reinterpret_cast<float *>(ws + L.wu_ft),
-                                  reinterpret_cast<float *>(ws + L.wu_fs), reinterpret_cast<float *>(ws + L.wu_dt),
-                                  reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
+  float *u_ft = reinterpret_cast<float *>(ws + L.wu_ft), *u_fs = reinterpret_cast<float *>(ws + L.wu_fs);
+  float *u_dt = reinterpret_cast<float *>(ws + L.wu_dt), *u_ds = reinterpret_cast<float *>(ws + L.wu_ds);
+  if (w16) {
+    const bool d16 = fc_w16_dgrad(k);
+    GFLA_TRY(fc_wino16_pack_weights(w0, reinterpret_cast<const uint32_t *>(ws + L.amax) + kAmaxW, u_ft, u_fs, d16 ? u_dt : nullptr,
+                                    d16 ? u_ds : nullptr, C, k, stream));
+    return d16 ? GFLA_OK : fc_wino_pack_weights(w0, nullptr, nullptr, u_dt, u_ds, C, k, stream);
+  }
   return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), reinterpret_cast<float *>(ws + L.wu_fs),
                               reinterpret_cast<float *>(ws + L.wu_dt), reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
 }
@@ -234,9 +244,10 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
         const WnConvJob job{Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C, C, g.Md,
                             g.Wp, g.Wp, g.Sz};
         uint32_t *a_z16 = amax + (source ? kAmaxZs : kAmaxZt);
-        if (w16) GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z16, stream));   // (the slot was zeroed by the caller)
+        const bool d16 = w16 && fc_w16_dgrad(k);
+        if (d16) GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z16, stream));   // (the slot was zeroed by the caller)
         const uint32_t *const am[1] = {a_z16};
-        GFLA_TRY(fc_wino_jobs(&job, 1, am, amax + kAmaxW, w16, B, nch_h, k, stream));
+        GFLA_TRY(fc_wino_jobs(&job, 1, am, amax + kAmaxW, d16, B, nch_h, k, stream));
       }
     } else {
       const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, mode) / fc_nsplit(mode);
@@ -318,7 +329,8 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const bool both_dgrads = fc_is_wino(mode_) && g_source && g_target;
   if (both_dgrads) {
     const int nch_h = kFcHidden / kFcChunk;
-    if (w16)   // max |dz| of both gradient maps: the scale of their two-term f16 split
+    const bool d16 = w16 && fc_w16_dgrad(k);
+    if (d16)   // max |dz| of both gradient maps: the scale of their two-term f16 split
       GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
                                0, nullptr, stream));
     const WnConvJob jobs[2] = {
@@ -327,7 +339,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
         {fc_desc_nhwc(dzt, L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
     const uint32_t *const am[2] = {amax + kAmaxZs, amax + kAmaxZt};
-    GFLA_TRY(fc_wino_jobs(jobs, 2, am, amax + kAmaxW, w16, B, nch_h, k, stream));
+    GFLA_TRY(fc_wino_jobs(jobs, 2, am, amax + kAmaxW, d16, B, nch_h, k, stream));
     // ... and their replicate-pad folds in one launch (fc_sample.hip)
     GFLA_TRY(fc_fold2(reinterpret_cast<const float *>(sc + L.dxs), g_source, L.hs, L.hs.Mdg * (int64_t)C,
                       (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, reinterpret_cast<const float *>(sc + L.dxt), g_target, L.ht,
@@ -539,7 +551,7 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
          reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
         {fc_desc_nhwc(reinterpret_cast<float *>(sc + L.dzt), L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
-    return fc_wino_jobs(jobs, 2, am_d, amx + kAmaxW, w16, B, kFcHidden / kFcChunk, k, stream);
+    return fc_wino_jobs(jobs, 2, am_d, amx + kAmaxW, w16 && fc_w16_dgrad(k), B, kFcHidden / kFcChunk, k, stream);
   }
   if (fc_is_wino(mode)) {
     const PackedDesc X4 = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, 0);
@@ -553,7 +565,7 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
     if (which < 4) {
       const WnConvJob job{Z4, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)),
                           reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt)), g.Mdg * (int64_t)C, C, C, g.Md, g.Wp, g.Wp, g.Sz};
-      return fc_wino_jobs(&job, 1, am_d + (source ? 0 : 1), amx + kAmaxW, w16, B, kFcHidden / kFcChunk, k, stream);
+      return fc_wino_jobs(&job, 1, am_d + (source ? 0 : 1), amx + kAmaxW, w16 && fc_w16_dgrad(k), B, kFcHidden / kFcChunk, k, stream);
     }
     if (!fc_wgrad_in_wino_domain(mode, k))
       return fc_wgrad_f32(X4, Z4, g.lead, reinterpret_cast<float *>(sc + L.dwp), L.cpad, B, g.M, g.Wp, k, stream);

@@ -460,7 +460,7 @@ bool fc_wino_fits(int M, int Wv, int Wp, int k) {
 
 // out[b][r][n] = sum_{chunk, tap, c} X[b][chunk][pix(r) + tap][c] * w[...]  -- the contract of fc_conv (fc_conv_impl.h),
 // with the weights given as the transformed U of fc_wino_pack_weights.  S = pixels per sample X may be read for.
-static unsigned long long *g_wino_stamps = nullptr;  // timing probe buffer (gfla_fc_wino_debug_buffer; tools only)
+unsigned long long *g_wino_stamps = nullptr;  // timing probe buffer (gfla_fc_wino_debug_buffer; tools only; also fc_wino16.hip)
 
 template <int K_>
 static int wn_launch(const WnConvJob *jobs, int njobs, int64_t B, int nch, hipStream_t stream) {

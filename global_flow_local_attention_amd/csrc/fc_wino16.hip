@@ -147,9 +147,21 @@ struct PgTag { static constexpr int value = PG_; };
 
 // DBG (timing ablations, `make PROBES=1` builds only, tuning key 20; results are garbage): 1 no transform, 2 no MFMAs / A reads,
 // 4 no B reloads, 8 no raw staging, 32 transform without the f16 split (hi only), 64 no epilogue
+extern unsigned long long *g_wino_stamps;   // fc_wino.hip (DBG & 16: per-wave phase times, s_memtime; tools/probe_wino_phases.py)
 template <int KS, bool DB = true, int DBG = 0>
 __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs a0, Wn16KArgs a1, unsigned n0, int nch,
-                                                                      const uint32_t *__restrict__ amax_w) {
+                                                                      const uint32_t *__restrict__ amax_w,
+                                                                      unsigned long long *stamps) {
+  unsigned long long tk0 = 0, t_first = 0, t_second = 0, t_bar = 0, t_pro = 0, t_epi = 0;
+  if constexpr (DBG & 16) tk0 = __builtin_amdgcn_s_memtime();
+  auto stamp = [&](unsigned long long &slot) {
+    if constexpr (DBG & 16) {
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long n = __builtin_amdgcn_s_memtime();
+      slot += n - tk0;
+      tk0 = n;
+    }
+  };
   constexpr int M = Wn<KS>::M, PITCH = Wn<KS>::PITCH, NP = 9;   // points per wave
   const bool second = blockIdx.x >= n0;
 #define GFLA_PICK(f) (second ? a1.f : a0.f)
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
   else transform(Half1{}, 0);
   __syncthreads();
 
+  stamp(t_pro);
   for (int s = 0; s < nsteps; ++s) {
     const int cc = s >> 1;
     const int sn = min(s + 1, nsteps - 1);
@@ -343,6 +356,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
     if (xh == 0) {
       if constexpr (kM) multiply(s, sn);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(t_first);
       if (kS && stage_next) {
         prefetch(cc + 1);
         if constexpr (kT) transform(Half0{}, s + 1);
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
       } else {
         if constexpr (kT) transform(Half0{}, s + 1);
       }
+      stamp(t_second);
     } else {
       if (kS && stage_next) {
         prefetch(cc + 1);
@@ -359,9 +374,12 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
         if constexpr (kT) transform(Half1{}, s + 1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      stamp(t_first);
       if constexpr (kM) multiply(s, sn);
+      stamp(t_second);
     }
     __syncthreads();
+    stamp(t_bar);
     if constexpr (!DB) {
       if (stage_next) {  // single raw buffer: written between two barriers (large maps only)
         commit(cc + 1);
@@ -482,6 +500,13 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
   else if (pg == 1) finish(PgTag<1>{});
   else if (pg == 2) finish(PgTag<2>{});
   else finish(PgTag<3>{});
+  if constexpr (DBG & 16) {
+    stamp(t_epi);
+    if (stamps && lane == 0) {
+      unsigned long long *o = stamps + ((int64_t)blockIdx.x * 8 + wave) * 6;
+      o[0] = t_pro, o[1] = t_first, o[2] = t_second, o[3] = t_bar, o[4] = t_epi, o[5] = (unsigned long long)xh;
+    }
+  }
 }
 
 static unsigned wn16_lds_bytes(int k, const WnGeo &g, bool double_raw) {
@@ -515,7 +540,7 @@ static int wn16_launch(const Wn16ConvJob *jobs, int njobs, int64_t B, int nch, c
   {                                                                                                                     \
     auto kern = fc_wino16_conv_kernel<K_, true, D_>;                                                                    \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, amax_w);       \
+    kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, amax_w, g_wino_stamps); \
   }
   if (db) {
 #ifdef GFLA_PROBES
@@ -525,6 +550,7 @@ static int wn16_launch(const Wn16ConvJob *jobs, int njobs, int64_t B, int nch, c
       case 3: GFLA_W16_LAUNCH(3) break;
       case 4: GFLA_W16_LAUNCH(4) break;
       case 8: GFLA_W16_LAUNCH(8) break;
+      case 16: GFLA_W16_LAUNCH(16) break;
       case 32: GFLA_W16_LAUNCH(32) break;
       case 64: GFLA_W16_LAUNCH(64) break;
       case 128: GFLA_W16_LAUNCH(128) break;
@@ -541,7 +567,7 @@ static int wn16_launch(const Wn16ConvJob *jobs, int njobs, int64_t B, int nch, c
   } else {
     auto kern = fc_wino16_conv_kernel<K_, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, amax_w);
+    kern<<<dim3((unsigned)(wgs[0] + wgs[1])), kWnThreads, lds, stream>>>(a[0], a[1], (unsigned)wgs[0], nch, amax_w, nullptr);
   }
   return launch_status();
 }

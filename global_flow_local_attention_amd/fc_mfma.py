@@ -6,12 +6,13 @@ logits (B, k*k, H, W) -- what the reference computes as
 -- through gfla_fc_forward_f32 / gfla_fc_backward_f32 (csrc/fc_block.hip): no block tensor, no library GEMM or
 convolution.  `mode` picks the arithmetic of the contraction (include/gfla_hip.h):
   4  float32 throughout, Winograd-domain convolutions and weight gradient (csrc/fc_wino.hip: F(2x2,5x5) / F(4x4,3x3),
-     2.78x / 4x fewer multiplies) -- THE DEFAULT; errors against float64 at the bench shapes 1e-6 .. 9e-6, held to the same
-     test bars as mode 0;
+     2.78x / 4x fewer multiplies); errors against float64 at the bench shapes 1e-6 .. 9e-6, held to the same test bars as
+     mode 0;
   0  float32, direct convolution: a k-ordered fma chain per output (what mode 4 falls back to for maps its tiles do not fit);
   5  float32 tensors and transforms, Winograd domain as in 4, the 36 point-wise GEMMs on the f16 matrix cores with every
      transformed value split into two f16 terms (hi + lo = the value to 2^-24) and all four cross products accumulated in f32
-     (csrc/fc_wino16.hip): 4x less matrix-core time than 4, the same measured error, the same test bars;
+     (csrc/fc_wino16.hip): 4x less matrix-core time than 4, the same measured error, the same test bars -- THE DEFAULT
+     (round 6); the weight gradient and the k = 3 data gradient are mode 4's kernels;
   3 / 2  operands split into three / two f16 terms, f32 accumulation (labelled experiments);  1  one f16 term (bf16 path).
 """
 import ctypes
@@ -22,10 +23,12 @@ from torch.autograd import Function
 from . import _lib
 
 MODES = (0, 1, 2, 3, 4, 5)
-# float32 arithmetic is what the reference computes this layer in (base_function.py:799-810): a module without an explicit
-# `fc_mode` gets the float32 Winograd-domain kernels (4), or the float32 direct kernels (0) where 4 does not take the shape;
-# 2 / 3 are labelled experiments, 1 belongs to the bf16-feature path
-DEFAULT_MODE = 4
+# float32 is what the reference computes this layer in (base_function.py:799-810): a module without an explicit `fc_mode`
+# gets float32-grade arithmetic -- the Winograd-domain kernels with two-term f16 operands (5: every operand represented to
+# 2^-24, all four cross products, f32 accumulation; measured error = mode 4's), the float32 Winograd kernels (4) or the
+# float32 direct kernels (0) where the shape does not fit the faster one; 2 / 3 are labelled experiments (lower / other
+# precision trade-offs), 1 belongs to the bf16-feature path
+DEFAULT_MODE = 5
 MODE_NAMES = {0: "f32 MFMA, direct convolution", 1: "one f16 term per operand (exact for bf16 values), f32 accumulate",
               2: "two f16 terms per operand, f32 accumulate", 3: "three f16 terms per operand, f32 accumulate",
               4: "f32 MFMA, Winograd-domain convolutions F(2x2,5x5) / F(4x4,3x3)",

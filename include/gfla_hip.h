@@ -94,6 +94,7 @@ const char *gfla_status_string(int status);
  *           ignores the key
  *   key 40: channels per pixel chunk of block_extractor's forward tiles (0 auto)
  *   key 41: 1 = block_extractor's backward tiles without the cross-lane fold of the patch rows (csrc/be_tile.h: BeLinks)
+ *   key 43: arithmetic mode 5: 1 = the two-term f16 kernel also for the k = 3 data gradient (default: float32 Winograd kernel there)
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);

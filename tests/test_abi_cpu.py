@@ -32,7 +32,7 @@ def test_header_and_library_agree(gfla):
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(handle, name), name
-    assert _lib.lib().gfla_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().gfla_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_validation_without_gpu(gfla):

@@ -37,7 +37,7 @@ BENCH_SHAPES = [  # (name, B, C, H, W, k)
     # the 128-channel layer, a combination the two DeepFashion layers do not have
     ("attn2_market_128x64", 32, 128, 32, 16, 3),
 ]
-FC_PATHS = [("mfma", 0), ("mfma", 4), ("mfma", 3), ("mfma", 2), ("library", 0)]
+FC_PATHS = [("mfma", 0), ("mfma", 4), ("mfma", 5), ("mfma", 3), ("mfma", 2), ("library", 0)]
 
 
 def _ref():

@@ -98,7 +98,7 @@ def test_extractor_attn_bench_shape_rough_flows(gfla, name, B, C, H, W, k, kind)
     case = _case(B, C, H, W, k, kind, seed=900)
     want_out, want_grads, min_hidden = _reference(case, k, torch.float64)
     assert min_hidden > 1e-3, "test parameters put a hidden activation on the LeakyReLU kink (%.2e)" % min_hidden
-    for mode in (4, 0):
+    for mode in (5, 4, 0):
         out, grads = run_module(gfla, case, C, k, "mfma", mode)
         # oob: everything behind d/d logits vanishes identically (see rel_err); absolute bounds = tolerance x the scale the
         # tensor has on ordinary flows: 1e-2 per position, 100 for the parameter gradients (sums over 22 528 positions of

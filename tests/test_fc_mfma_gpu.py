@@ -17,7 +17,7 @@ from util import assert_close, make_flow, max_abs, randn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MODES = (0, 4, 3, 2)
+MODES = (0, 4, 5, 3, 2)
 FWD_TOL, GRAD_TOL = 1e-5, 2e-5
 
 
@@ -303,7 +303,7 @@ def test_extractor_attn_bf16_features(lib, gfla, oracle, k, C, H, W):
     assert not bad, errs
 
 
-@pytest.mark.parametrize("mode", (4, 0))
+@pytest.mark.parametrize("mode", (5, 4, 0))
 @pytest.mark.parametrize("k,C", [(3, 16), (5, 8)])
 def test_leaky_relu_at_exactly_zero_takes_the_negative_slope(lib, gfla, oracle, mode, k, C):
     """A hidden unit whose pre-activation is EXACTLY 0 everywhere (zero weights, zero bias): torch's LeakyReLU backward uses

@@ -57,8 +57,23 @@ SWEEP = [  # (k, B, C, H, W): ragged / tiny / odd / wide
 
 @pytest.mark.parametrize("k,B,C,H,W", SWEEP)
 @pytest.mark.parametrize("is_source", [0, 1])
-@pytest.mark.parametrize("wmode", [4, 5])
+@pytest.mark.parametrize("wmode", [4, 5, 50])
 def test_winograd_half_on_ragged_shapes(gfla, k, B, C, H, W, is_source, wmode):
+    """wmode 50 = mode 5 with the two-term f16 kernel forced for EVERY convolution (tuning key 43 = 1: by default mode 5 keeps
+    the k = 3 data gradient on the float32 Winograd kernel, where that is faster)."""
+    from global_flow_local_attention_amd import fc_mfma
+    force16 = wmode == 50
+    wmode = 5 if force16 else wmode
+    if force16 and k != 3:
+        pytest.skip("key 43 only changes k = 3")
+    old43 = gfla.set_tuning(43, 1 if force16 else 0)
+    try:
+        _ragged(gfla, k, B, C, H, W, is_source, wmode)
+    finally:
+        gfla.set_tuning(43, old43)
+
+
+def _ragged(gfla, k, B, C, H, W, is_source, wmode):
     from global_flow_local_attention_amd import fc_mfma
     mode = fc_mfma.resolve_mode(C, H, W, k, wmode)
     assert mode in (wmode, 4, 0)
@@ -86,7 +101,7 @@ def test_mode4_falls_back_to_the_direct_kernels_where_its_tiles_do_not_fit(gfla)
     and still matches the reference's op-by-op composition on the library's own ops."""
     from global_flow_local_attention_amd import _lib, fc_mfma
     C, H, W, k = 8, 6, 200, 5
-    assert not fc_mfma.supported(C, H, W, k, 4) and fc_mfma.resolve_mode(C, H, W, k) == 0
+    assert not fc_mfma.supported(C, H, W, k, 4) and not fc_mfma.supported(C, H, W, k, 5) and fc_mfma.resolve_mode(C, H, W, k) == 0
     m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
     s, t = randn((1, C, H, W), seed=1).to(DEV), randn((1, C, H, W), seed=2).to(DEV)
     f = (randn((1, 2, H, W), seed=3) * 1.5).to(DEV)

@@ -960,34 +960,36 @@ def test_streaming_kernels_random_shapes_against_round1_kernels(gfla, kernel_var
 
 # ------------------------------------------------------------------------------ dispatch: defaults and tuning
 def test_default_fc_arithmetic_is_float32(gfla, kernel_variant):
-    """A module built through the reference surface, WITHOUT an explicit fc_mode, runs float32 arithmetic -- the
-    reference's precision (base_function.py:799-810): the Winograd-domain f32 kernels (mode 4) in forward and backward,
-    never an f16-split mode; fc_mode = 0 selects the direct f32 kernels; a map whose tiles mode 4 does not take falls
-    back to mode 0 by itself."""
+    """A module built through the reference surface, WITHOUT an explicit fc_mode, runs float32-grade arithmetic -- the
+    reference's precision (base_function.py:799-810): the Winograd-domain kernels whose operands are two-term f16 splits
+    exact to 2^-24 with all four cross products (mode 5, round 6) in forward and backward, never one of the lossy f16-split
+    modes (1 / 2 / 3); fc_mode = 4 / 0 select the float32 Winograd / direct kernels; a map whose tiles modes 5 / 4 do not
+    take falls back to mode 0 by itself."""
     if kernel_variant == "global":
         pytest.skip("dispatch test, independent of the gather/scatter variant")
     from global_flow_local_attention_amd import _lib, fc_mfma
-    assert fc_mfma.DEFAULT_MODE == 4
-    F0, B0 = _lib.PATH_FC_FWD_MODE0, _lib.PATH_FC_BWD_MODE0
-    counts = lambda: [_lib.path_count(i) for i in range(_lib.PATH_COUNT)]
+    assert fc_mfma.DEFAULT_MODE == 5
+    fc_ids = [_lib.fc_path(m, bwd) for m in range(6) for bwd in (False, True)]
+    counts = lambda: {i: _lib.path_count(i) for i in fc_ids}
+
+    def delta_of(before):
+        after = counts()
+        return {i: after[i] - before[i] for i in fc_ids if after[i] != before[i]}
+
     mod = gfla.ExtractorAttn(16, 3, torch.nn.LeakyReLU(0.1), softmax=True).to(DEV)
     assert not hasattr(mod, "fc_mode")
     s, t = (randn((2, 16, 12, 10), seed=i).to(DEV).requires_grad_() for i in (1, 2))
     f = make_flow("smooth", 2, 12, 10, seed=3).to(DEV).requires_grad_()
-    before = counts()
-    mod(s, t, f).sum().backward()
-    torch.cuda.synchronize()
-    delta = [a - b for a, b in zip(counts(), before)]
-    assert delta[F0 + 4] == 1 and delta[B0 + 4] == 1, delta
-    assert sum(delta[F0:F0 + 4]) == 0 and sum(delta[B0:B0 + 4]) == 0, delta       # nothing else ran
-    before = counts()
-    mod.fc_mode = 0                                                               # the direct f32 kernels on request
-    mod(s, t, f).sum().backward()
-    delta = [a - b for a, b in zip(counts(), before)]
-    assert delta[F0] == 1 and delta[B0] == 1 and delta[F0 + 4] == 0, delta
-    assert fc_mfma.resolve_mode(16, 12, 10, 3) == 4
+    for mode, want in ((None, 5), (4, 4), (0, 0)):
+        if mode is not None:
+            mod.fc_mode = mode                                                    # the float32 kernels on request
+        before = counts()
+        mod(s, t, f).sum().backward()
+        torch.cuda.synchronize()
+        assert delta_of(before) == {_lib.fc_path(want): 1, _lib.fc_path(want, True): 1}, (mode, delta_of(before))   # nothing else ran
+    assert fc_mfma.resolve_mode(16, 12, 10, 3) == 5
     wide = fc_mfma.resolve_mode(8, 8, 700, 5)                                     # a span of 10 rows x 708 pixels: no LDS for it
-    assert wide in (0, None) and not fc_mfma.supported(8, 8, 700, 5, 4)
+    assert wide in (0, None) and not fc_mfma.supported(8, 8, 700, 5, 4) and not fc_mfma.supported(8, 8, 700, 5, 5)
 
 
 def test_tuning_reaches_the_autograd_backward_thread(gfla, kernel_variant):

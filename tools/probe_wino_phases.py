@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from global_flow_local_attention_amd import _lib, fc_mfma
 DEV = "cuda:0"
 p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-B, C, H, W, k, mode = 32, 128, 64, 44, 5, 4
+B, C, H, W, k, mode = 32, 128, 64, 44, 5, int(sys.argv[1]) if len(sys.argv) > 1 else 4
 torch.manual_seed(0)
 s, t = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
 f = torch.randn(B, 2, H, W, device=DEV)
