@@ -562,7 +562,8 @@ def fc_kernel_probes(hp, iters=10):
     from global_flow_local_attention_amd import fc_mfma
     names = ("conv fwd source", "conv fwd target", "data-grad source", "data-grad target", "weight-grad source",
              "weight-grad target", "conv fwd source + target (one launch, as in the step)",
-             "data-grad source + target (one launch, as in the step)")
+             "data-grad source + target (one launch, as in the step)",
+             "weight-grad source + target (one launch, as in the step)")
     rows = []
     for mod, (src, tgt, flow) in zip(hp.attn, hp.inputs):
         mode = getattr(mod, "fc_mode", None)
@@ -602,10 +603,10 @@ def fc_kernel_probes(hp, iters=10):
                 us = e0.elapsed_time(e1) / iters * 1e3
                 row = {"dims": [B, C, H, W, k], "avg_us": round(us, 1)}
                 if which > 5:   # two jobs in one launch: the sums of the two halves' rows above
-                    halves = layer_rows[0:2] if which == 6 else layer_rows[2:4]
+                    halves = layer_rows[0:2] if which == 6 else (layer_rows[2:4] if which == 7 else layer_rows[4:6])
                     done = sum(r["alg_GFLOP"] for r in halves) * 1e9
                     eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
-                    kern = "fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel"
+                    kern = "fc_wino_wgrad_kernel" if which == 8 else ("fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel")
                     row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
                                 "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
                                 "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
@@ -1237,7 +1238,8 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
         # with the longest launch
         dom = max(probes, key=lambda r: r["avg_us"])
-        step_rows = [r for r in probes if r.get("in_step") and r["dims"] == dom["dims"]]
+        step_rows = [r for r in probes if r.get("in_step") and r["dims"] == dom["dims"]
+                     and r["kernel"].split("<")[0] == dom["kernel"].split("<")[0]]
         if dom.get("in_step") and len(step_rows) > 1:
             # the step launches this kernel twice per layer (forward of both halves, data gradient of both halves): the
             # object describes the kernel over both launches, so its average duration is the one a kernel trace shows

@@ -525,7 +525,7 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
 int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C_, int64_t H_, int64_t W_,
                        int kernel_size, int mode, gfla_stream_t stream_) {
   if (!workspace || !scratch) return GFLA_ERR_NULL_POINTER;
-  if (which < 0 || which > 7 || (which > 5 && !fc_is_wino(mode))) return GFLA_ERR_BAD_SHAPE;
+  if (which < 0 || which > 8 || (which > 5 && !fc_is_wino(mode))) return GFLA_ERR_BAD_SHAPE;
   const int C = (int)C_, H = (int)H_, W = (int)W_, k = kernel_size;
   GFLA_TRY(fc_args_ok(B, C, H, W, k, mode));
   if (B == 0) return GFLA_OK;
@@ -552,6 +552,15 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
         {fc_desc_nhwc(reinterpret_cast<float *>(sc + L.dzt), L.ht.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_dt),
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
     return fc_wino_jobs(jobs, 2, am_d, amx + kAmaxW, w16 && fc_w16_dgrad(k), B, kFcHidden / kFcChunk, k, stream);
+  }
+  if (which == 8) {
+    if (!fc_wgrad_in_wino_domain(mode, k)) return GFLA_ERR_UNSUPPORTED;
+    const WwJob jobs[2] = {
+        {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, 0), reinterpret_cast<float *>(sc + L.dzs), reinterpret_cast<float *>(sc + L.dwp),
+         L.hs.Sz * kFcHidden, L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
+        {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, 0), reinterpret_cast<float *>(sc + L.dzt), reinterpret_cast<float *>(sc + L.dwp2),
+         L.ht.Sz * kFcHidden, L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
+    return fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream);
   }
   if (fc_is_wino(mode)) {
     const PackedDesc X4 = fc_desc_packed(ws + (source ? L.xs : L.xt), B, L.nch_c, g.Sx, 0);

@@ -110,11 +110,18 @@ __global__ __launch_bounds__(256) void fc_maxabs_kernel(MaxAbsJobs jobs) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
   const float4 *x4 = reinterpret_cast<const float4 *>(x);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const float4 v = x4[i];
+  // four 16-byte requests in flight per thread: with one the pass ran at 2.8 TB/s (82 us per step in arithmetic mode 5, which
+  // reads every operand tensor once more than mode 4: one-stream trace, round 6)
+  auto fold4 = [&](const float4 &v) {
     m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
     m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  };
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    fold4(v0), fold4(v1), fold4(v2), fold4(v3);
   }
+  for (; i < n4; i += stride) fold4(x4[i]);
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
     m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
 #pragma unroll
@@ -145,7 +152,7 @@ int fc_maxabs_multi(const float *x0, int64_t n0, uint32_t *slot0, const float *x
   if (nj == 0) return GFLA_OK;
   for (int i = nj; i < 3; ++i) jobs.j[i] = jobs.j[0];
   int64_t blocks = ceil_div(most, 256 * 16);
-  if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
+  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
   fc_maxabs_kernel<<<dim3((unsigned)blocks, (unsigned)nj), 256, 0, stream>>>(jobs);
   return launch_status();
 }

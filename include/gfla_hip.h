@@ -440,8 +440,9 @@ int gfla_fc_conv_bwd_f32(const float *z, int is_source, void *workspace, void *s
                          gfla_stream_t stream);
 /* gfla_fc_kernel: ONE internal kernel of the path on the state a forward + backward of the same shape left in
  * workspace / scratch, for per-kernel timing (bench.py, profiles).  which: 0 / 1 convolution forward of the source /
- * target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient; mode 4 only: 6 / 7 = the forward / data-gradient
- * convolutions of both halves in ONE launch, the way gfla_fc_forward / gfla_fc_backward issue them.               */
+ * target half, 2 / 3 data-gradient convolution, 4 / 5 weight gradient; modes 4 / 5 only: 6 / 7 = the forward / data-gradient
+ * convolutions of both halves in ONE launch, 8 = both Winograd-domain weight gradients in one launch, the way
+ * gfla_fc_forward / gfla_fc_backward issue them.                                                                  */
 int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int64_t C, int64_t H, int64_t W,
                        int kernel_size, int mode, gfla_stream_t stream);
 int gfla_fc_tr_probe(const int16_t *image, int n_halves, const int32_t *offsets, int16_t *out,
