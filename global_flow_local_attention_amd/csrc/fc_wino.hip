@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
   const int ntn = GFLA_PICK(ntn);
   WnGeo geo;
   geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.ngroups = GFLA_PICK(geo.ngroups), geo.span = GFLA_PICK(geo.span);
+  geo.tpg = GFLA_PICK(geo.tpg);
 #undef GFLA_PICK
   // DBG & 16: per-wave phase timing (s_memtime) summed over the steps -> stamps[workgroup][wave][6]
   unsigned long long tk0 = 0, t_first = 0, t_second = 0, t_bar = 0, t_pro = 0, t_epi = 0;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
   const int64_t b = glin / geo.ngroups;
   const int grp = (int)(glin - b * geo.ngroups);
   const int ntiles = geo.TH * geo.TW;
-  const int tile0 = grp * kWnTiles;
+  const int tile0 = grp * geo.tpg;
   const int ty_first = tile0 / geo.TW;
   const int p0 = M * ty_first * Wp;                         // first pixel of the staged span
   const int64_t avail = S - p0;                             // pixels of this sample behind p0 (the rest reads as zero)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
   const int tl = (t & 255) >> 3, c8 = t & 7;
   int toff;
   {
-    const int tau = min(tile0 + tl, ntiles - 1);
+    const int tau = min(tile0 + min(tl, geo.tpg - 1), ntiles - 1);   // (slots behind the group's tiles repeat its last one)
     const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
     toff = ((M * ty * Wp + M * tx) - p0) * PITCH + c8 * 4;
   }
@@ -424,8 +425,8 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_conv_kernel(WnKArgs a0,
     const float *srcp = xch + ((HALF * 4 + nb) * 64 + lane) * 4 * M * M;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tau = tile0 + HALF * 16 + 4 * (lane >> 4) + r;
-      if (tau >= ntiles || col >= n_valid) continue;
+      const int slot_ = HALF * 16 + 4 * (lane >> 4) + r, tau = tile0 + slot_;
+      if (slot_ >= geo.tpg || tau >= ntiles || col >= n_valid) continue;
       const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
 #pragma unroll
       for (int i = 0; i < M; ++i) {

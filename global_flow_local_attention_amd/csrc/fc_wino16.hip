@@ -176,6 +176,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
   const int ntn = GFLA_PICK(ntn);
   WnGeo geo;
   geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.ngroups = GFLA_PICK(geo.ngroups), geo.span = GFLA_PICK(geo.span);
+  geo.tpg = GFLA_PICK(geo.tpg);
 #undef GFLA_PICK
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   uint32_t *vbuf = reinterpret_cast<uint32_t *>(gfla_smem);   // [2][36 points][2 quads][32 tiles][4 channels] (hi, lo) words
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
   const int64_t b = glin / geo.ngroups;
   const int grp = (int)(glin - b * geo.ngroups);
   const int ntiles = geo.TH * geo.TW;
-  const int tile0 = grp * kWnTiles;
+  const int tile0 = grp * geo.tpg;
   const int ty_first = tile0 / geo.TW;
   const int p0 = M * ty_first * Wp;
   const int64_t avail = S - p0;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
   const int tl = (t & 255) >> 3, c8 = t & 7;
   int toff;
   {
-    const int tau = min(tile0 + tl, ntiles - 1);
+    const int tau = min(tile0 + min(tl, geo.tpg - 1), ntiles - 1);   // (slots behind the group's tiles repeat its last one)
     const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
     toff = ((M * ty * Wp + M * tx) - p0) * PITCH + c8 * 4;
   }
@@ -469,8 +470,8 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_conv_kernel(Wn16KArgs
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int tau = tile0 + 8 * qd + 4 * g + r;
-          if (tau >= ntiles || col >= n_valid) continue;
+          const int slot_ = 8 * qd + 4 * g + r, tau = tile0 + slot_;
+          if (slot_ >= geo.tpg || tau >= ntiles || col >= n_valid) continue;
           const int ty = tau / geo.TW, tx = tau - ty * geo.TW;
 #pragma unroll
           for (int i = 0; i < M; ++i) {

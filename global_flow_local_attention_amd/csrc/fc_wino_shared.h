@@ -102,27 +102,19 @@ struct WnPackJobs {
 };
 
 struct WnGeo {
-  int TH, TW, ngroups, span;  // tile grid, groups of 32 tiles per sample, raw pixels a group stages per chunk
+  int TH, TW, ngroups, span;  // tile grid, groups of up to 32 tiles per sample, raw pixels a group stages per chunk
+  int tpg;                    // tiles per group: 32, or whole tile rows on narrow maps (below)
 };
 
+// span of the groups of `tpg` consecutive tiles: from the first pixel of a group's first tile row to the last pixel of its last
+// tile's 6 x 6 window (groups start at multiples of tpg tiles, so few of them are the worst case)
 template <int KS>
-inline WnGeo wn_geometry(int M, int Wv, int Wp) {
+inline int wn_span(const WnGeo &g, int tpg, int Wp) {
   constexpr int m = Wn<KS>::M;
-  WnGeo g;
-  const int Ho = M / Wv;
-  g.TH = (Ho + m - 1) / m;
-  g.TW = (Wv + m - 1) / m;
-  g.ngroups = (g.TH * g.TW + kWnTiles - 1) / kWnTiles;
-  // tile rows a group of 32 consecutive tiles can touch
-  int rows = g.TW >= kWnTiles ? 2 : (kWnTiles + g.TW - 2) / g.TW + 1;
-  if (rows > g.TH) rows = g.TH;
-  g.span = ((rows - 1) * m + 6) * Wp + 6;
-  // ... and what the groups of THIS map actually reach: from the first pixel of a group's first tile row to the last pixel of
-  // its last tile's 6 x 6 window (groups start at multiples of 32 tiles, so few of them are the worst case)
-  const int ntiles = g.TH * g.TW;
+  const int ntiles = g.TH * g.TW, ngroups = (ntiles + tpg - 1) / tpg;
   int exact = 0;
-  for (int grp = 0; grp < g.ngroups; ++grp) {
-    const int t0 = grp * kWnTiles, t1 = std::min(t0 + kWnTiles, ntiles) - 1;
+  for (int grp = 0; grp < ngroups; ++grp) {
+    const int t0 = grp * tpg, t1 = std::min(t0 + tpg, ntiles) - 1;
     const int r0 = t0 / g.TW, r1 = t1 / g.TW;
     int need = 0;
     for (int r = std::max(r0, r1 - 1); r <= r1; ++r) {   // the last pixel is the last tile's, or the previous row's last tile's
@@ -131,7 +123,29 @@ inline WnGeo wn_geometry(int M, int Wv, int Wp) {
     }
     exact = std::max(exact, need);
   }
-  if (exact < g.span) g.span = exact;
+  return exact;
+}
+
+template <int KS>
+inline WnGeo wn_geometry(int M, int Wv, int Wp) {
+  constexpr int m = Wn<KS>::M;
+  WnGeo g;
+  const int Ho = M / Wv;
+  g.TH = (Ho + m - 1) / m;
+  g.TW = (Wv + m - 1) / m;
+  const int ntiles = g.TH * g.TW;
+  g.tpg = kWnTiles;
+  g.ngroups = (ntiles + kWnTiles - 1) / kWnTiles;
+  g.span = wn_span<KS>(g, kWnTiles, Wp);
+  // Narrow maps (the k = 3 layer at 32x22: 6 tiles of 4 x 4 per row): groups of WHOLE tile rows -- 30 of the 32 slots -- reach
+  // one tile row less than 32 consecutive tiles that start mid-row, and that is what lets the span fit TWO raw buffers next
+  // to the V buffers (610 -> 534 pixels at 32x22: 161.5 KB -> 151 KB; the single-buffer staging costs a barrier and an exposed
+  // copy per chunk).  Taken when it wastes at most 4 slots and does not add a group.  Tuning key 44 = 1: always 32.
+  const int whole = g.TW < kWnTiles ? (kWnTiles / g.TW) * g.TW : kWnTiles;
+  if (whole != kWnTiles && whole >= kWnTiles - 4 && (ntiles + whole - 1) / whole == g.ngroups && tuning(44) != 1) {
+    const int sp = wn_span<KS>(g, whole, Wp);
+    if (sp < g.span) g.tpg = whole, g.span = sp;
+  }
   return g;
 }
 

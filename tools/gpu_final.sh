@@ -10,7 +10,8 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # the default bench FIRST: after rocprofv3 --pmc passes in the same job the f32-MFMA kernels run ~10 % slower for a while
-( time timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
+# (the last stdout line is the short one; the full record is written to the detail file)
+( time BENCH_DETAIL=$OUT/bench_detail.json timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json; cat $OUT/bench.time | tail -3
 BENCH="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-legs"
 NS="python $PWD/tools/bench_north_star.py --sweep none --iters 3"
 for C in FETCH_SIZE WRITE_SIZE; do
