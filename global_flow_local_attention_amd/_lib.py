@@ -178,6 +178,11 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class Unsupported(RuntimeError):
+    """GFLA_ERR_UNSUPPORTED (-3): the arguments are valid but outside what this entry point's kernels take (nothing was
+    launched).  Callers that have another way to the same result catch exactly this."""
+
+
 def call(name, ref_tensor, *args):
     """Invoke `name` on the current stream of ref_tensor's device; raise on non-zero status."""
     fn = getattr(lib(), name)
@@ -185,7 +190,8 @@ def call(name, ref_tensor, *args):
         stream = ctypes.c_void_p(torch.cuda.current_stream(ref_tensor.device).cuda_stream)
         status = fn(*args, stream)
     if status != 0:
-        raise RuntimeError("%s failed: %s (status %d)" % (name, lib().gfla_status_string(status).decode(), status))
+        err = Unsupported if status == -3 else RuntimeError
+        raise err("%s failed: %s (status %d)" % (name, lib().gfla_status_string(status).decode(), status))
 
 
 def convert_many(tensors, dtype):

@@ -58,9 +58,22 @@ class BlockExtractorFunction(Function):
         if (want_source or want_flow) and grad_patches.numel() > 0 and source.numel() > 0:
             B, C, Hs, Ws = source.shape
             Hf, Wf = flow_field.shape[2:]
-            _lib.call(_ENTRY_BWD + _lib.suffix(source, "block_extractor backward"), source,
-                      _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_patches),
-                      _lib.ptr(g_source), _lib.ptr(g_flow), B, C, Hs, Ws, Hf, Wf, ctx.kernel_size)
+            try:
+                _lib.call(_ENTRY_BWD + _lib.suffix(source, "block_extractor backward"), source,
+                          _lib.ptr(source), _lib.ptr(flow_field), _lib.ptr(grad_patches),
+                          _lib.ptr(g_source), _lib.ptr(g_flow), B, C, Hs, Ws, Hf, Wf, ctx.kernel_size)
+            except _lib.Unsupported:
+                if source.dtype != torch.bfloat16:
+                    raise
+                # bfloat16 planes beyond the LDS budget (e.g. one (1,64,256,176) map): the bf16 backward exists for the
+                # planes-in-LDS kernels only -- the tile kernels accumulate into float32 / float64 windows and flush with float
+                # atomics.  Storage is widened for this call: the float32 kernels run on exact up-casts of the bf16 values, the
+                # source gradient is rounded to bf16 once at the end (one rounding per element, as the bf16 kernels do).
+                s32, f32_, gp32 = _lib.convert_many([source, flow_field, grad_patches], torch.float32)
+                gs32 = torch.zeros_like(s32) if want_source else None
+                _lib.call(_ENTRY_BWD + "f32", s32, _lib.ptr(s32), _lib.ptr(f32_), _lib.ptr(gp32), _lib.ptr(gs32),
+                          _lib.ptr(g_flow), B, C, Hs, Ws, Hf, Wf, ctx.kernel_size)
+                g_source = None if gs32 is None else _lib.convert_many([gs32], torch.bfloat16)[0]
         if g_flow is not None and g_flow.dtype != flow_field.dtype:
             g_flow = g_flow.to(flow_field.dtype)
         return g_source, g_flow, None

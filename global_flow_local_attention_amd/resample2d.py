@@ -54,22 +54,35 @@ class Resample2dFunction(Function):
             _, C, Hi, Wi = input1.shape
             B, _, H, W = input2.shape
             sfx = _lib.suffix(input1, "resample2d backward")
-            entry = "gfla_resample2d_bwd_" + sfx
             tail = (B, C, Hi, Wi, H, W, ctx.kernel_size, ctx.dilation, 1 if TRUNC_COMPAT else 0)
             tail1 = tail[:-1] + (tail[-1] | 2,)  # bit 1: overwrite grad_in1
             # two independent kernels (scatter into input1 / reduction for (dx, dy, sigma)): one C-ABI
             # call each keeps them separately visible to profilers
-            if want1:
-                if sfx == "f32":  # d/d input1 as a block-sparse product on the matrix cores when the shape allows
-                    ws = _lib.scatter_workspace(input1, B, H, W, ctx.kernel_size * ctx.kernel_size)
-                    _lib.call("gfla_resample2d_bwd_ws_f32", input1, _lib.ptr(input1), _lib.ptr(input2),
-                              _lib.ptr(grad_warped), _lib.ptr(g1), None, _lib.ptr(ws), *tail1)
-                else:
-                    _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
-                              _lib.ptr(g1), None, *tail1)
-            if want2:
-                _lib.call(entry, input1, _lib.ptr(input1), _lib.ptr(input2), _lib.ptr(grad_warped),
-                          None, _lib.ptr(g2), *tail)
+            def run(i1, i2, gw, o1, o2, sfx_):
+                entry_ = "gfla_resample2d_bwd_" + sfx_
+                if o1 is not None:
+                    if sfx_ == "f32":  # d/d input1 as a block-sparse product on the matrix cores when the shape allows
+                        ws = _lib.scatter_workspace(i1, B, H, W, ctx.kernel_size * ctx.kernel_size)
+                        _lib.call("gfla_resample2d_bwd_ws_f32", i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(gw), _lib.ptr(o1), None,
+                                  _lib.ptr(ws), *tail1)
+                    else:
+                        _lib.call(entry_, i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(gw), _lib.ptr(o1), None, *tail1)
+                if o2 is not None:
+                    _lib.call(entry_, i1, _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(gw), None, _lib.ptr(o2), *tail)
+
+            try:
+                run(input1, input2, grad_warped, g1, g2, sfx)
+            except _lib.Unsupported:
+                if sfx != "bf16":
+                    raise
+                # bfloat16 planes beyond the LDS budget: the bf16 backward exists for the planes-in-LDS kernels only; storage is
+                # widened for this call (exact up-casts; d/d input1 rounded to bf16 once at the end) -- block_extractor.py
+                i1, i2, gw = _lib.convert_many([input1, input2, grad_warped], torch.float32)
+                g1_32 = torch.empty_like(i1) if want1 else None
+                if g2 is not None:
+                    g2.zero_()   # (a first, refused call may not have touched it; the float32 kernels accumulate into it)
+                run(i1, i2, gw, g1_32, g2, "f32")
+                g1 = None if g1_32 is None else _lib.convert_many([g1_32], torch.bfloat16)[0]
         elif g1 is not None:
             g1.zero_()  # nothing was launched (an empty input2 / gradient): d/d input1 is zero, not uninitialised memory
         if g2 is not None and g2.dtype != input2.dtype:
