@@ -137,6 +137,28 @@ def test_two_term_f16_operands_over_the_float32_range(gfla, k, B, C, H, W, scale
         assert e_f <= FWD_TOL and e_x <= GRAD_TOL and e_w <= GRAD_TOL, (e_f, e_x, e_w)
 
 
+@pytest.mark.parametrize("k,B,C,H,W", [(5, 2, 24, 11, 9), (3, 2, 40, 9, 14)])
+def test_two_term_f16_operands_all_zero_and_denormal_tensors(gfla, k, B, C, H, W):
+    """max |x| = 0 (no scale can be derived: scale 1) and max |x| in float32's denormal range: mode 5 must return exact zeros /
+    finite values, never NaN from a 0 * inf or an overflowing inverse scale."""
+    from global_flow_local_attention_amd import fc_mfma
+    for scale_x, scale_w, scale_g in ((0.0, 1.0, 1.0), (1.0, 0.0, 1.0), (1.0, 1.0, 0.0), (1e-42, 1.0, 1e-43)):
+        for is_source in (0, 1):
+            x = (randn((B, C, H, W), seed=1) * scale_x).to(DEV)
+            w0 = (randn((128, 2 * C, k, k), seed=2) * 0.05 * scale_w).to(DEV)
+            g = fc_mfma.geometry(H, W, k, is_source)
+            dG = (randn((B, 128, g["Ho"], g["Wo"]), seed=3) * scale_g).to(DEV)
+            fwd, gx, gw, _ = _run_half(B, C, H, W, k, is_source, 5, x, w0, dG)
+            for name, t in (("map", fwd), ("grad_x", gx), ("grad_w", gw)):
+                assert torch.isfinite(t).all(), (scale_x, scale_w, scale_g, name)
+            if scale_x == 0.0 or scale_w == 0.0:
+                assert float(fwd.abs().max()) == 0.0
+            if scale_g == 0.0 or scale_w == 0.0:
+                assert float(gx.abs().max()) == 0.0
+            if scale_g == 0.0 or scale_x == 0.0:
+                assert float(gw.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("wmode", [4, 5])
 @pytest.mark.parametrize("k,C,H,W", [(5, 128, 64, 44), (3, 256, 32, 22)])
 def test_winograd_linearity_and_adjointness_at_bench_shape(gfla, k, C, H, W, wmode):
