@@ -83,12 +83,13 @@ class _RefLocalAttnReshape(Function):  # local_attn_reshape.py:8-37
         return ref_ext.local_attn_reshape_bwd(x, g.contiguous(), ctx.k), None
 
 
-def reference_extractor_attn(s, t, f, w0, b0, w1, b1, k):
+def reference_extractor_attn(s, t, f, w0, b0, w1, b1, k, slope=None):
     """ExtractorAttn.forward (base_function.py:804-810), softmax=True, with the real reference kernels."""
+    slope = SLOPE if slope is None else slope
     block_source = _RefBlockExtractor.apply(s, f, k)
     block_target = _RefBlockExtractor.apply(t, torch.zeros_like(f), k)
     hidden = F.conv2d(torch.cat((block_target, block_source), 1), w0, b0, stride=k)
-    attn = torch.softmax(F.conv2d(F.leaky_relu(hidden, SLOPE), w1, b1), 1)
+    attn = torch.softmax(F.conv2d(F.leaky_relu(hidden, slope), w1, b1), 1)
     attn = _RefLocalAttnReshape.apply(attn.contiguous(), k)
     return F.avg_pool2d(attn * block_source, k, k), hidden.detach()
 
@@ -104,9 +105,9 @@ def make_case(B, C, H, W, k, seed):
     return s, t, f, w0, b0, w1, b1, up
 
 
-def run_module(gfla, case, C, k, impl, mode, dev=DEV):
+def run_module(gfla, case, C, k, impl, mode, dev=DEV, act=None):
     s, t, f, w0, b0, w1, b1, up = case
-    m = gfla.ExtractorAttn(C, k, torch.nn.LeakyReLU(SLOPE), softmax=True)
+    m = gfla.ExtractorAttn(C, k, act if act is not None else torch.nn.LeakyReLU(SLOPE), softmax=True)
     with torch.no_grad():
         m.fully_connect_layer[0].weight.copy_(w0)
         m.fully_connect_layer[0].bias.copy_(b0)
@@ -166,6 +167,43 @@ def test_extractor_attn_bench_shape_vs_real_reference_kernels(gfla, reference_re
     print("%s %s/%d: " % (name, impl, mode) + " ".join("%s %.2e" % e for e in errs))
     for n, e in errs:
         assert e <= TOL, "%s, %s mode %d: %s rel err %.3e" % (name, impl, mode, n, e)
+
+
+# ShapeNet novel-view synthesis (generator.py:590-670: layers = 6, attn_layer = [1, 2], kernel size 5 on both, ngf = 64,
+# activation ReLU, 256x256 images): ExtractorAttn(128, 5) on 64x64 maps and ExtractorAttn(64, 5) on 128x128 maps.  The second is
+# the widest map of any recipe of the reference (single raw buffer in the Winograd kernels); whatever arithmetic mode
+# fc_mfma.resolve_mode picks for it is the one asserted to have run (round 6: mode 5 on both).
+SHAPENET_SHAPES = [("shapenet_attn2", 4, 128, 64, 64, 5), ("shapenet_attn1", 2, 64, 128, 128, 5)]
+
+
+@pytest.mark.parametrize("name,B,C,H,W,k", SHAPENET_SHAPES)
+def test_extractor_attn_shapenet_shapes_relu_default_dispatch(gfla, name, B, C, H, W, k):
+    _ref()
+    from global_flow_local_attention_amd import _lib, fc_mfma
+    mode = fc_mfma.resolve_mode(C, H, W, k)
+    assert mode is not None, "no MFMA kernel takes %s" % name
+    case = make_case(B, C, H, W, k, seed=800)
+    s, t, f, w0, b0, w1, b1, up = [x.double().to(DEV) for x in case]
+    params = [p.clone().requires_grad_() for p in (w0, b0, w1, b1)]
+    outs, gin = [], [[], [], []]
+    for lo in range(0, B, 1):     # one sample at a time: the float64 block tensors of a 128x128 map are 0.4 GB each
+        a = [x[lo:lo + 1].clone().requires_grad_() for x in (s, t, f)]
+        out, hidden = reference_extractor_attn(*a, *params, k, slope=0.0)     # ReLU
+        out.backward(up[lo:lo + 1])
+        assert hidden.abs().min().item() > 1e-3
+        outs.append(out.detach())
+        for dst, x in zip(gin, a):
+            dst.append(x.grad)
+        del out, hidden
+    want_out, want_grads = torch.cat(outs), [torch.cat(g) for g in gin] + [p.grad for p in params]
+    before = _lib.path_count(_lib.fc_path(mode))
+    out, grads = run_module(gfla, case, C, k, "mfma", None, act=torch.nn.ReLU())
+    assert _lib.path_count(_lib.fc_path(mode)) == before + 1, "the resolved arithmetic mode %d did not run" % mode
+    errs = [("out", rel_err(out, want_out))] + [(n, rel_err(g, w)) for n, g, w in zip(NAMES, grads, want_grads)]
+    print("%s (mode %d): " % (name, mode) + " ".join("%s %.2e" % e for e in errs))
+    for n, e in errs:
+        assert e <= TOL, "%s: %s rel err %.3e" % (name, n, e)
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("impl,mode", [("mfma", 0), ("library", 0)])
