@@ -1209,7 +1209,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.fc_mode in (0, 4) else
-                 ("f32 tensors / transforms / accumulation; FC products as two-term f16 splits (exact to 2^-24) on f16 MFMA"
+                 ("f32 (FC products: 2-term f16 splits exact to 2^-24 on f16 MFMA, f32 accumulate)"
                   if args.fc_mode == 5 else "f32 tensors; FC operands split into f16 terms (mode %d)" % args.fc_mode),
         "data": data,
         "config": {"workload": "GFLA hot path at PoseGenerator 256x176 shapes, attn_layer=2,3 kernel_size 2=5,3=3: "
@@ -1334,7 +1334,7 @@ def compact_line(line, detail_file):
 
     out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data") if k in line}
-    out["metric"], out["dtype"], out["data"] = cut(out["metric"], 160), cut(out["dtype"], 80), cut(out["data"], 100)
+    out["metric"], out["dtype"], out["data"] = cut(out["metric"], 160), cut(out["dtype"], 100), cut(out["data"], 100)
     cfg = line.get("config", {})
     out["config"] = {"workload": cut(cfg.get("workload", ""), 330)}
     for k in ("batch_per_gpu", "global_batch", "clips_per_gpu", "frames_per_clip"):

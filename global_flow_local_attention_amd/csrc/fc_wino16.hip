@@ -38,10 +38,15 @@ __host__ __device__ __forceinline__ int wn16_scale_exp(uint32_t amax_bits, int h
 __device__ __forceinline__ float wn16_pow2(int biased) { return __uint_as_float((uint32_t)biased << 23); }
 constexpr int kWn16HeadX = 6, kWn16HeadW = 3;
 
+// (hi, lo) word of a value in three instructions: v_cvt_f16_f32, v_fma_mix_f32 (v * 1 - hi with hi read as f16: the exact
+// remainder, no convert back), v_cvt_pk_f16_f32 of (v, remainder) -- RN16(v) again in the low half, RN16(remainder) in the
+// high one.  (The plain C form compiles to five: two converts, a convert back, a subtract and an or.)
+typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t wn16_split(float v) {
   const _Float16 h = (_Float16)v;
-  const _Float16 l = (_Float16)(v - (float)h);
-  return (uint32_t)__builtin_bit_cast(unsigned short, h) | ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
+  float rem;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rem) : "v"(v), "v"(h));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v, rem}, f16x2w));
 }
 
 // ---- weights: conv0.weight (128, 2C, k, k) -> U = G w G^T * scale as (hi, lo) words in B-fragment order --------------
