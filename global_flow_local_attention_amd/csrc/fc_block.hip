@@ -303,18 +303,25 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   uint32_t *amax = reinterpret_cast<uint32_t *>(ws + L.amax);
   const float *hid = reinterpret_cast<const float *>(ws + L.hid);
   float *red_tmp = reinterpret_cast<float *>(sc + L.red_tmp);
-  if (hipMemsetAsync(sc, 0, L.zero_bytes, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
   const bool w16 = mode_ == 5;
-  if ((mode || w16) && hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
   const float *gs = reinterpret_cast<const float *>(ws + L.gs);
   const bool need_s = g_source || g_w0, need_t = g_target || g_w0;
   float *dzs = need_s ? reinterpret_cast<float *>(sc + L.dzs) : nullptr;
   float *dzt = need_t ? reinterpret_cast<float *>(sc + L.dzt) : nullptr;
   float *b0p = g_b0 ? reinterpret_cast<float *>(sc + L.b0p) : nullptr;
   const int64_t tiles = ceil_div((int64_t)H * W, 64);
-  GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
+  // d Gs by owner-computes (fc_sample.hip: fc_scatter_own_kernel) whenever both gradient maps are wanted and a row of the
+  // map fits the LDS: no global atomics, no memset of the source half's map, and max |dz| of both maps as by-products
+  // (tuning key 46 = 1: round 2's atomics)
+  const bool own = dzs && dzt && tuning(46) != 1 && fc_scatter_own_rows(B, L.hs.Ho, L.hs.Wo) >= 1;
+  if (hipMemsetAsync(sc + (own ? L.dzt : 0), 0, L.zero_bytes - (own ? L.dzt : 0), stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  if ((mode || w16 || own) && hipMemsetAsync(amax + kAmaxZs, 0, 8, stream) != hipSuccess) return GFLA_ERR_LAUNCH;
+  GFLA_TRY(fc_sample_tail_bwd(gs, flow, hid, w1, g_logits, own ? nullptr : dzs, dzt, g_flow, b0p, B, H, W, k, L.hs.Mg * kFcHidden,
                               L.hs.Wo, L.hs.Wp, L.ht.Wp, L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, slope,
-                              flags & GFLA_FC_ACCUMULATE_FLOW, stream));
+                              flags & GFLA_FC_ACCUMULATE_FLOW, stream, own ? amax + kAmaxZt : nullptr));
+  if (own)
+    GFLA_TRY(fc_sample_scatter_own(flow, dzt, dzs, amax + kAmaxZt, amax + kAmaxZs, B, H, W, k, L.hs.Ho, L.hs.Wo, L.hs.Wp, L.ht.Wp,
+                                   L.hs.Sz * kFcHidden, L.ht.Sz * kFcHidden, L.hs.lead, L.ht.lead, L.hs.Sz, stream));
   const float *dw1p = nullptr;
   if (g_w1 || g_b1) {
     float *part = reinterpret_cast<float *>(sc + L.dw1p);
@@ -330,7 +337,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   if (both_dgrads) {
     const int nch_h = kFcHidden / kFcChunk;
     const bool d16 = w16 && fc_w16_dgrad(k);
-    if (d16)   // max |dz| of both gradient maps: the scale of their two-term f16 split
+    if (d16 && !own)   // max |dz| of both gradient maps: the scale of their two-term f16 split
       GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
                                0, nullptr, stream));
     const WnConvJob jobs[2] = {
@@ -355,7 +362,8 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   // joint Winograd launch above) both replicate-pad folds by one launch behind the two data-gradient convolutions
   const bool z_both = mode != 0 && need_s && need_t;
   if (z_both) {
-    GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
+    if (!own)
+      GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
                              0, nullptr, stream));
     GFLA_TRY(fc_pack_z2(dzs, amax + kAmaxZs, sc + L.zs_pk, L.hs.Sz, dzt, amax + kAmaxZt, sc + L.zt_pk, L.ht.Sz, B, kFcHidden,
                         mode, stream));

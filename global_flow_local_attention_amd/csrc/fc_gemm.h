@@ -220,7 +220,12 @@ int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, cons
 int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
                        float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
                        int64_t gs_bs, int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
-                       float slope, int acc_flow, hipStream_t stream);
+                       float slope, int acc_flow, hipStream_t stream, uint32_t *amax_d = nullptr);
+// d Gs by owner-computes (no global atomics, no memset, max |d Gs| as a by-product): fc_sample.hip
+int fc_scatter_own_rows(int64_t B, int Ho, int Wo);
+int fc_sample_scatter_own(const float *flow, const float *dzt, float *dzs, const uint32_t *amax_d, uint32_t *amax_out,
+                          int64_t B, int H, int W, int k, int Ho, int Wo, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs,
+                          int lead_s, int lead_t, int64_t Sz, hipStream_t stream);
 int fc_dw1(const float *hid, const float *g_logits, float *partials, int64_t B, int HW, int KK, int tiles_per_sample,
            float slope, hipStream_t stream);
 int fc_fold(const float *dxpad, float *grad, int64_t B, int C, int H, int W, const FcHalf &g, int64_t dx_bs,

@@ -15,6 +15,7 @@
 // channels on the lanes (a tap is 512 contiguous bytes), the 1x1 convolution puts the positions on the lanes and
 // deals the channels to the 4 waves (as fc_tail.hip); a (64 x 128) tile in LDS turns one into the other.
 #include "fc_gemm.h"
+#include "lds_plane.h"
 
 namespace gfla {
 
@@ -60,6 +61,22 @@ __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f 
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+// The same sum, valid in LANE 63 ONLY, as six data-parallel-primitive adds: quad swaps, row mirrors, then the row totals
+// handed down the wave (row_bcast:15 / :31).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip per step, twelve
+// dependent ones per walked position in fc_tail_bwd_kernel.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0xB1>(v);        // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);        // quad_perm:[2,3,0,1]
+  v = dpp_add<0x141>(v);       // row_half_mirror
+  v = dpp_add<0x140>(v);       // row_mirror: every lane of a row holds the row's sum
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
@@ -141,7 +158,8 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     const float *__restrict__ gs, const float *__restrict__ flow, const float *__restrict__ hid,
     const float *__restrict__ w1, const float *__restrict__ g_logits, float *__restrict__ dzs,
     float *__restrict__ dzt, float *__restrict__ gflow, float *__restrict__ b0_partials, int H, int W, int64_t gs_bs,
-    int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope, int acc_flow) {
+    int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, float slope, int acc_flow,
+    uint32_t *__restrict__ amax_d) {
   constexpr int KK = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
   float *tile = reinterpret_cast<float *>(gfla_smem);  // [64][129]: hidden pre-activations, then their gradient
@@ -167,6 +185,7 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
     const float *glp = g_logits + b * (int64_t)KK * HW + (live ? p : 0);
 #pragma unroll
     for (int q = 0; q < KK; ++q) gl[q] = live ? glp[(int64_t)q * HW] : 0.f;
+    uint32_t mx = 0;   // max |d hidden| of this lane (bit pattern: a NaN compares above every finite value)
 #pragma unroll 4
     for (int o = wave; o < kFcHidden; o += 4) {
       const float pre = tile[lane * kSmpPitch + o];
@@ -174,7 +193,15 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       float ga = 0.f;
 #pragma unroll
       for (int q = 0; q < KK; ++q) ga = fmaf(w[q], gl[q], ga);
-      tile[lane * kSmpPitch + o] = pre > 0.f ? ga : ga * slope;
+      const float gp = pre > 0.f ? ga : ga * slope;
+      tile[lane * kSmpPitch + o] = gp;
+      mx = max(mx, __float_as_uint(gp) & 0x7fffffffu);
+    }
+    if (amax_d) {   // the scale of the gradient map's fixed-point scatter (fc_scatter_own_kernel) and of its two-term f16 split
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+      // one atomic per wave, and only when it would raise the slot (a stale read costs an atomic, never a wrong maximum)
+      if (lane == 0 && mx > __hip_atomic_load(amax_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_d, mx);
     }
   }
   __syncthreads();
@@ -214,8 +241,60 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       gn[4] = g00[64], gn[5] = g01[64], gn[6] = g10[64], gn[7] = g11[64];
     }
   };
-  if (nwalk > 0) issue(0);
-  for (int it = 0; it < nwalk; ++it) {
+  if (!zsb) {
+    // The gradient map of Gs is somebody else's (fc_scatter_own_kernel): nothing is carried from position to position, so the
+    // corner values of FOUR positions are in flight at a time, and the flow gradients of the wave's 16 positions are
+    // collected in lanes 0-15 and leave through one store each (the read-modify-write of an accumulated gradient used to sit
+    // in lane 63 of every iteration: a dependent global round trip per position, 16 in a row)
+    float old_x = 0.f, old_y = 0.f, res_x = 0.f, res_y = 0.f;
+    if (gflow && acc_flow && lane < nwalk) {
+      old_x = gflow[(b * 2 + 0) * HW + pw0 + lane];
+      old_y = gflow[(b * 2 + 1) * HW + pw0 + lane];
+    }
+    for (int it0 = 0; it0 < nwalk; it0 += 4) {
+      Corner c4[4];
+      float g4[4][8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        issue(min(it0 + j, nwalk - 1));
+        c4[j] = cn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g4[j][i] = gn[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int it = it0 + j;
+        if (it >= nwalk) break;
+        const int pp = wave * kWalk + it, p = p0 + pp;
+        const Corner &c = c4[j];
+        const float *g = g4[j];
+        const float d0 = tile[pp * kSmpPitch + lane], d1 = tile[pp * kSmpPitch + lane + 64];
+        s0 += d0;
+        s1 += d1;
+        if (ztb) {
+          const int y = p / W, x = p - y * W;
+          float *zp = ztb + (int64_t)(lead_t + y * wpt + x) * kFcHidden + lane;
+          zp[0] = d0;
+          zp[64] = d1;
+        }
+        if (gflow) {
+          float gx = d0 * (c.yt * (g[1] - g[0]) + c.yb * (g[3] - g[2])) + d1 * (c.yt * (g[5] - g[4]) + c.yb * (g[7] - g[6]));
+          float gy = d0 * (c.xl * (g[2] - g[0]) + c.xr * (g[3] - g[1])) + d1 * (c.xl * (g[6] - g[4]) + c.xr * (g[7] - g[5]));
+          gx = wave_sum_lane63(gx);
+          gy = wave_sum_lane63(gy);
+          const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx), 63));
+          const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), 63));
+          if (lane == it) res_x = sx, res_y = sy;
+        }
+      }
+    }
+    if (gflow && lane < nwalk) {  // this workgroup is the only writer of its pixels
+      gflow[(b * 2 + 0) * HW + pw0 + lane] = acc_flow ? old_x + res_x : res_x;
+      gflow[(b * 2 + 1) * HW + pw0 + lane] = acc_flow ? old_y + res_y : res_y;
+    }
+  }
+  if (zsb && nwalk > 0) issue(0);
+  for (int it = 0; zsb && it < nwalk; ++it) {
     const int pp = wave * kWalk + it, p = p0 + pp;
     const Corner c = cn;
     float g[8];
@@ -251,9 +330,9 @@ __global__ __launch_bounds__(256) void fc_tail_bwd_kernel(
       // block_extractor_kernel.cu:160-161 with the convolved map in place of the source plane
       float gx = d0 * (c.yt * (g[1] - g[0]) + c.yb * (g[3] - g[2])) + d1 * (c.yt * (g[5] - g[4]) + c.yb * (g[7] - g[6]));
       float gy = d0 * (c.xl * (g[2] - g[0]) + c.xr * (g[3] - g[1])) + d1 * (c.xl * (g[6] - g[4]) + c.xr * (g[7] - g[5]));
-      gx = wave_sum_f(gx);
-      gy = wave_sum_f(gy);
-      if (lane == 0) {  // this workgroup is the only writer of its pixels
+      gx = wave_sum_lane63(gx);
+      gy = wave_sum_lane63(gy);
+      if (lane == 63) {  // this workgroup is the only writer of its pixels
         float *fxp = gflow + (b * 2 + 0) * HW + p, *fyp = gflow + (b * 2 + 1) * HW + p;
         *fxp = acc_flow ? *fxp + gx : gx;
         *fyp = acc_flow ? *fyp + gy : gy;
@@ -300,7 +379,7 @@ int fc_sample_tail_fwd(const float *gs, const float *gt, const float *flow, cons
 int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, const float *w1, const float *g_logits,
                        float *dzs, float *dzt, float *gflow, float *b0_partials, int64_t B, int H, int W, int k,
                        int64_t gs_bs, int wps, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t,
-                       float slope, int acc_flow, hipStream_t stream) {
+                       float slope, int acc_flow, hipStream_t stream, uint32_t *amax_d) {
   if (!gs || !flow || !hid || !w1 || !g_logits) return GFLA_ERR_NULL_POINTER;
   if (int rc = smp_check(B, H, W, k)) return rc;
   if (B == 0) return GFLA_OK;
@@ -308,10 +387,237 @@ int fc_sample_tail_bwd(const float *gs, const float *flow, const float *hid, con
   const unsigned lds = (unsigned)((kSmpPix * kSmpPitch + kFcHidden * k * k + 4 * kFcHidden) * sizeof(float));
   if (k == 3)
     fc_tail_bwd_kernel<3><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow, amax_d);
   else
     fc_tail_bwd_kernel<5><<<grid, 256, lds, stream>>>(gs, flow, hid, w1, g_logits, dzs, dzt, gflow, b0_partials, H, W,
-                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow);
+                                                       gs_bs, wps, wpz, wpt, zs_bs, zt_bs, lead_s, lead_t, slope, acc_flow, amax_d);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ d Gs without global atomics (round 6)
+// fc_tail_bwd_kernel scatters d hidden into the gradient of the convolved source map with 4 coalesced 128-channel float
+// atomics per position: 46 M lane-atomics at B = 32, 64x44 -- and global float atomics run at 250 G lane-ops/s whatever
+// their scope or contention (profiles/r5_ubench_global_atomics_scope_and_xcc_id.txt): 184 of the kernel's 195 us.  Here the
+// OUTPUT is dealt out instead: a workgroup owns R whole rows of one sample's gradient map (R x Wo cells x 128 channels), finds
+// the positions whose corners land in its rows -- every workgroup of a sample walks all H W positions of the flow field, 512
+// at a time: corner geometry is ~40 instructions per position, and an arbitrary flow needs no special case, only more list
+// entries --, reads their d hidden rows (the target half's gradient map: d hidden IS d Gt, written by fc_tail_bwd_kernel
+// a moment earlier) with the 128 channels on the lanes, and adds the weighted rows into its cells in LDS: 64-bit FIXED POINT
+// (lds_plane.h: ds_add_u64 at 5-8 lanes/clk/CU = 3-5 T lane-ops/s per chip, against 0.25 T for the global float atomics;
+// scale = the power of two that puts max |d hidden| -- fc_tail_bwd_kernel's by-product -- at 2^40; integer sums are exactly
+// associative: the map comes out bit-reproducible run to run, which float atomics never were).  The rows leave through ONE
+// coalesced plain store, zero border of the "Z layout" included: the map needs no memset any more, and the maximum of its
+// entries (the scale of the data-gradient convolution's two-term f16 split) falls out of the flush: no max |x| pass either.
+constexpr int kOwnThreads = 512;
+constexpr int kOwnCap = 1024;    // list entries (32 KB): all of a workgroup's positions in ONE round unless the flow is wild
+constexpr int kOwnPD = 8;        // list entries whose d hidden rows a wave keeps in flight
+constexpr int kOwnPre = 6;       // positions per thread whose flow values are requested up front (maps beyond 6 x 512: on demand)
+struct OwnEntry {
+  int zt;          // pixel index of the position in the target half's gradient map
+  int row_t, row_b;  // word offset / 128 of the corner rows inside the tile (row * Wo), -1: not this workgroup's
+  int gx;          // gx0 | gx1 << 16
+  float xl, xr, yt, yb;
+};
+
+// 64-bit fixed point -> double by the magic-number add run backwards (|x| < 2^51), the plain conversion otherwise
+__device__ __forceinline__ double fix_to_double(lds_fix_t x) {
+  if (__builtin_expect(((unsigned long long)(x + (1ll << 51)) >> 52) != 0ull, 0)) return (double)x;
+  return __longlong_as_double(x + 0x4338000000000000ll) - kFixMagic;
+}
+
+template <int KS>
+__global__ __launch_bounds__(kOwnThreads) void fc_scatter_own_kernel(
+    const float *__restrict__ flow, const float *__restrict__ dzt, float *__restrict__ dzs,
+    const uint32_t *__restrict__ amax_d, uint32_t *__restrict__ amax_out, int H, int W, int Ho, int Wo, int wpz, int wpt,
+    int64_t zs_bs, int64_t zt_bs, int lead_s, int lead_t, int64_t Sz, int R) {
+  constexpr int LO = KS / 2, HI = KS - 1 - LO;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  lds_fix_t *tile = reinterpret_cast<lds_fix_t *>(gfla_smem);                              // [R][Wo][128]
+  OwnEntry *list = reinterpret_cast<OwnEntry *>(tile + (size_t)R * Wo * kFcHidden);         // [kOwnCap]
+  __shared__ int s_count, s_total;
+  __shared__ unsigned s_max;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t b = blockIdx.y;
+  const int r0 = blockIdx.x * R, rows = min(R, Ho - r0);
+  const int HW = H * W;
+  const float *fxp = flow + (b * 2 + 0) * HW, *fyp = flow + (b * 2 + 1) * HW;
+  const float *dzb = dzt + b * zt_bs + lane;
+  // every workgroup of a sample walks the whole flow field: its values are requested once, up front
+  float fxq[kOwnPre], fyq[kOwnPre];
+#pragma unroll
+  for (int i = 0; i < kOwnPre; ++i) {
+    const int p = min(i * kOwnThreads + t, HW - 1);
+    fxq[i] = fxp[p], fyq[i] = fyp[p];
+  }
+  {
+    longlong2 *t2 = reinterpret_cast<longlong2 *>(tile);
+    for (int i = t; i < rows * Wo * (kFcHidden / 2); i += kOwnThreads) t2[i] = longlong2{0, 0};
+  }
+  if (t == 0) s_max = 0, s_total = 0, s_count = 0;
+  const FixScale fs = fix_scale(*amax_d);
+  const int npos = (HW + kOwnThreads - 1) / kOwnThreads;   // positions per thread: p = i * 512 + t
+  // corner geometry of position i * 512 + t: block_extractor_kernel.cu:58-70 for the centre tap on the convolved map's
+  // domain (as corners<KS>() above); false: none of its corners lands in this workgroup's rows
+  auto evaluate = [&](int i, OwnEntry &e) -> bool {
+    const int p = i * kOwnThreads + t;
+    if (p >= HW) return false;
+    float fx = 0.f, fy = 0.f;
+    if (i < kOwnPre) {
+#pragma unroll
+      for (int q = 0; q < kOwnPre; ++q)
+        if (q == i) fx = fxq[q], fy = fyq[q];
+    } else {
+      fx = fxp[p], fy = fyp[p];
+    }
+    const int y = p / W, x = p - y * W;
+    const float dx = fx + (float)x, dy = fy + (float)y;
+    const float fdx = floorf(dx), fdy = floorf(dy);
+    const float cx = fminf(fmaxf(fdx, -(float)(HI + 1)), (float)(W + LO));
+    const float cy = fminf(fmaxf(fdy, -(float)(HI + 1)), (float)(H + LO));
+    const int qx = (int)cx, qy = (int)cy;
+    const int gx0 = clampi(qx, -HI, W - 1 + LO) + HI, gx1 = clampi(qx + 1, -HI, W - 1 + LO) + HI;
+    const int gy0 = clampi(qy, -HI, H - 1 + LO) + HI, gy1 = clampi(qy + 1, -HI, H - 1 + LO) + HI;
+    const bool top = gy0 >= r0 && gy0 < r0 + rows, bot = gy1 >= r0 && gy1 < r0 + rows;
+    e.zt = lead_t + y * wpt + x;
+    e.row_t = top ? (gy0 - r0) * Wo : -1;
+    e.row_b = bot ? (gy1 - r0) * Wo : -1;
+    e.gx = gx0 | (gx1 << 16);
+    e.xr = dx - fdx;
+    e.xl = 1.f - e.xr;
+    e.yb = dy - fdy;
+    e.yt = 1.f - e.yb;
+    return top || bot;
+  };
+  // how many positions reach this workgroup's rows?  A smooth flow: about (R + 1) rows of positions -- one list round;
+  // otherwise rounds of kOwnCap / 512 positions per thread
+  {
+    int mine = 0;
+    for (int i = 0; i < npos; ++i) {
+      OwnEntry e;
+      mine += evaluate(i, e) ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
+    if (lane == 0 && mine) atomicAdd(&s_total, mine);
+  }
+  __syncthreads();   // (the tile is clear, the total is known)
+  const int per_round = s_total <= kOwnCap ? npos : kOwnCap / kOwnThreads;
+  for (int i0 = 0; i0 < npos; i0 += per_round) {
+    for (int i = i0; i < min(npos, i0 + per_round); ++i) {
+      OwnEntry e;
+      const bool in = evaluate(i, e);
+      // list slots: one LDS atomic per wave (returning atomics on ONE address run at half a lane per clock)
+      const unsigned long long mask = __ballot(in);
+      int base = 0;
+      if (lane == 0 && mask) base = atomicAdd(&s_count, __popcll(mask));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (in) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    }
+    __syncthreads();
+    const int n = s_count;
+    for (int e0 = wave; e0 < n; e0 += (kOwnThreads / 64) * kOwnPD) {
+      OwnEntry en[kOwnPD];
+      float d0[kOwnPD], d1[kOwnPD];
+#pragma unroll
+      for (int j = 0; j < kOwnPD; ++j) {
+        en[j] = list[min(e0 + (kOwnThreads / 64) * j, n - 1)];   // (one address per wave: a broadcast read)
+        const float *dp = dzb + (int64_t)__builtin_amdgcn_readfirstlane(en[j].zt) * kFcHidden;
+        d0[j] = dp[0];
+        d1[j] = dp[64];
+      }
+#pragma unroll
+      for (int j = 0; j < kOwnPD; ++j) {
+        if (e0 + (kOwnThreads / 64) * j >= n) break;
+        const int row_t = __builtin_amdgcn_readfirstlane(en[j].row_t), row_b = __builtin_amdgcn_readfirstlane(en[j].row_b);
+        const int gx = __builtin_amdgcn_readfirstlane(en[j].gx);
+        const int gx0 = gx & 0xffff, gx1 = gx >> 16;
+        const float s0 = d0[j] * fs.up, s1 = d1[j] * fs.up;   // (a power of two: the products below round as the float ones)
+        if (row_t >= 0) {
+          const float wl = en[j].xl * en[j].yt, wr = en[j].xr * en[j].yt;
+          lds_fix_t *cl = tile + (size_t)(row_t + gx0) * kFcHidden + lane, *cr = tile + (size_t)(row_t + gx1) * kFcHidden + lane;
+          lds_add_fix(cl, wl * s0), lds_add_fix(cl + 64, wl * s1);
+          lds_add_fix(cr, wr * s0), lds_add_fix(cr + 64, wr * s1);
+        }
+        if (row_b >= 0) {
+          const float wl = en[j].xl * en[j].yb, wr = en[j].xr * en[j].yb;
+          lds_fix_t *cl = tile + (size_t)(row_b + gx0) * kFcHidden + lane, *cr = tile + (size_t)(row_b + gx1) * kFcHidden + lane;
+          lds_add_fix(cl, wl * s0), lds_add_fix(cl + 64, wl * s1);
+          lds_add_fix(cr, wr * s0), lds_add_fix(cr + 64, wr * s1);
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the list
+    if (t == 0) s_count = 0;
+    __syncthreads();
+  }
+  // flush: the workgroup's rows of the Z layout, pitch wpz, columns >= Wo zero, four channels per lane (16-byte stores); the
+  // first / last workgroup of a sample also write the zero pixels ahead of / behind the map
+  float *zb = dzs + b * zs_bs;
+  const float nanv = __uint_as_float(0x7fc00000u);
+  uint32_t mx = 0;
+  float4 *out4 = reinterpret_cast<float4 *>(zb + (int64_t)(lead_s + r0 * wpz) * kFcHidden);
+  for (int i = t; i < rows * wpz * (kFcHidden / 4); i += kOwnThreads) {
+    int cell = i >> 5, r = 0;
+    const int c4 = i & 31;
+    while (cell >= wpz) cell -= wpz, ++r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cell < Wo) {
+      const longlong2 *src = reinterpret_cast<const longlong2 *>(tile + (size_t)(r * Wo + cell) * kFcHidden + c4 * 4);
+      const longlong2 a = src[0], c = src[1];
+      if (fs.finite) {
+        v.x = (float)(fix_to_double(a.x) * fs.down), v.y = (float)(fix_to_double(a.y) * fs.down);
+        v.z = (float)(fix_to_double(c.x) * fs.down), v.w = (float)(fix_to_double(c.y) * fs.down);
+      } else {
+        v = make_float4(nanv, nanv, nanv, nanv);
+      }
+    }
+    out4[i] = v;
+    mx = max(max(mx, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+    mx = max(max(mx, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r0 == 0)
+    for (int64_t i = t; i < (int64_t)lead_s * (kFcHidden / 4); i += kOwnThreads) reinterpret_cast<float4 *>(zb)[i] = z4;
+  if (r0 + rows >= Ho)
+    for (int64_t i = (int64_t)(lead_s + Ho * wpz) * (kFcHidden / 4) + t; i < Sz * (kFcHidden / 4); i += kOwnThreads)
+      reinterpret_cast<float4 *>(zb)[i] = z4;
+  if (amax_out) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+    if (lane == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (t == 0 && s_max > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, s_max);
+  }
+}
+
+// rows of the gradient map one workgroup owns (0: a single row does not fit the LDS -- the caller keeps the atomics)
+int fc_scatter_own_rows(int64_t B, int Ho, int Wo) {
+  const int64_t budget = 160 * 1024 - 512 - (int64_t)kOwnCap * (int64_t)sizeof(OwnEntry);
+  const int64_t row_bytes = (int64_t)Wo * kFcHidden * (int64_t)sizeof(lds_fix_t);
+  int R = (int)std::min<int64_t>(budget / row_bytes, Ho);
+  while (R > 1 && ceil_div(Ho, R) * B < 2 * kNumCU) --R;   // enough workgroups to fill the chip twice
+  return R;
+}
+
+int fc_sample_scatter_own(const float *flow, const float *dzt, float *dzs, const uint32_t *amax_d, uint32_t *amax_out,
+                          int64_t B, int H, int W, int k, int Ho, int Wo, int wpz, int wpt, int64_t zs_bs, int64_t zt_bs,
+                          int lead_s, int lead_t, int64_t Sz, hipStream_t stream) {
+  if (!flow || !dzt || !dzs || !amax_d) return GFLA_ERR_NULL_POINTER;
+  if (int rc = smp_check(B, H, W, k)) return rc;
+  if (B == 0) return GFLA_OK;
+  const int R = fc_scatter_own_rows(B, Ho, Wo);
+  if (R < 1 || Wo > 0x7fff) return GFLA_ERR_UNSUPPORTED;
+  const unsigned lds = (unsigned)((size_t)R * Wo * kFcHidden * sizeof(lds_fix_t) + (size_t)kOwnCap * sizeof(OwnEntry));
+  const dim3 grid((unsigned)ceil_div(Ho, R), (unsigned)B);
+#define GFLA_OWN(K_)                                                                                                         \
+  {                                                                                                                           \
+    auto kern = fc_scatter_own_kernel<K_>;                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    kern<<<grid, kOwnThreads, lds, stream>>>(flow, dzt, dzs, amax_d, amax_out, H, W, Ho, Wo, wpz, wpt, zs_bs, zt_bs, lead_s,  \
+                                             lead_t, Sz, R);                                                                  \
+  }
+  if (k == 3) GFLA_OWN(3) else GFLA_OWN(5)
+#undef GFLA_OWN
   return launch_status();
 }
 

@@ -43,6 +43,9 @@ constexpr int kWn16HeadX = 6, kWn16HeadW = 3;
 // high one.  (The plain C form compiles to five: two converts, a convert back, a subtract and an or.)
 typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t wn16_split(float v) {
+  // (v made opaque: with the multiply that produced it in sight hipcc fuses it into the convert -- v_fma_mixlo_f16 of the
+  // unrounded product -- and `h` is no longer the half the packed convert below stores)
+  asm("" : "+v"(v));
   const _Float16 h = (_Float16)v;
   float rem;
   asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rem) : "v"(v), "v"(h));

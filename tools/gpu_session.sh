@@ -23,7 +23,7 @@ timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/benc
 echo "== rocprof"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.log 2>&1); echo "rocprof rc=$?"
 find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null; find /tmp/prof_$TAG -type f | head -20; cat $OUT/*kernel_stats.csv 2>/dev/null | head -30 | cut -c1-220
-python tools/trace_steps.py /tmp/prof_$TAG/bench_kernel_trace.csv > $OUT/steady_state_steps.txt 2>&1; head -45 $OUT/steady_state_steps.txt
+python tools/trace_steps.py /tmp/prof_$TAG/bench_kernel_trace.csv "fc_tail_fwd_kernel<3>" > $OUT/steady_state_steps.txt 2>&1; head -45 $OUT/steady_state_steps.txt
 echo "== pmc (HBM traffic of the gfla kernels; separate passes, kernel-trace only)"
 for CNT in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/pmc_${TAG}_$CNT -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT rc=$?"

@@ -17,6 +17,9 @@ rs = gfla.Resample2d(4, 1, 2)
 hp.step(rs, allreduce=False)
 
 
+calls = {}
+
+
 def logits():
     outs = []
     for mod, (src, tgt, flow) in zip(hp.attn, hp.inputs):
@@ -37,7 +40,20 @@ def logits():
             _lib.call("gfla_fc_backward_f32", s, _lib.ptr(ws), _lib.ptr(f), _lib.ptr(w1), _lib.ptr(gl), _lib.ptr(sc),
                       _lib.ptr(gs), _lib.ptr(gt), _lib.ptr(gf), _lib.ptr(gw0), None, None, None, B, C, H, W, k, 0.1, 5, 0)
             torch.cuda.synchronize()
-            outs += [lg.clone(), gs.clone(), gt.clone(), gw0.clone()]
+            outs += [lg.clone(), gs.clone(), gt.clone(), gw0.clone(), gf.clone()]
+            st = torch.cuda.current_stream(dev)
+            for name, fn in (("fwd", lambda: _lib.call("gfla_fc_forward_f32", s, _lib.ptr(s), _lib.ptr(t), _lib.ptr(f), _lib.ptr(w0), _lib.ptr(fc[0].bias),
+                                                      _lib.ptr(w1), _lib.ptr(fc[2].bias), _lib.ptr(ws), _lib.ptr(lg), B, C, H, W, k, 0.1, 5)),
+                             ("bwd", lambda: _lib.call("gfla_fc_backward_f32", s, _lib.ptr(ws), _lib.ptr(f), _lib.ptr(w1), _lib.ptr(gl), _lib.ptr(sc),
+                                                      _lib.ptr(gs), _lib.ptr(gt), _lib.ptr(gf), _lib.ptr(gw0), None, None, None, B, C, H, W, k, 0.1, 5, 0))):
+                fn(); fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for _ in range(10):
+                    fn()
+                e1.record(st)
+                torch.cuda.synchronize()
+                calls["%s k%d" % (name, k)] = round(e0.elapsed_time(e1) * 100, 1)
     return outs
 
 
@@ -50,5 +66,5 @@ for v in vals:
     diff = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(o, base)]
     rows = bench.fc_kernel_probes(hp)
     r = {x["kernel"].split(": ")[1][:28] + " k%d" % x["dims"][-1]: x["avg_us"] for x in rows if "one launch" in x["kernel"]}
-    print(json.dumps({"key": key, "value": v, "rel_diff_vs_0": ["%.1e" % d for d in diff], "us": r}), flush=True)
+    print(json.dumps({"key": key, "value": v, "rel_diff_vs_0": ["%.1e" % d for d in diff], "us": r, "call_us": dict(calls)}), flush=True)
 gfla.set_tuning(key, 0)
