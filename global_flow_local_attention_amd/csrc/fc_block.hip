@@ -128,6 +128,9 @@ static int fc_args_ok(int64_t B, int64_t C, int64_t H, int64_t W, int k, int mod
 // f16 kernel's epilogue its largest part) stays on fc_wino.hip: 141 against 166 us at (32,256,32,22).  Tuning key 43 = 1: f16
 // kernels everywhere (tests).
 static bool fc_w16_dgrad(int k) { return k == 5 || tuning(43) == 1; }
+// ... and the weight gradient of the k = 5 layer (both halves in one launch; needs max |dz| of both gradient maps, which the
+// data-gradient convolutions of that layer need anyway)
+static bool fc_w16_wgrad(int mode_, int k) { return mode_ == 5 && k == 5 && tuning(49) != 1; }
 
 // the four Winograd weight sets of one layer (mode 4; mode 5: two-term f16 words, scaled by the slot kAmaxW)
 static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream,
@@ -387,7 +390,14 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
     const WwJob jobs[2] = {
         {Xs, dzs, reinterpret_cast<float *>(sc + L.dwp), L.hs.Sz * kFcHidden, L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
         {Xt, dzt, reinterpret_cast<float *>(sc + L.dwp2), L.ht.Sz * kFcHidden, L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
-    GFLA_TRY(fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream));
+    // mode 5, k = 5: both operands as two-term f16 values on the f16 matrix cores (fc_wino.hip: fc_wino16_wgrad_kernel); the
+    // max |x| slots of the activations are the forward's, those of the gradient maps this call's (tuning key 49 = 1: float32)
+    if (fc_w16_wgrad(mode_, k) && !L.wgrad_f32_wino) {
+      const uint32_t *const ax[2] = {amax + kAmaxSrc, amax + kAmaxTgt}, *const az[2] = {amax + kAmaxZs, amax + kAmaxZt};
+      GFLA_TRY(fc_wino16_wgrad_jobs(jobs, 2, L.cpad, B, k, ax, az, stream));
+    } else {
+      GFLA_TRY(fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream));
+    }
   }
   if (defer) {
     float *part_s = reinterpret_cast<float *>(sc + L.dwp), *part_t = reinterpret_cast<float *>(sc + L.dwp2);
@@ -568,6 +578,10 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
          L.hs.Sz * kFcHidden, L.hs.lead, L.hs.Sx, L.hs.Ho, L.hs.Wo, L.hs.Wp},
         {fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, 0), reinterpret_cast<float *>(sc + L.dzt), reinterpret_cast<float *>(sc + L.dwp2),
          L.ht.Sz * kFcHidden, L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
+    if (fc_w16_wgrad(mode, k)) {
+      const uint32_t *const ax[2] = {amx + kAmaxSrc, amx + kAmaxTgt}, *const az[2] = {amx + kAmaxZs, amx + kAmaxZt};
+      return fc_wino16_wgrad_jobs(jobs, 2, L.cpad, B, k, ax, az, stream);
+    }
     return fc_wino_wgrad_jobs(jobs, 2, L.cpad, B, k, stream);
   }
   if (fc_is_wino(mode)) {

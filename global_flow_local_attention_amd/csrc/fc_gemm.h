@@ -191,6 +191,8 @@ struct WwJob {   // one Winograd-domain weight gradient (fc_wino_wgrad's argumen
   int Ho, Wo, Wp;
 };
 int fc_wino_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, hipStream_t stream);
+int fc_wino16_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, const uint32_t *const *amax_x,
+                         const uint32_t *const *amax_z, hipStream_t stream);
 int fc_wino_wgrad(const PackedDesc &X, const float *Z, int64_t z_bs, int64_t z_lead, float *part, int cpad, int64_t B, int Ho,
                   int Wo, int Wp, int64_t SX, int k, hipStream_t stream);
 int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream);

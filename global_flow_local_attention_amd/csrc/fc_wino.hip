@@ -927,6 +927,338 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino_wgrad_kernel(WwKArgs a0
   }
 }
 
+
+// =====================================================================================================================
+// The k = 5 weight gradient with TWO-TERM f16 OPERANDS (arithmetic mode 5, round 6).
+//
+// fc_wino_wgrad_kernel spends 4 608 of a step's cycles per wave in v_mfma_f32_16x16x4_f32 (36 points x 4 k steps x 32 cycles),
+// and the float32 matrix instructions run at the f32 VECTOR rate: 0.54-0.56 of that pipe is all the kernel ever reached.  Same
+// formulation, units, staging and epilogue here, but both operands of the 36 point-wise products are split into two f16 terms
+// (fc_wino16.hip: hi = RN16(v s), lo = RN16(v s - hi), s a power of two from the tensor's max |x|) and a step's 16 tiles are ONE
+// K = 32 reduction of v_mfma_f32_16x16x32_f16 -- K slots of a lane = its four tiles as (hi, hi, lo, lo | hi, hi, lo, lo) --
+// issued twice per point: against the lifted gradient's words as they are (hi hi + lo lo) and with the words of each pair
+// exchanged, which is a RENAMING of registers (hi lo + lo hi): 72 MFMAs of 16 cycles per step instead of 144 of 32.
+//   A = V[point][tile quad][c][(hi, hi, lo, lo) x 2] from LDS: the transform threads store their two halves of a value as two
+//       16-bit words (a lane = one (tile, channel, half of the points) item as before, but lanes now run over the four tiles of a
+//       quad first: 16-byte records fill up from four lanes);
+//   B = Zh: a lane lifts the dY values of ITS FOUR tiles (tile quad = lane >> 4) of a step, one point row at a time, and splits
+//       PAIRS of tiles: v_cvt_pk_f16_f32 (both hi), two v_fma_mix_f32 (the exact remainders, hi read as f16 from either half),
+//       v_cvt_pk_f16_f32 (both lo) -- two instructions per value, no half swaps;
+//   dY of the NEXT step (16 floats per lane) is requested while this step multiplies.
+// Error: the same as the convolutions' (every product is formed from all four cross terms with f32 accumulation inside the
+// MFMA); the accumulation over the tiles is f32 in both kernels.
+template <int V_>
+struct PgTag6 { static constexpr int value = V_; };
+constexpr int kWw16Pitch = 80;      // LDS bytes per raw pixel: the four tiles of a quad are 2 pixels = 40 words = 8 banks apart
+constexpr int kWn16HeadZ = 4;       // A dY A^T grows a gradient by at most 9
+constexpr int kWw16VBytes = kWnXi * 4 * 16 * 16;   // one V buffer: [point][tile quad][channel][16 bytes]
+
+__device__ __forceinline__ void wn16_split_halves(float v, _Float16 &h, _Float16 &l) {
+  asm("" : "+v"(v));   // (opaque: see wn16_split)
+  h = (_Float16)v;
+  float rem;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rem) : "v"(v), "v"(h));
+  l = (_Float16)rem;
+}
+// (hi0, hi1) and (lo0, lo1) words of two values
+__device__ __forceinline__ void wn16_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo) {
+  asm("" : "+v"(v0));
+  asm("" : "+v"(v1));
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v0, v1}, f16x2w));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(hi));
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{r0, r1}, f16x2w));
+}
+// row `A6` of A (6 x 2) applied to (a, b): the lift of one output-gradient pair to a point
+template <int A6>
+__device__ __forceinline__ float ww_lift2(float a, float b) {
+  if constexpr (A6 == 0) return a;
+  else if constexpr (A6 == 1) return a + b;
+  else if constexpr (A6 == 2) return a - b;
+  else if constexpr (A6 == 3) return fmaf(2.f, b, a);
+  else if constexpr (A6 == 4) return fmaf(-0.5f, b, a);
+  else return b;
+}
+
+template <bool MR>
+__global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad,
+                                                                       int raw_stride, const uint32_t *__restrict__ amax_x0,
+                                                                       const uint32_t *__restrict__ amax_x1,
+                                                                       const uint32_t *__restrict__ amax_z0,
+                                                                       const uint32_t *__restrict__ amax_z1) {
+  constexpr int KS = 5;
+  const bool second = (int)blockIdx.y >= nsplit0;
+#define GFLA_PICK(f) (second ? a1.f : a0.f)
+  PackedDesc X;
+  X.base = GFLA_PICK(X.base), X.split_stride = 0, X.batch_stride = GFLA_PICK(X.batch_stride);
+  X.chunk_stride = GFLA_PICK(X.chunk_stride), X.pix_stride = GFLA_PICK(X.pix_stride);
+  const float *__restrict__ Z = GFLA_PICK(Z);
+  float *__restrict__ part = GFLA_PICK(part);
+  const int64_t z_bs = GFLA_PICK(z_bs), z_lead = GFLA_PICK(z_lead), total_units = GFLA_PICK(total_units), SX = GFLA_PICK(SX);
+  const int Wp = GFLA_PICK(Wp), nsplit = GFLA_PICK(nsplit);
+  WwGeo geo;
+  geo.TH = GFLA_PICK(geo.TH), geo.TW = GFLA_PICK(geo.TW), geo.nseg = GFLA_PICK(geo.nseg);
+  geo.R = GFLA_PICK(geo.R), geo.ups = GFLA_PICK(geo.ups);
+#undef GFLA_PICK
+  const int ex = wn16_scale_exp(second ? *amax_x1 : *amax_x0, kWn16HeadX), ez = wn16_scale_exp(second ? *amax_z1 : *amax_z0, kWn16HeadZ);
+  const float sx = wn16_pow2(ex), sz = wn16_pow2(ez), inv_x = wn16_pow2(254 - ex), inv_z = wn16_pow2(254 - ez);
+  constexpr int M = 2, SEG = Ww<KS>::SEG, L = Ww<KS>::L, PITCH = kWw16Pitch;
+  constexpr int RAW1 = (6 * L * PITCH + 15) & ~15;
+  const int RAW = MR ? raw_stride : RAW1;   // bytes between the two raw buffers
+  constexpr int PF1 = (6 * L * 4 + kWnThreads - 1) / kWnThreads;
+  constexpr int PF = MR ? (PF1 > Ww<KS>::PFM ? PF1 : Ww<KS>::PFM) : PF1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gfla_smem[];
+  unsigned char *vbuf = gfla_smem;                                  // [2][kWw16VBytes]
+  unsigned char *raw = gfla_smem + 2 * kWw16VBytes;                 // [2][rows][L][PITCH] float32, scaled
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xh = wave >> 2;
+  const int cc = blockIdx.x, sp = (int)blockIdx.y - (second ? nsplit0 : 0);
+  const int64_t u0 = total_units * sp / nsplit, u1 = total_units * (sp + 1) / nsplit;
+  const int per_sample = geo.ups;
+  const int Lr = (MR && geo.R > 1) ? M * geo.TW + 6 - M : L;
+  const int raw_rows = (MR && geo.R > 1) ? M * geo.R + 6 - M : 6;
+  const int npieces = raw_rows * Lr * 4;
+  const unsigned inv_ntx = (65536u + (unsigned)geo.TW - 1u) / (unsigned)geo.TW;
+
+  f32x4v acc[kWnXi];
+#pragma unroll
+  for (int q = 0; q < kWnXi; ++q) acc[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto unit_of = [&](int64_t u) {
+    WwUnit un;
+    un.b = u / per_sample;
+    const int r = (int)(u - un.b * per_sample);
+    if (MR && geo.R > 1) {
+      un.ty = r * geo.R;
+      un.tx0 = 0;
+      un.ntx = geo.TW;
+      un.nt = geo.TW * min(geo.R, geo.TH - un.ty);
+    } else {
+      un.ty = r / geo.nseg;
+      un.tx0 = (r - un.ty * geo.nseg) * SEG;
+      un.ntx = min(SEG, geo.TW - un.tx0);
+      un.nt = un.ntx;
+    }
+    return un;
+  };
+  auto tile_rc = [&](int t_, int &tr, int &tcol) {
+    if (MR && geo.R > 1) {
+      tr = (int)(((unsigned)t_ * inv_ntx) >> 16);
+      tcol = t_ - tr * geo.TW;
+    } else {
+      tr = 0;
+      tcol = t_;
+    }
+  };
+
+  // raw rows of a unit, scaled: global -> registers -> LDS
+  u32x4v pf[PF];
+  auto piece_addr = [&](const WwUnit &un, int q, int &ldso) -> const unsigned char * {
+    const int row = q / (4 * Lr), rem = q - row * (4 * Lr), px = rem >> 2, prt = rem & 3;
+    ldso = (row * Lr + px) * PITCH + prt * 16;
+    const int64_t pix = (int64_t)(M * un.ty + row) * Wp + M * un.tx0 + px;
+    return X.base + un.b * X.batch_stride + (int64_t)cc * X.chunk_stride + (pix < SX ? pix : SX - 1) * X.pix_stride + prt * 16;
+  };
+  auto prefetch = [&](const WwUnit &un) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      int ldso;
+      pf[i] = *reinterpret_cast<const u32x4v *>(piece_addr(un, min(t + kWnThreads * i, npieces - 1), ldso));
+    }
+  };
+  auto commit = [&](const WwUnit &un, int buf) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int q = min(t + kWnThreads * i, npieces - 1);
+      int ldso;
+      (void)piece_addr(un, q, ldso);
+      float2 *d = reinterpret_cast<float2 *>(raw + buf * RAW + ldso);
+      d[0] = make_float2(__uint_as_float(pf[i][0]) * sx, __uint_as_float(pf[i][1]) * sx);
+      d[1] = make_float2(__uint_as_float(pf[i][2]) * sx, __uint_as_float(pf[i][3]) * sx);
+    }
+  };
+
+  // transform item: tile 4 * (wave & 3) + (lane & 3) of the step's 16, channel lane >> 2, point rows 3*xh..
+  const int tj = lane & 3, tc = lane >> 2, tkg = wave & 3;
+  const int tl = 4 * tkg + tj;
+  // byte offset of this item's hi half inside a (point, quad, channel) record: (hi0, hi1, lo0, lo1, hi2, hi3, lo2, lo3)
+  const int vpos = (tkg * 16 + tc) * 16 + (tj >> 1) * 8 + (tj & 1) * 2;
+  auto transform = [&](auto half_tag, const WwUnit &un, int h, int rbuf, int vb) {
+    constexpr int HALF = decltype(half_tag)::value;
+    const int tile = min(h * 16 + tl, un.nt - 1);
+    int tr, tcol;
+    tile_rc(tile, tr, tcol);
+    const unsigned char *src = raw + rbuf * RAW + ((M * tr) * Lr + M * tcol) * PITCH + tc * 4;
+    unsigned char *dst = vbuf + vb * kWw16VBytes + vpos;
+    __builtin_amdgcn_s_setprio(3);
+    float tm[3][6];
+#pragma unroll
+    for (int jp = 0; jp < 3; ++jp) {
+      f32x2v d[6], o[3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        d[i] = f32x2v{*reinterpret_cast<const float *>(src + (i * Lr + 2 * jp) * PITCH),
+                      *reinterpret_cast<const float *>(src + (i * Lr + 2 * jp + 1) * PITCH)};
+      wn_bt3<HALF, f32x2v>(d, o);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) tm[r][2 * jp] = o[r][0], tm[r][2 * jp + 1] = o[r][1];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float o[6];
+      wn_bt_pk(tm[r], o);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        _Float16 hh, ll;
+        wn16_split_halves(o[e], hh, ll);
+        unsigned char *rec = dst + ((HALF * 3 + r) * 6 + e) * (4 * 16 * 16);
+        *reinterpret_cast<_Float16 *>(rec) = hh;
+        *reinterpret_cast<_Float16 *>(rec + 4) = ll;
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // multiply: this lane's B operand = Zh of the step's tiles 4 kq .. 4 kq + 3, hidden channel 16 wave + (lane & 15)
+  const int kq = lane >> 4, n = wave * 16 + (lane & 15);
+  float dyn[4][M][M];   // the NEXT step's dY values (raw: masked and scaled where they are used)
+  auto load_dy = [&](const WwUnit &un, int h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tile = h * 16 + 4 * kq + j;
+      int tr, tcol;
+      tile_rc(tile < un.nt ? tile : 0, tr, tcol);
+      const float *zp = Z + un.b * z_bs + (z_lead + (int64_t)(M * (un.ty + tr)) * Wp + M * (un.tx0 + tcol)) * kFcHidden + n;
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) dyn[j][i][jj] = zp[(int64_t)(i * Wp + jj) * kFcHidden];
+    }
+  };
+  auto multiply = [&](const WwUnit &un, int h, int vb, const WwUnit &un_next, int h_next, bool any_next) {
+    float dy[4][M][M];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool live = h * 16 + 4 * kq + j < un.nt;
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = live ? dyn[j][i][jj] * sz : 0.f;
+    }
+    if (any_next) load_dy(un_next, h_next);
+    const u32x4w *va = reinterpret_cast<const u32x4w *>(vbuf + vb * kWw16VBytes) + kq * 16 + (lane & 15);
+    auto row = [&](auto a6_tag) {
+      constexpr int A6 = decltype(a6_tag)::value;
+      float ta[4], tb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ta[j] = ww_lift2<A6>(dy[j][0][0], dy[j][1][0]), tb[j] = ww_lift2<A6>(dy[j][0][1], dy[j][1][1]);
+      auto point = [&](auto e_tag) {
+        constexpr int E = decltype(e_tag)::value;
+        constexpr int q = A6 * 6 + E;
+        const u32x4w a4 = va[q * 64];
+        uint32_t h01, l01, h23, l23;
+        wn16_split_pair(ww_lift2<E>(ta[0], tb[0]), ww_lift2<E>(ta[1], tb[1]), h01, l01);
+        wn16_split_pair(ww_lift2<E>(ta[2], tb[2]), ww_lift2<E>(ta[3], tb[3]), h23, l23);
+        const u32x4w bw = u32x4w{h01, l01, h23, l23}, bx = u32x4w{l01, h01, l23, h23};
+        const f16x8 av = __builtin_bit_cast(f16x8, a4);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, bw), acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, bx), acc[q], 0, 0, 0);
+      };
+      point(PgTag6<0>{}), point(PgTag6<1>{}), point(PgTag6<2>{}), point(PgTag6<3>{}), point(PgTag6<4>{}), point(PgTag6<5>{});
+    };
+    row(PgTag6<0>{}), row(PgTag6<1>{}), row(PgTag6<2>{}), row(PgTag6<3>{}), row(PgTag6<4>{}), row(PgTag6<5>{});
+  };
+
+  if (u0 < u1) {
+    WwUnit cur = unit_of(u0);
+    prefetch(cur);
+    load_dy(cur, 0);
+    commit(cur, 0);
+    __syncthreads();
+    if (xh == 0) transform(Half0{}, cur, 0, 0, 0);
+    else transform(Half1{}, cur, 0, 0, 0);
+    __syncthreads();
+    int vb = 0, rbuf = 0;
+    for (int64_t u = u0; u < u1; ++u) {
+      const int nh = (cur.nt + 15) >> 4;
+      const bool has_next = u + 1 < u1;
+      const WwUnit nxt = has_next ? unit_of(u + 1) : cur;
+      for (int h = 0; h < nh; ++h) {
+        const bool last_h = h + 1 == nh;
+        const bool t_same = !last_h, t_next = last_h && has_next && nh > 1;
+        const bool stage = h == 0 && has_next;
+        // the step whose dY values this step's multiply half requests
+        const bool any_next = !last_h || has_next;
+        const WwUnit &dn = last_h ? nxt : cur;
+        const int hn = last_h ? 0 : h + 1;
+        if (xh == 0) {
+          multiply(cur, h, vb, dn, hn, any_next);
+          __builtin_amdgcn_sched_barrier(0);
+          if (stage) prefetch(nxt);
+          if (t_same) transform(Half0{}, cur, h + 1, rbuf, vb ^ 1);
+          else if (t_next) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if (stage) commit(nxt, rbuf ^ 1);
+        } else {
+          if (stage) prefetch(nxt);
+          if (t_same) transform(Half1{}, cur, h + 1, rbuf, vb ^ 1);
+          else if (t_next) transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if (stage) commit(nxt, rbuf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(cur, h, vb, dn, hn, any_next);
+        }
+        __syncthreads();
+        if (last_h && has_next && nh == 1) {
+          if (xh == 0) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          else transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          __syncthreads();
+        }
+        vb ^= 1;
+      }
+      cur = nxt;
+      rbuf ^= 1;
+    }
+  }
+
+  // epilogue: dW = G^T dU G per (c, n) pair, as in fc_wino_wgrad_kernel, times the two inverse scales
+  constexpr float inv_f[5] = {1.f, -1.f / 3.f, 1.f / 3.f, 1.f / 15.f, -16.f / 15.f};
+  constexpr float pt[5] = {0.f, 1.f, -1.f, 2.f, -0.5f};
+  float G[6][KS];
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    float pw = 1.f;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      G[a][i] = pw * inv_f[a];
+      pw *= pt[a];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KS; ++i) G[5][i] = i == KS - 1 ? 1.f : 0.f;
+  float *o = part + (((int64_t)sp * KS * KS) * cpad + cc * kFcChunk) * kFcHidden + wave * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float tmp[KS][6];
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sum += G[a][i] * acc[a * 6 + e][r];
+        tmp[i][e] = sum;
+      }
+#pragma unroll
+    for (int i = 0; i < KS; ++i)
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) sum += tmp[i][e] * G[e][j];
+        o[((int64_t)(i * KS + j) * cpad + 4 * kq + r) * kFcHidden] = (sum * inv_x) * inv_z;
+      }
+  }
+}
+
 static WwGeo ww_geometry(int Ho, int Wo, int k) {
   const int m = k == 5 ? 2 : 4, seg = k == 5 ? 32 : 16;
   WwGeo g;
@@ -1027,6 +1359,41 @@ int fc_wino_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k,
   if (njobs > 2) return GFLA_ERR_UNSUPPORTED;
   return ww_launch(jobs, njobs, cpad, B, k, stream);
 }
+
+// the k = 5 weight gradients of both halves with two-term f16 operands: fc_wino_wgrad_jobs' contract plus the max |x| slots of
+// every job's activations (amax_x) and gradient map (amax_z)
+int fc_wino16_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int k, const uint32_t *const *amax_x,
+                         const uint32_t *const *amax_z, hipStream_t stream) {
+  if (k != 5 || njobs > 2) return GFLA_ERR_UNSUPPORTED;
+  if (B <= 0 || njobs <= 0) return GFLA_OK;
+  WwKArgs a[2];
+  int ns[2] = {0, 0};
+  bool multirow = false;
+  int raw_stride = 0;
+  for (int j = 0; j < 2; ++j) {
+    const int jj = j < njobs ? j : 0;
+    const WwJob &J = jobs[jj];
+    if (J.X.pix_stride != 64 || !amax_x[jj] || !amax_z[jj]) return GFLA_ERR_UNSUPPORTED;
+    const WwGeo g = ww_geometry(J.Ho, J.Wo, k);
+    const int nsplit = fc_wino_wgrad_splits(B, J.Ho, J.Wo, cpad, k);
+    a[j] = WwKArgs{J.X, J.Z, J.part, J.z_bs, J.z_lead, B * g.ups, J.SX, J.Wp, J.Wo, nsplit, g};
+    if (j < njobs) {
+      ns[j] = nsplit;
+      multirow = multirow || g.R > 1;
+      const int need = g.R > 1 ? (((2 * g.R + 4) * (2 * g.TW + 4) * kWw16Pitch + 15) & ~15) : ((6 * Ww<5>::L * kWw16Pitch + 15) & ~15);
+      if (need > raw_stride) raw_stride = need;
+    }
+  }
+  const unsigned lds = (unsigned)(2 * kWw16VBytes + 2 * raw_stride);
+  if (lds > kWnLdsLimit) return GFLA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)(ns[0] + ns[1]));
+  auto kern = multirow ? fc_wino16_wgrad_kernel<true> : fc_wino16_wgrad_kernel<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, kWnThreads, lds, stream>>>(a[0], a[1], ns[0], cpad, raw_stride, amax_x[0], amax_x[njobs > 1 ? 1 : 0], amax_z[0],
+                                          amax_z[njobs > 1 ? 1 : 0]);
+  return launch_status();
+}
+
 
 // `part` holds nsplit slabs of k*k * cpad * 128 floats (the kernel's epilogue has applied G^T . G): the direct kernel's layout
 int fc_wino_wgrad_reduce(float *part, int nsplit, float *grad_w0, int C, int c_off, int cpad, int k, hipStream_t stream) {

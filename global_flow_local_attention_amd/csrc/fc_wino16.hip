@@ -27,31 +27,6 @@
 
 namespace gfla {
 
-typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
-
-// power-of-two scale of a tensor that gets split into f16 terms, with `headroom` bits left for what the transform adds:
-// B^T d B grows an input by at most 49 (6 bits), G w G^T a weight by at most 4.3 (3 bits)
-__host__ __device__ __forceinline__ int wn16_scale_exp(uint32_t amax_bits, int headroom) {
-  int se = fc_scale_exp(amax_bits) - headroom;
-  return se < 2 ? 2 : se;
-}
-__device__ __forceinline__ float wn16_pow2(int biased) { return __uint_as_float((uint32_t)biased << 23); }
-constexpr int kWn16HeadX = 6, kWn16HeadW = 3;
-
-// (hi, lo) word of a value in three instructions: v_cvt_f16_f32, v_fma_mix_f32 (v * 1 - hi with hi read as f16: the exact
-// remainder, no convert back), v_cvt_pk_f16_f32 of (v, remainder) -- RN16(v) again in the low half, RN16(remainder) in the
-// high one.  (The plain C form compiles to five: two converts, a convert back, a subtract and an or.)
-typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t wn16_split(float v) {
-  // (v made opaque: with the multiply that produced it in sight hipcc fuses it into the convert -- v_fma_mixlo_f16 of the
-  // unrounded product -- and `h` is no longer the half the packed convert below stores)
-  asm("" : "+v"(v));
-  const _Float16 h = (_Float16)v;
-  float rem;
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rem) : "v"(v), "v"(h));
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v, rem}, f16x2w));
-}
-
 // ---- weights: conv0.weight (128, 2C, k, k) -> U = G w G^T * scale as (hi, lo) words in B-fragment order --------------
 // U16[ntile][step = ci >> 3][point][g = (ci >> 2) & 1][n = co & 63][ci & 3]: a lane of channel block nb (n = 32 nb + lane & 31,
 // g = lane >> 5) loads its 16 bytes of a (step, point) with one request; a wave's request is two runs of 512 bytes.
