@@ -981,6 +981,16 @@ __device__ __forceinline__ float ww_lift2(float a, float b) {
   else return b;
 }
 
+template <int A6>
+__device__ __forceinline__ f32x2v ww_lift2v(f32x2v a, f32x2v b) {
+  if constexpr (A6 == 0) return a;
+  else if constexpr (A6 == 1) return a + b;
+  else if constexpr (A6 == 2) return a - b;
+  else if constexpr (A6 == 3) return __builtin_elementwise_fma(f32x2v{2.f, 2.f}, b, a);
+  else if constexpr (A6 == 4) return __builtin_elementwise_fma(f32x2v{-0.5f, -0.5f}, b, a);
+  else return b;
+}
+
 template <bool MR>
 __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad,
                                                                        int raw_stride, const uint32_t *__restrict__ amax_x0,
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
 
   // multiply: this lane's B operand = Zh of the step's tiles 4 kq .. 4 kq + 3, hidden channel 16 wave + (lane & 15)
   const int kq = lane >> 4, n = wave * 16 + (lane & 15);
-  float dyn[4][M][M];   // the NEXT step's dY values (raw: masked and scaled where they are used)
+  float dy[4][M][M];   // raw dY values of the step about to be multiplied (masked and scaled at the top of multiply)
   auto load_dy = [&](const WwUnit &un, int h) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1132,41 +1142,69 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
 #pragma unroll
       for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int jj = 0; jj < M; ++jj) dyn[j][i][jj] = zp[(int64_t)(i * Wp + jj) * kFcHidden];
+        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = zp[(int64_t)(i * Wp + jj) * kFcHidden];
     }
   };
+  typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
   auto multiply = [&](const WwUnit &un, int h, int vb, const WwUnit &un_next, int h_next, bool any_next) {
-    float dy[4][M][M];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool live = h * 16 + 4 * kq + j < un.nt;
 #pragma unroll
       for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = live ? dyn[j][i][jj] * sz : 0.f;
+        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = live ? dy[j][i][jj] * sz : 0.f;
     }
-    if (any_next) load_dy(un_next, h_next);
     const u32x4w *va = reinterpret_cast<const u32x4w *>(vbuf + vb * kWw16VBytes) + kq * 16 + (lane & 15);
+    // A words run two points ahead of their MFMAs (an LDS round trip is longer than a point's eight split instructions)
+    u32x4w a_q[4];
+    a_q[0] = va[0];
+    a_q[1] = va[64];
     auto row = [&](auto a6_tag) {
       constexpr int A6 = decltype(a6_tag)::value;
-      float ta[4], tb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ta[j] = ww_lift2<A6>(dy[j][0][0], dy[j][1][0]), tb[j] = ww_lift2<A6>(dy[j][0][1], dy[j][1][1]);
-      auto point = [&](auto e_tag) {
+      // the row's lift of the four tiles, as PAIRS of tiles (packed f32 adds; a pair is what one split consumes)
+      f32x2v ta01, ta23, tb01, tb23;
+      ta01 = ww_lift2v<A6>(f32x2v{dy[0][0][0], dy[1][0][0]}, f32x2v{dy[0][1][0], dy[1][1][0]});
+      ta23 = ww_lift2v<A6>(f32x2v{dy[2][0][0], dy[3][0][0]}, f32x2v{dy[2][1][0], dy[3][1][0]});
+      tb01 = ww_lift2v<A6>(f32x2v{dy[0][0][1], dy[1][0][1]}, f32x2v{dy[0][1][1], dy[1][1][1]});
+      tb23 = ww_lift2v<A6>(f32x2v{dy[2][0][1], dy[3][0][1]}, f32x2v{dy[2][1][1], dy[3][1][1]});
+      // two points at a time: the second product of a point depends on its first -- the other point's MFMA sits between them
+      auto points = [&](auto e_tag) {
         constexpr int E = decltype(e_tag)::value;
         constexpr int q = A6 * 6 + E;
-        const u32x4w a4 = va[q * 64];
-        uint32_t h01, l01, h23, l23;
-        wn16_split_pair(ww_lift2<E>(ta[0], tb[0]), ww_lift2<E>(ta[1], tb[1]), h01, l01);
-        wn16_split_pair(ww_lift2<E>(ta[2], tb[2]), ww_lift2<E>(ta[3], tb[3]), h23, l23);
-        const u32x4w bw = u32x4w{h01, l01, h23, l23}, bx = u32x4w{l01, h01, l23, h23};
-        const f16x8 av = __builtin_bit_cast(f16x8, a4);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, bw), acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, bx), acc[q], 0, 0, 0);
+        u32x4w bw[2], bx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (q + u + 2 < kWnXi) a_q[(q + u + 2) % 4] = va[(q + u + 2) * 64];
+          f32x2v z01, z23;
+          if (u == 0) z01 = ww_lift2v<E>(ta01, tb01), z23 = ww_lift2v<E>(ta23, tb23);
+          else z01 = ww_lift2v<E + 1>(ta01, tb01), z23 = ww_lift2v<E + 1>(ta23, tb23);
+          uint32_t h01, l01, h23, l23;
+          wn16_split_pair(z01[0], z01[1], h01, l01);
+          wn16_split_pair(z23[0], z23[1], h23, l23);
+          const u32x2w p01 = u32x2w{h01, l01}, p23 = u32x2w{h23, l23};
+          // (lo, hi) of each pair for the cross terms: one v_pk_mov_b32 per pair (the MFMA wants four consecutive registers).
+          // EARLY-CLOBBER outputs + s_nop: hipcc's hazard recognizer does not look inside inline asm.  Allocated in place the
+          // move landed right behind the first MFMA, which was still reading those registers (wrong sums, measured); a vector
+          // write also needs wait states before an MFMA reads the register (NaNs without the s_nop, measured).
+          u32x2w x01, x23;
+          asm("v_pk_mov_b32 %0, %2, %2 op_sel:[1,0]\n\tv_pk_mov_b32 %1, %3, %3 op_sel:[1,0]\n\ts_nop 3"
+              : "=&v"(x01), "=&v"(x23)
+              : "v"(p01), "v"(p23));
+          bw[u] = u32x4w{p01[0], p01[1], p23[0], p23[1]}, bx[u] = u32x4w{x01[0], x01[1], x23[0], x23[1]};
+        }
+        const f16x8 av0 = __builtin_bit_cast(f16x8, a_q[q % 4]), av1 = __builtin_bit_cast(f16x8, a_q[(q + 1) % 4]);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bw[0]), acc[q], 0, 0, 0);
+        acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bw[1]), acc[q + 1], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bx[0]), acc[q], 0, 0, 0);
+        acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bx[1]), acc[q + 1], 0, 0, 0);
       };
-      point(PgTag6<0>{}), point(PgTag6<1>{}), point(PgTag6<2>{}), point(PgTag6<3>{}), point(PgTag6<4>{}), point(PgTag6<5>{});
+      points(PgTag6<0>{}), points(PgTag6<2>{}), points(PgTag6<4>{});
     };
     row(PgTag6<0>{}), row(PgTag6<1>{}), row(PgTag6<2>{}), row(PgTag6<3>{}), row(PgTag6<4>{}), row(PgTag6<5>{});
+    // the NEXT step's dY values: requested now, into the registers this step is done with; they fly through the barrier and
+    // the other half of the next step
+    if (any_next) load_dy(un_next, h_next);
   };
 
   if (u0 < u1) {
