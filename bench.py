@@ -606,7 +606,8 @@ def fc_kernel_probes(hp, iters=10):
                     halves = layer_rows[0:2] if which == 6 else (layer_rows[2:4] if which == 7 else layer_rows[4:6])
                     done = sum(r["alg_GFLOP"] for r in halves) * 1e9
                     eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
-                    kern = "fc_wino_wgrad_kernel" if which == 8 else ("fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel")
+                    kern = ("fc_wino16_wgrad_kernel" if mode == 5 and k == 5 else "fc_wino_wgrad_kernel") if which == 8 else \
+                        ("fc_wino_conv_kernel" if mode == 4 else "fc_wino16_conv_kernel")
                     row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
                                 "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
                                 "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
@@ -631,7 +632,8 @@ def fc_kernel_probes(hp, iters=10):
                     kern = "fc_conv_kernel" if which < 4 else ("fc_wgrad_f32_kernel" if mode in (0, 4) else "fc_wgrad_kernel")
                     row.update({"alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 # mode 5: which convolutions run on the two-term f16 kernel (csrc/fc_block.hip: fc_w16_dgrad)
-                w16 = mode == 5 and (which in (0, 1, 6) or (which in (2, 3, 7) and k == 5))
+                # ... and the weight gradient of the k = 5 layer (both halves in one launch: csrc/fc_block.hip: fc_w16_wgrad)
+                w16 = mode == 5 and (which in (0, 1, 6) or (which in (2, 3, 7) and k == 5) or (which == 8 and k == 5))
                 if mode == 5 and not w16 and kern == "fc_wino16_conv_kernel":
                     kern = "fc_wino_conv_kernel"
                 row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
