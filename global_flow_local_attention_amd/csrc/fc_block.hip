@@ -272,8 +272,17 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
         GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
                                       stream));
     } else if (fc_wgrad_in_wino_domain(mode_, k)) {
-      if (!wgrad_done)   // (fc_backward launches both halves' kernels as one grid)
-        GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+      if (!wgrad_done) {   // (fc_backward launches both halves' kernels as one grid)
+        if (fc_w16_wgrad(mode_, k)) {   // two-term f16 operands (one job: the per-half entry points and one-sided backward calls)
+          uint32_t *a_z16 = amax + (source ? kAmaxZs : kAmaxZt);
+          GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z16, stream));   // (raises a slot that is zero or already holds the maximum)
+          const WwJob job{X, dz, part, g.Sz * kFcHidden, g.lead, g.Sx, g.Ho, g.Wo, g.Wp};
+          const uint32_t *const ax[1] = {amax + (source ? kAmaxSrc : kAmaxTgt)}, *const az[1] = {a_z16};
+          GFLA_TRY(fc_wino16_wgrad_jobs(&job, 1, L.cpad, B, k, ax, az, stream));
+        } else {
+          GFLA_TRY(fc_wino_wgrad(X, dz, g.Sz * kFcHidden, g.lead, part, L.cpad, B, g.Ho, g.Wo, g.Wp, g.Sx, k, stream));
+        }
+      }
       if (reduce_now)
         GFLA_TRY(fc_wino_wgrad_reduce(part, fc_wino_wgrad_splits(B, g.Ho, g.Wo, L.cpad, k), g_w0, C, source ? C : 0, L.cpad, k,
                                       stream));
@@ -392,7 +401,9 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
         {Xt, dzt, reinterpret_cast<float *>(sc + L.dwp2), L.ht.Sz * kFcHidden, L.ht.lead, L.ht.Sx, L.ht.Ho, L.ht.Wo, L.ht.Wp}};
     // mode 5, k = 5: both operands as two-term f16 values on the f16 matrix cores (fc_wino.hip: fc_wino16_wgrad_kernel); the
     // max |x| slots of the activations are the forward's, those of the gradient maps this call's (tuning key 49 = 1: float32)
-    if (fc_w16_wgrad(mode_, k) && !L.wgrad_f32_wino) {
+    // (bf16 features, k = 5: the same kernel on the unpacked activations -- their max |x| slots and those of the gradient maps
+    // were filled for the one-f16-term convolutions)
+    if (fc_w16_wgrad(mode_, k) || (L.wgrad_f32_wino && k == 5 && tuning(49) != 1)) {
       const uint32_t *const ax[2] = {amax + kAmaxSrc, amax + kAmaxTgt}, *const az[2] = {amax + kAmaxZs, amax + kAmaxZt};
       GFLA_TRY(fc_wino16_wgrad_jobs(jobs, 2, L.cpad, B, k, ax, az, stream));
     } else {

@@ -342,3 +342,104 @@ def test_leaky_relu_at_exactly_zero_takes_the_negative_slope(lib, gfla, oracle, 
                              [a.grad.cpu() for a in args] + [p.grad.cpu() for p in m.parameters()],
                              [a.grad for a in cargs] + [p.grad for p in ref.parameters()]):
             assert_close(g, w_, 1e-4, "%s mode %d grad %s with a unit exactly on the kink" % (impl, mode, n_))
+
+
+# ------------------------------------------------------------------------------- round 6: owner-computes scatter, f16 weight gradient
+def _fc_backward_raw(lib, mode, s, t, f, w0, b0, w1, b1, up, k, slope=0.1):
+    """gfla_fc_forward_f32 + gfla_fc_backward_f32 through the C ABI: every gradient the layer returns."""
+    from global_flow_local_attention_amd import fc_mfma
+    B, C, H, W = s.shape
+    ws = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 0), dtype=torch.uint8, device=DEV)
+    sc = torch.empty(fc_mfma.workspace_bytes(B, C, H, W, k, mode, 1), dtype=torch.uint8, device=DEV)
+    lg = torch.full((B, k * k, H, W), float("nan"), device=DEV)
+    w1r = w1.reshape(k * k, 128).contiguous()
+    lib.call("gfla_fc_forward_f32", s, _ptr(s), _ptr(t), _ptr(f), _ptr(w0), _ptr(b0), _ptr(w1r), _ptr(b1), _ptr(ws), _ptr(lg),
+             B, C, H, W, k, slope, mode)
+    gs, gt, gf = (torch.full_like(x, float("nan")) for x in (s, t, f))
+    gw0, gb0, gw1, gb1 = (torch.full_like(x, float("nan")) for x in (w0, b0, w1r, b1))
+    lib.call("gfla_fc_backward_f32", s, _ptr(ws), _ptr(f), _ptr(w1r), _ptr(up), _ptr(sc), _ptr(gs), _ptr(gt), _ptr(gf), _ptr(gw0),
+             _ptr(gb0), _ptr(gw1), _ptr(gb1), B, C, H, W, k, slope, mode, 0)
+    torch.cuda.synchronize()
+    return lg, gs, gt, gf, gw0, gb0, gw1, gb1
+
+
+def _collapse_flow(B, H, W):
+    """Every position of a sample lands in ONE corner of the map (a gradient row that collects H W contributions: the list of
+    fc_scatter_own_kernel needs several rounds, the fixed-point cells see their largest sums)."""
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    f = torch.stack((0.37 - xs, 0.21 - ys))[None].repeat(B, 1, 1, 1)
+    f[1:] = f[1:] + 100.0   # the other samples: far outside, every tap clamps onto the last row / column
+    return f.contiguous()
+
+
+@pytest.mark.parametrize("mode", (5, 4, 0))
+@pytest.mark.parametrize("k,C,H,W,kind", [(5, 16, 40, 28, "collapse"), (3, 16, 40, 28, "collapse"), (5, 8, 30, 22, "wild"),
+                                          (3, 24, 33, 17, "smooth"), (5, 16, 64, 44, "coherent")])
+def test_owner_computes_scatter_equals_the_atomics(lib, gfla, mode, k, C, H, W, kind):
+    """fc_scatter_own_kernel (rows of the convolved source map's gradient owned by one workgroup, 64-bit fixed-point LDS cells)
+    against round 2's global float atomics (tuning key 46 = 1) through the whole backward: the same gradients to float rounding
+    of the SUMS (the atomics add in arrival order), incl. a flow that sends every position of a sample into one corner (> 1 024
+    list entries for one workgroup: several list rounds) and far out-of-range flows; and bit-identical from run to run."""
+    B = 3
+    s, t = randn((B, C, H, W), seed=61).to(DEV), randn((B, C, H, W), seed=62).to(DEV)
+    f = (_collapse_flow(B, H, W) if kind == "collapse" else make_flow(kind, B, H, W, seed=63)).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=64) / (2 * C * k * k) ** 0.5).to(DEV)
+    b0, b1 = (randn((128,), seed=65) * 0.1).to(DEV), (randn((k * k,), seed=67) * 0.1).to(DEV)
+    w1 = (randn((k * k, 128, 1, 1), seed=66) / 128 ** 0.5).to(DEV)
+    up = randn((B, k * k, H, W), seed=68).to(DEV)
+    names = ("logits", "source", "target", "flow", "w0", "b0", "w1", "b1")
+    own = _fc_backward_raw(lib, mode, s, t, f, w0, b0, w1, b1, up, k)
+    again = _fc_backward_raw(lib, mode, s, t, f, w0, b0, w1, b1, up, k)
+    old = gfla.set_tuning(46, 1)
+    try:
+        atom = _fc_backward_raw(lib, mode, s, t, f, w0, b0, w1, b1, up, k)
+    finally:
+        gfla.set_tuning(46, old)
+    for n_, a, b_, c_ in zip(names, own, atom, again):
+        assert torch.isfinite(a).all(), n_
+        e = rel_err(a.cpu(), b_.cpu())
+        assert e <= 2e-6, "%s: owner-computes vs atomics %.2e" % (n_, e)
+        if n_ in ("source", "target", "flow", "b0", "w1", "b1", "logits"):   # (w0: the weight gradient's split sums are fixed order too)
+            assert torch.equal(a, c_), "%s differs from run to run" % n_
+    assert torch.equal(own[4], again[4]), "w0 differs from run to run"
+
+
+def test_owner_computes_scatter_non_finite_gradient(lib, gfla):
+    """An inf in the upstream gradient: the fixed-point cells cannot hold it -- the owned rows come out NaN (the reference's float
+    atomics would poison only the cells the value reaches); nothing hangs, the other sample stays finite."""
+    B, C, H, W, k = 2, 8, 12, 10, 5
+    s, t = randn((B, C, H, W), seed=71).to(DEV), randn((B, C, H, W), seed=72).to(DEV)
+    f = make_flow("smooth", B, H, W, seed=73).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=74) / (2 * C * k * k) ** 0.5).to(DEV)
+    b0, b1 = (randn((128,), seed=75) * 0.1).to(DEV), (randn((k * k,), seed=77) * 0.1).to(DEV)
+    w1 = (randn((k * k, 128, 1, 1), seed=76) / 128 ** 0.5).to(DEV)
+    up = randn((B, k * k, H, W), seed=78).to(DEV)
+    up[0, 3, 5, 4] = float("inf")
+    out = _fc_backward_raw(lib, 4, s, t, f, w0, b0, w1, b1, up, k)
+    assert not torch.isfinite(out[1][0]).all()        # the poisoned sample's source gradient
+    assert torch.isfinite(out[0]).all()               # the forward is untouched
+
+
+@pytest.mark.parametrize("C,H,W", [(16, 64, 44), (24, 20, 26), (8, 9, 14), (16, 40, 66), (128, 64, 44)])
+def test_two_term_f16_weight_gradient_equals_float32(lib, gfla, C, H, W):
+    """fc_wino16_wgrad_kernel (mode 5, k = 5: both operands of the Winograd-domain products as two f16 terms on
+    v_mfma_f32_16x16x32_f16) against the float32 kernel it replaces (tuning key 49 = 1) through the whole backward, one-row and
+    multi-row units, and against float64 where the host can afford it (test_fc_function_against_float64 runs in mode 5 too)."""
+    B, k = 2, 5
+    s, t = randn((B, C, H, W), seed=81).to(DEV), randn((B, C, H, W), seed=82).to(DEV)
+    f = make_flow("smooth", B, H, W, seed=83).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=84) / (2 * C * k * k) ** 0.5).to(DEV)
+    b0, b1 = (randn((128,), seed=85) * 0.1).to(DEV), (randn((k * k,), seed=87) * 0.1).to(DEV)
+    w1 = (randn((k * k, 128, 1, 1), seed=86) / 128 ** 0.5).to(DEV)
+    up = randn((B, k * k, H, W), seed=88).to(DEV)
+    f16 = _fc_backward_raw(lib, 5, s, t, f, w0, b0, w1, b1, up, k)
+    old = gfla.set_tuning(49, 1)
+    try:
+        f32 = _fc_backward_raw(lib, 5, s, t, f, w0, b0, w1, b1, up, k)
+    finally:
+        gfla.set_tuning(49, old)
+    e = rel_err(f16[4].cpu(), f32[4].cpu())
+    print("C %d %dx%d: f16 vs f32 weight gradient %.2e" % (C, H, W, e))
+    assert torch.isfinite(f16[4]).all() and e <= 1e-5, e
+    for a, b_ in zip(f16[:4] + f16[5:], f32[:4] + f32[5:]):
+        assert torch.equal(a, b_)   # nothing else changes
