@@ -991,7 +991,9 @@ __device__ __forceinline__ f32x2v ww_lift2v(f32x2v a, f32x2v b) {
   else return b;
 }
 
-template <bool MR>
+// DBG (timing ablations, `make PROBES=1` builds only, tuning key 20 = 64 + bits; results are garbage): 1 no input transform,
+// 2 no MFMAs / A reads, 4 no lift / split of dY (constant B words), 8 no dY loads
+template <bool MR, int DBG = 0>
 __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs a0, WwKArgs a1, int nsplit0, int cpad,
                                                                        int raw_stride, const uint32_t *__restrict__ amax_x0,
                                                                        const uint32_t *__restrict__ amax_x1,
@@ -1142,7 +1144,7 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
 #pragma unroll
       for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = zp[(int64_t)(i * Wp + jj) * kFcHidden];
+        for (int jj = 0; jj < M; ++jj) dy[j][i][jj] = (DBG & 8) ? 1.f : zp[(int64_t)(i * Wp + jj) * kFcHidden];
     }
   };
   typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
@@ -1175,13 +1177,17 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
         u32x4w bw[2], bx[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          if (q + u + 2 < kWnXi) a_q[(q + u + 2) % 4] = va[(q + u + 2) * 64];
+          if (q + u + 2 < kWnXi && !(DBG & 2)) a_q[(q + u + 2) % 4] = va[(q + u + 2) * 64];
           f32x2v z01, z23;
           if (u == 0) z01 = ww_lift2v<E>(ta01, tb01), z23 = ww_lift2v<E>(ta23, tb23);
           else z01 = ww_lift2v<E + 1>(ta01, tb01), z23 = ww_lift2v<E + 1>(ta23, tb23);
           uint32_t h01, l01, h23, l23;
-          wn16_split_pair(z01[0], z01[1], h01, l01);
-          wn16_split_pair(z23[0], z23[1], h23, l23);
+          if constexpr (DBG & 4) {
+            h01 = __float_as_uint(dy[0][0][0]), l01 = __float_as_uint(dy[1][0][0]), h23 = __float_as_uint(dy[2][0][0]), l23 = __float_as_uint(dy[3][0][0]);
+          } else {
+            wn16_split_pair(z01[0], z01[1], h01, l01);
+            wn16_split_pair(z23[0], z23[1], h23, l23);
+          }
           const u32x2w p01 = u32x2w{h01, l01}, p23 = u32x2w{h23, l23};
           // (lo, hi) of each pair for the cross terms: one v_pk_mov_b32 per pair (the MFMA wants four consecutive registers).
           // EARLY-CLOBBER outputs + s_nop: hipcc's hazard recognizer does not look inside inline asm.  Allocated in place the
@@ -1194,10 +1200,14 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
           bw[u] = u32x4w{p01[0], p01[1], p23[0], p23[1]}, bx[u] = u32x4w{x01[0], x01[1], x23[0], x23[1]};
         }
         const f16x8 av0 = __builtin_bit_cast(f16x8, a_q[q % 4]), av1 = __builtin_bit_cast(f16x8, a_q[(q + 1) % 4]);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bw[0]), acc[q], 0, 0, 0);
-        acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bw[1]), acc[q + 1], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bx[0]), acc[q], 0, 0, 0);
-        acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bx[1]), acc[q + 1], 0, 0, 0);
+        if constexpr (DBG & 2) {
+          acc[q][0] += __uint_as_float(bw[0][0] ^ bx[0][1]), acc[q + 1][0] += __uint_as_float(bw[1][2] ^ bx[1][3]);
+        } else {
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bw[0]), acc[q], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bw[1]), acc[q + 1], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8, bx[0]), acc[q], 0, 0, 0);
+          acc[q + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8, bx[1]), acc[q + 1], 0, 0, 0);
+        }
       };
       points(PgTag6<0>{}), points(PgTag6<2>{}), points(PgTag6<4>{});
     };
@@ -1233,13 +1243,17 @@ __global__ __launch_bounds__(kWnThreads, 2) void fc_wino16_wgrad_kernel(WwKArgs 
           multiply(cur, h, vb, dn, hn, any_next);
           __builtin_amdgcn_sched_barrier(0);
           if (stage) prefetch(nxt);
-          if (t_same) transform(Half0{}, cur, h + 1, rbuf, vb ^ 1);
-          else if (t_next) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if constexpr (!(DBG & 1)) {
+            if (t_same) transform(Half0{}, cur, h + 1, rbuf, vb ^ 1);
+            else if (t_next) transform(Half0{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          }
           if (stage) commit(nxt, rbuf ^ 1);
         } else {
           if (stage) prefetch(nxt);
-          if (t_same) transform(Half1{}, cur, h + 1, rbuf, vb ^ 1);
-          else if (t_next) transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          if constexpr (!(DBG & 1)) {
+            if (t_same) transform(Half1{}, cur, h + 1, rbuf, vb ^ 1);
+            else if (t_next) transform(Half1{}, nxt, 0, rbuf ^ 1, vb ^ 1);
+          }
           if (stage) commit(nxt, rbuf ^ 1);
           __builtin_amdgcn_sched_barrier(0);
           multiply(cur, h, vb, dn, hn, any_next);
@@ -1426,6 +1440,19 @@ int fc_wino16_wgrad_jobs(const WwJob *jobs, int njobs, int cpad, int64_t B, int 
   if (lds > kWnLdsLimit) return GFLA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(cpad / kFcChunk), (unsigned)(ns[0] + ns[1]));
   auto kern = multirow ? fc_wino16_wgrad_kernel<true> : fc_wino16_wgrad_kernel<false>;
+#ifdef GFLA_PROBES
+  switch (tuning(20) >= 64 ? tuning(20) - 64 : 0) {
+    case 1: kern = fc_wino16_wgrad_kernel<true, 1>; break;
+    case 2: kern = fc_wino16_wgrad_kernel<true, 2>; break;
+    case 3: kern = fc_wino16_wgrad_kernel<true, 3>; break;
+    case 4: kern = fc_wino16_wgrad_kernel<true, 4>; break;
+    case 6: kern = fc_wino16_wgrad_kernel<true, 6>; break;
+    case 7: kern = fc_wino16_wgrad_kernel<true, 7>; break;
+    case 8: kern = fc_wino16_wgrad_kernel<true, 8>; break;
+    case 15: kern = fc_wino16_wgrad_kernel<true, 15>; break;
+    default: break;
+  }
+#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<grid, kWnThreads, lds, stream>>>(a[0], a[1], ns[0], cpad, raw_stride, amax_x[0], amax_x[njobs > 1 ? 1 : 0], amax_z[0],
                                           amax_z[njobs > 1 ? 1 : 0]);
