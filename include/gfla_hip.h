@@ -57,7 +57,7 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   7: round 5 (path ids 13-17, tuning keys 30-41: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
  *      gfla_xcd_swizzle)
  *   8: round 6 (arithmetic mode 5 of gfla_fc_*: Winograd domain with two-term f16 operands on the f16 matrix cores,
- *      csrc/fc_wino16.hip; path ids 18 / 19) */
+ *      csrc/fc_wino16.hip; path ids 18 / 19; tuning keys 43, 46, 49) */
 #define GFLA_ABI_VERSION 8
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
@@ -95,6 +95,10 @@ const char *gfla_status_string(int status);
  *   key 40: channels per pixel chunk of block_extractor's forward tiles (0 auto)
  *   key 41: 1 = block_extractor's backward tiles without the cross-lane fold of the patch rows (csrc/be_tile.h: BeLinks)
  *   key 43: arithmetic mode 5: 1 = the two-term f16 kernel also for the k = 3 data gradient (default: float32 Winograd kernel there)
+ *   key 46: 1 = gfla_fc_backward_f32 scatters the gradient of the convolved source map with global float atomics (round 2)
+ *           instead of the owner-computes kernel of round 6 (csrc/fc_sample.hip: fc_scatter_own_kernel)
+ *   key 49: arithmetic mode 5: 1 = the k = 5 weight gradient on the float32 Winograd kernel (rounds 3-5) instead of the
+ *           two-term f16 kernel (csrc/fc_wino.hip: fc_wino16_wgrad_kernel)
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
