@@ -1265,7 +1265,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                             **({"pipe": "f16 matrix cores, two f16 terms per operand: executed f16 MACs = 4 x the Winograd-domain "
                                         "multiplies; the kernel is bound by its LDS / vector work (transforms, f16 split), not by "
                                         "the matrix cores (DESIGN.md 4)",
-                                "f32_equivalent_TFLOPs": dom["TFLOPs"]} if f16pipe else {}),
+                                "f32_equivalent_TFLOPs": dom["TFLOPs"],
+                                # round 5's yardstick for this kernel (executed Winograd-domain flops / time / f32 MFMA peak:
+                                # 0.58 on the f32 pipe then): NOT a pipe fraction in this mode, the same work per second
+                                "f32_equivalent_frac_of_f32_peak": round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)} if f16pipe else {}),
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
                             **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
                             **({"useful_frac": round((4.0 if f16pipe else 1.0) * dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12
@@ -1348,7 +1351,7 @@ def compact_line(line, detail_file):
         out["roofline"] = {k: rf[k] for k in ("bound", "kernel", "dims", "achieved", "peak", "unit", "frac", "useful_frac",
                                               "avg_us", "traffic") if k in rf}
         out["roofline"]["kernel"] = cut(rf["kernel"], 110)
-        for k in ("alg_GFLOP_per_launch", "alg_MB_per_launch"):
+        for k in ("alg_GFLOP_per_launch", "alg_MB_per_launch", "f32_equivalent_TFLOPs", "f32_equivalent_frac_of_f32_peak"):
             if k in rf:
                 out["roofline"][k] = rf[k]
         if rf.get("traffic") and "alg_MB_read_write_per_launch" in rf:
