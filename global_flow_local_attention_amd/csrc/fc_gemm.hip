@@ -117,6 +117,11 @@ __global__ __launch_bounds__(256) void fc_maxabs_kernel(MaxAbsJobs jobs) {
     m = max(max(m, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
   };
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n4; i += 8 * stride) {   // eight requests in flight
+    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    const float4 v4 = x4[i + 4 * stride], v5 = x4[i + 5 * stride], v6 = x4[i + 6 * stride], v7 = x4[i + 7 * stride];
+    fold4(v0), fold4(v1), fold4(v2), fold4(v3), fold4(v4), fold4(v5), fold4(v6), fold4(v7);
+  }
   for (; i + 3 * stride < n4; i += 4 * stride) {
     const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
     fold4(v0), fold4(v1), fold4(v2), fold4(v3);
@@ -152,7 +157,10 @@ int fc_maxabs_multi(const float *x0, int64_t n0, uint32_t *slot0, const float *x
   if (nj == 0) return GFLA_OK;
   for (int i = nj; i < 3; ++i) jobs.j[i] = jobs.j[0];
   int64_t blocks = ceil_div(most, 256 * 16);
-  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  // about one workgroup per CU over all jobs: every workgroup ends in an atomic on its job's slot, and with four workgroups per
+  // CU and job (rounds 2-5) those were most of the kernel -- 40 -> 16 us per launch at the bench shapes (round 6)
+  const int64_t cap = std::max<int64_t>(64, kNumCU / nj);
+  if (blocks > cap) blocks = cap;
   fc_maxabs_kernel<<<dim3((unsigned)blocks, (unsigned)nj), 256, 0, stream>>>(jobs);
   return launch_status();
 }
