@@ -44,11 +44,13 @@ static FcLayout fc_layout(int64_t B, int C, int H, int W, int k, int mode_) {
   L.xt = take(fc_packed_bytes(B, L.nch_c, L.ht.Sx, mode));
   L.gs = take(B * L.hs.Mg * kFcHidden * 4);
   L.hid = take(B * (int64_t)H * W * kFcHidden * 4);
-  L.wd_t = take(wino ? 0 : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
-  L.wd_s = take(wino ? 0 : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  // mode 5 runs its data-gradient convolutions (and the k = 5 forward ones) on the direct f16x2 kernels: mode 2's weight packs
+  const bool hyb = mode_ == 5;
+  L.wd_t = take(wino ? (hyb ? fc_wpack_bytes(L.nt_d, nch_h, k, 2) : 0) : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
+  L.wd_s = take(wino ? (hyb ? fc_wpack_bytes(L.nt_d, nch_h, k, 2) : 0) : fc_wpack_bytes(L.nt_d, nch_h, k, mode));
   L.gt = take(B * L.ht.Mg * kFcHidden * 4);
-  L.wf_t = take(wino ? 0 : fc_wpack_bytes(1, L.nch_c, k, mode));
-  L.wf_s = take(wino ? 0 : fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.wf_t = take(wino ? (hyb ? fc_wpack_bytes(1, L.nch_c, k, 2) : 0) : fc_wpack_bytes(1, L.nch_c, k, mode));
+  L.wf_s = take(wino ? (hyb ? fc_wpack_bytes(1, L.nch_c, k, 2) : 0) : fc_wpack_bytes(1, L.nch_c, k, mode));
   // Winograd mode: U = G w G^T of the forward (C -> 128) and data-gradient (128 -> C) convolutions of both halves
   L.wu_ft = take(wino ? fc_wino_wpack_bytes(C, kFcHidden) : 0);
   L.wu_fs = take(wino ? fc_wino_wpack_bytes(C, kFcHidden) : 0);
@@ -132,16 +134,33 @@ static bool fc_w16_dgrad(int k) { return k == 5 || tuning(43) == 1; }
 // data-gradient convolutions of that layer need anyway)
 static bool fc_w16_wgrad(int mode_, int k) { return mode_ == 5 && k == 5 && tuning(49) != 1; }
 
-// the four Winograd weight sets of one layer (mode 4; mode 5: two-term f16 words, scaled by the slot kAmaxW)
+// Mode 5, later in round 6: WHICH convolution runs on which kernel.  Measured per launch at B = 32 (tools/probe_modes.py): the
+// DIRECT kernels with two f16 terms per operand and three cross products (mode 2's arithmetic, fc_conv_impl.h) beat the
+// Winograd-domain f16 kernel on the k = 5 layer -- forward 216 + 189 against 437 us, data gradient 236 + 211 against 527 -- and
+// the float32 Winograd kernel on the k = 3 data gradient (58 + 56 against 142); the k = 3 forward stays in the Winograd domain
+// (114 against 65 + 65).  Round 6's first half had found the same and gained nothing, because mode 2 wanted its own packed f16
+// copies of the activations and of the gradient maps (a pack pass each, and the weight gradients want float32 anyway); the
+// SRC32 form of the direct kernel reads the float32 maps every other kernel of the mode uses and splits while it stages.
+// The weight gradients stay in the Winograd domain (k = 5: two-term f16, k = 3: float32): direct 418 + 359 / 113 + 95 us.
+// Tuning key 52 = 1: Winograd-domain convolutions everywhere (the first half of round 6).
+static bool fc_hyb(int mode_) { return mode_ == 5 && tuning(52) != 1; }
+static bool fc_hyb_fwd(int mode_, int k) { return fc_hyb(mode_) && k == 5; }
+static bool fc_hyb_fits(const FcLayout &L, int k) {
+  return fc_conv_fits(L.hs.Wo, L.hs.Wp, k, 2) && fc_conv_fits(L.hs.Wp, L.hs.Wp, k, 2) && fc_conv_fits(L.ht.Wo, L.ht.Wp, k, 2) &&
+         fc_conv_fits(L.ht.Wp, L.ht.Wp, k, 2);
+}
+
+// the four Winograd weight sets of one layer (mode 4; mode 5: two-term f16 words, scaled by the slot kAmaxW; fwd_only: the
+// data-gradient sets are not wanted)
 static int fc_wino_pack_all(const FcLayout &L, const float *w0, unsigned char *ws, int C, int k, hipStream_t stream,
-                            bool w16 = false) {
+                            bool w16 = false, bool fwd_only = false) {
   float *u_ft = reinterpret_cast<float *>(ws + L.wu_ft), *u_fs = reinterpret_cast<float *>(ws + L.wu_fs);
   float *u_dt = reinterpret_cast<float *>(ws + L.wu_dt), *u_ds = reinterpret_cast<float *>(ws + L.wu_ds);
   if (w16) {
-    const bool d16 = fc_w16_dgrad(k);
+    const bool d16 = fc_w16_dgrad(k) && !fwd_only;
     GFLA_TRY(fc_wino16_pack_weights(w0, reinterpret_cast<const uint32_t *>(ws + L.amax) + kAmaxW, u_ft, u_fs, d16 ? u_dt : nullptr,
                                     d16 ? u_ds : nullptr, C, k, stream));
-    return d16 ? GFLA_OK : fc_wino_pack_weights(w0, nullptr, nullptr, u_dt, u_ds, C, k, stream);
+    return (d16 || fwd_only) ? GFLA_OK : fc_wino_pack_weights(w0, nullptr, nullptr, u_dt, u_ds, C, k, stream);
   }
   return fc_wino_pack_weights(w0, reinterpret_cast<float *>(ws + L.wu_ft), reinterpret_cast<float *>(ws + L.wu_fs),
                               reinterpret_cast<float *>(ws + L.wu_dt), reinterpret_cast<float *>(ws + L.wu_ds), C, k, stream);
@@ -178,12 +197,22 @@ static int fc_forward(const float *source, const float *target, const float *flo
     GFLA_TRY(fc_maxabs_multi(source, B * (int64_t)C * H * W, amax + kAmaxSrc, target, B * (int64_t)C * H * W, amax + kAmaxTgt,
                              w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
   }
-  if (wino) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16));
+  const bool hyb = fc_hyb(mode_) && fc_hyb_fits(L, k), hyb_f = hyb && fc_hyb_fwd(mode_, k);
+  if (hyb)   // mode 2's packs of the sets the direct kernels take (scaled by the slot kAmaxW)
+    GFLA_TRY(fc_pack_weights(w0, amax + kAmaxW, hyb_f ? ws + L.wf_t : nullptr, hyb_f ? ws + L.wf_s : nullptr, ws + L.wd_t, ws + L.wd_s,
+                             C, k, 2, stream));
+  if (wino && !hyb_f) GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16, hyb));
   GFLA_TRY(fc_pack_act2(source, a_src, ws + L.xs, L.hs, target, a_tgt, ws + L.xt, L.ht, B, C, H, W, mode, stream));
   float *gs = reinterpret_cast<float *>(ws + L.gs), *gt = reinterpret_cast<float *>(ws + L.gt);
   const PackedDesc xs = fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, mode);
   const PackedDesc xt = fc_desc_packed(ws + L.xt, B, L.nch_c, L.ht.Sx, mode);
-  if (wino) {
+  if (hyb_f) {
+    const int64_t wsplit_f = fc_wpack_bytes(1, L.nch_c, k, 2) / 2;
+    GFLA_TRY(fc_conv_f32src(xs, ws + L.wf_s, wsplit_f, gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.hs.Mv,
+                            L.hs.Wo, L.hs.Wp, k, amax + kAmaxSrc, amax + kAmaxW, stream));
+    GFLA_TRY(fc_conv_f32src(xt, ws + L.wf_t, wsplit_f, gt, L.ht.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, L.ht.Mv,
+                            L.ht.Wo, L.ht.Wp, k, amax + kAmaxTgt, amax + kAmaxW, stream));
+  } else if (wino) {
     const WnConvJob jobs[2] = {   // both halves in one launch (fc_wino.hip: they share the half-empty last round)
         {xs, reinterpret_cast<const float *>(ws + L.wu_fs), gs, L.hs.Mg * kFcHidden, kFcHidden, kFcHidden, L.hs.Mv, L.hs.Wo,
          L.hs.Wp, L.hs.Sx},
@@ -242,7 +271,14 @@ static int fc_half_backward(const FcLayout &L, const FcHalf &g, bool source, uns
   }
   if (g_x) {
     float *dx = reinterpret_cast<float *>(sc + (source ? L.dxs : L.dxt));
-    if (wino) {
+    if (wino && fc_hyb(mode_) && fc_hyb_fits(L, k)) {
+      if (!dgrad_done) {   // the direct f16x2 kernel on the float32 gradient map (see fc_hyb)
+        uint32_t *a_z16 = amax + (source ? kAmaxZs : kAmaxZt);
+        GFLA_TRY(fc_maxabs(dz, B * g.Sz * kFcHidden, a_z16, stream));   // (raises a slot that is zero or already holds the maximum)
+        GFLA_TRY(fc_conv_f32src(Z, ws + (source ? L.wd_s : L.wd_t), fc_wpack_bytes(L.nt_d, nch_h, k, 2) / 2, dx, g.Mdg * (int64_t)C, C,
+                                C, B, nch_h, g.Md, g.Wp, g.Wp, k, a_z16, amax + kAmaxW, stream));
+      }
+    } else if (wino) {
       if (!dgrad_done) {
         const WnConvJob job{Z, reinterpret_cast<const float *>(ws + (source ? L.wu_ds : L.wu_dt)), dx, g.Mdg * (int64_t)C, C, C, g.Md,
                             g.Wp, g.Wp, g.Sz};
@@ -348,10 +384,18 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
   const bool both_dgrads = fc_is_wino(mode_) && g_source && g_target;
   if (both_dgrads) {
     const int nch_h = kFcHidden / kFcChunk;
+    const bool hyb_d = fc_hyb(mode_) && fc_hyb_fits(L, k);
     const bool d16 = w16 && fc_w16_dgrad(k);
-    if (d16 && !own)   // max |dz| of both gradient maps: the scale of their two-term f16 split
+    if ((d16 || hyb_d) && !own)   // max |dz| of both gradient maps: the scale of their two-term f16 split
       GFLA_TRY(fc_maxabs_multi(dzs, B * L.hs.Sz * kFcHidden, amax + kAmaxZs, dzt, B * L.ht.Sz * kFcHidden, amax + kAmaxZt, nullptr,
                                0, nullptr, stream));
+    if (hyb_d) {   // the direct f16x2 kernels on the float32 gradient maps (see fc_hyb)
+      const int64_t wsplit_d = fc_wpack_bytes(L.nt_d, nch_h, k, 2) / 2;
+      GFLA_TRY(fc_conv_f32src(fc_desc_nhwc(dzs, L.hs.Sz, kFcHidden), ws + L.wd_s, wsplit_d, reinterpret_cast<float *>(sc + L.dxs),
+                              L.hs.Mdg * (int64_t)C, C, C, B, nch_h, L.hs.Md, L.hs.Wp, L.hs.Wp, k, amax + kAmaxZs, amax + kAmaxW, stream));
+      GFLA_TRY(fc_conv_f32src(fc_desc_nhwc(dzt, L.ht.Sz, kFcHidden), ws + L.wd_t, wsplit_d, reinterpret_cast<float *>(sc + L.dxt),
+                              L.ht.Mdg * (int64_t)C, C, C, B, nch_h, L.ht.Md, L.ht.Wp, L.ht.Wp, k, amax + kAmaxZt, amax + kAmaxW, stream));
+    } else {
     const WnConvJob jobs[2] = {
         {fc_desc_nhwc(dzs, L.hs.Sz, kFcHidden), reinterpret_cast<const float *>(ws + L.wu_ds),
          reinterpret_cast<float *>(sc + L.dxs), L.hs.Mdg * (int64_t)C, C, C, L.hs.Md, L.hs.Wp, L.hs.Wp, L.hs.Sz},
@@ -359,6 +403,7 @@ static int fc_backward(void *ws_, const float *flow, const float *w1, const floa
          reinterpret_cast<float *>(sc + L.dxt), L.ht.Mdg * (int64_t)C, C, C, L.ht.Md, L.ht.Wp, L.ht.Wp, L.ht.Sz}};
     const uint32_t *const am[2] = {amax + kAmaxZs, amax + kAmaxZt};
     GFLA_TRY(fc_wino_jobs(jobs, 2, am, amax + kAmaxW, d16, B, nch_h, k, stream));
+    }
     // ... and their replicate-pad folds in one launch (fc_sample.hip)
     GFLA_TRY(fc_fold2(reinterpret_cast<const float *>(sc + L.dxs), g_source, L.hs, L.hs.Mdg * (int64_t)C,
                       (flags & GFLA_FC_ACCUMULATE_SOURCE) ? 1 : 0, reinterpret_cast<const float *>(sc + L.dxt), g_target, L.ht,
@@ -494,7 +539,15 @@ int gfla_fc_conv_fwd_f32(const float *x, const float *w0, int is_source, void *w
       GFLA_TRY(fc_maxabs(w0, (int64_t)kFcHidden * 2 * C * k * k, amax + kAmaxW, stream));
     }
     GFLA_TRY(fc_pack_act(x, nullptr, xq, B, C, H, W, g, 0, stream));
-    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16));
+    const bool hyb = fc_hyb(mode) && fc_hyb_fits(L, k), hyb_f = hyb && fc_hyb_fwd(mode, k);
+    if (hyb)
+      GFLA_TRY(fc_pack_weights(w0, amax + kAmaxW, hyb_f ? ws + L.wf_t : nullptr, hyb_f ? ws + L.wf_s : nullptr, ws + L.wd_t, ws + L.wd_s,
+                               C, k, 2, stream));
+    if (hyb_f)
+      return fc_conv_f32src(fc_desc_packed(xq, B, L.nch_c, g.Sx, 0), ws + (is_source ? L.wf_s : L.wf_t),
+                            fc_wpack_bytes(1, L.nch_c, k, 2) / 2, out, g.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, g.Mv, g.Wo,
+                            g.Wp, k, a_x16, amax + kAmaxW, stream);
+    GFLA_TRY(fc_wino_pack_all(L, w0, ws, C, k, stream, w16, hyb));
     const WnConvJob job{fc_desc_packed(xq, B, L.nch_c, g.Sx, 0), reinterpret_cast<const float *>(ws + (is_source ? L.wu_fs : L.wu_ft)),
                         out, g.Mg * kFcHidden, kFcHidden, kFcHidden, g.Mv, g.Wo, g.Wp, g.Sx};
     const uint32_t *const am[1] = {a_x16};
@@ -566,6 +619,31 @@ int gfla_fc_kernel_f32(int which, void *workspace, void *scratch, int64_t B, int
   const bool w16 = mode == 5;
   const uint32_t *amx = reinterpret_cast<const uint32_t *>(ws + L.amax);
   const uint32_t *const am_f[2] = {amx + kAmaxSrc, amx + kAmaxTgt}, *const am_d[2] = {amx + kAmaxZs, amx + kAmaxZt};
+  const bool hyb = fc_hyb(mode) && fc_hyb_fits(L, k), hyb_f = hyb && fc_hyb_fwd(mode, k);
+  const int64_t wsplit_hf = fc_wpack_bytes(1, L.nch_c, k, 2) / 2, wsplit_hd = fc_wpack_bytes(L.nt_d, kFcHidden / kFcChunk, k, 2) / 2;
+  auto hyb_fwd = [&](bool src) {
+    const FcHalf &h = src ? L.hs : L.ht;
+    return fc_conv_f32src(fc_desc_packed(ws + (src ? L.xs : L.xt), B, L.nch_c, h.Sx, 0), ws + (src ? L.wf_s : L.wf_t), wsplit_hf,
+                          reinterpret_cast<float *>(ws + (src ? L.gs : L.gt)), h.Mg * kFcHidden, kFcHidden, kFcHidden, B, L.nch_c, h.Mv,
+                          h.Wo, h.Wp, k, amx + (src ? kAmaxSrc : kAmaxTgt), amx + kAmaxW, stream);
+  };
+  auto hyb_dgrad = [&](bool src) {
+    const FcHalf &h = src ? L.hs : L.ht;
+    return fc_conv_f32src(fc_desc_nhwc(reinterpret_cast<float *>(sc + (src ? L.dzs : L.dzt)), h.Sz, kFcHidden),
+                          ws + (src ? L.wd_s : L.wd_t), wsplit_hd, reinterpret_cast<float *>(sc + (src ? L.dxs : L.dxt)),
+                          h.Mdg * (int64_t)C, C, C, B, kFcHidden / kFcChunk, h.Md, h.Wp, h.Wp, k, amx + (src ? kAmaxZs : kAmaxZt),
+                          amx + kAmaxW, stream);
+  };
+  if (hyb_f && which == 6) {   // (two launches: the direct kernels take one half each)
+    GFLA_TRY(hyb_fwd(true));
+    return hyb_fwd(false);
+  }
+  if (hyb && which == 7) {
+    GFLA_TRY(hyb_dgrad(true));
+    return hyb_dgrad(false);
+  }
+  if (hyb_f && which < 2) return hyb_fwd(source);
+  if (hyb && (which == 2 || which == 3)) return hyb_dgrad(source);
   if (which == 6) {
     const WnConvJob jobs[2] = {
         {fc_desc_packed(ws + L.xs, B, L.nch_c, L.hs.Sx, 0), reinterpret_cast<const float *>(ws + L.wu_fs),

@@ -56,7 +56,12 @@ struct ConvTiling {
   int T, base, rem, heavy, per_ntile;  // heavy = B * rem tiles of base + 1 blocks; per_ntile = B * T
 };
 
-template <int MODE, int KS, int NMB>
+// SRC32 (mode 2 only): the input map is FLOAT32 -- packed 64-byte records or a (B, S, C) map in place, mode 0's descriptor --
+// and becomes the two f16 term planes when a chunk's pixels are written to LDS (scale from the tensor's max |x| slot, pair
+// splits of fc_gemm.h: 12 vector instructions per 16-byte piece, once per chunk against k*k taps of MFMAs); the pieces are held
+// in registers across the previous chunk like mode 0's.  This is what lets arithmetic mode 5 run its k = 5 convolutions on the
+// direct kernels without a second packed copy of anything (round 6, fc_block.hip).
+template <int MODE, int KS, int NMB, bool SRC32 = false>
 __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const unsigned char *__restrict__ Wk,
                                                         int64_t w_split_stride, float *__restrict__ out,
                                                         int64_t out_bs, int ldo, int n_valid, int M, int Wv, int Wp,
@@ -109,8 +114,9 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-  const int per = tmh * F::PIECES;  // 16-byte pieces of one term of the input tile
-  const int x_total = per * F::NS;
+  static_assert(!SRC32 || MODE == 2, "float32 source: mode 2 arithmetic only");
+  const int per = tmh * (SRC32 ? 4 : F::PIECES);  // 16-byte pieces of one term of the input tile (SRC32: of the float32 tile)
+  const int x_total = SRC32 ? per : per * F::NS;
   const int xplane = tmh * PITCH;
 
   // Input tile staging.  Mode 0: the first 64*kFcPrefetch pixels of a chunk's tile are loaded into registers while
@@ -118,11 +124,20 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
   // barriers and the LDS writes, not a global-memory round trip.  (Modes 2/3, and tile pixels beyond the register
   // budget: loaded at the boundary.)
   constexpr int PF = kFcPrefetch;
-  constexpr bool kPrefetch = MODE == 0;
+  constexpr bool kPrefetch = MODE == 0 || SRC32;
+  const float sx32 = SRC32 ? fc_scale(amax_x) : 1.f;
+  // SRC32: a float32 piece (4 channels of a pixel) -> 8 bytes in each term plane
+  auto store_split = [&](unsigned char *dst8, u32x4 v) {
+    uint32_t h01, l01, h23, l23;
+    fc_split_pair(__uint_as_float(v[0]) * sx32, __uint_as_float(v[1]) * sx32, h01, l01);
+    fc_split_pair(__uint_as_float(v[2]) * sx32, __uint_as_float(v[3]) * sx32, h23, l23);
+    *reinterpret_cast<uint2 *>(dst8) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2 *>(dst8 + xplane) = make_uint2(l01, l23);
+  };
   u32x4 pf[PF];
   const int pix0 = t >> 2;
   const unsigned char *pf_src = xg + (t & 3) * 16;
-  unsigned char *pf_dst = xs + (size_t)pix0 * PITCH + (t & 3) * 16;
+  unsigned char *pf_dst = xs + (size_t)pix0 * PITCH + (t & 3) * (SRC32 ? 8 : 16);
   const int x_first = kPrefetch ? min(x_total, 256 * PF) : 0;  // pieces covered by the register path
 
   Frag<MODE> cur[F::KB], nxt[F::KB];
@@ -133,9 +148,16 @@ __global__ __launch_bounds__(256, 2) void fc_conv_kernel(PackedDesc X, const uns
     if constexpr (kPrefetch) {
 #pragma unroll
       for (int q = 0; q < PF; ++q)
-        if (pix0 + 64 * q < tmh) *reinterpret_cast<u32x4 *>(pf_dst + (size_t)q * 64 * PITCH) = pf[q];
+        if (pix0 + 64 * q < tmh) {
+          if constexpr (SRC32) store_split(pf_dst + (size_t)q * 64 * PITCH, pf[q]);
+          else *reinterpret_cast<u32x4 *>(pf_dst + (size_t)q * 64 * PITCH) = pf[q];
+        }
     }
-    if (x_first < x_total) {
+    if constexpr (SRC32) {   // tile pixels beyond the register budget: loaded at the boundary
+      const unsigned char *src = xg + (int64_t)cc * x_cs + (t & 3) * 16;
+      for (int pix = pix0 + 64 * PF; pix < tmh; pix += 64)
+        store_split(xs + (size_t)pix * PITCH + (t & 3) * 8, *reinterpret_cast<const u32x4 *>(src + (int64_t)pix * x_ps));
+    } else if (x_first < x_total) {
       const unsigned char *src = xg + (int64_t)cc * x_cs;
       for (int base = x_first + t; base < x_total; base += 256 * 4) {
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
@@ -249,7 +271,7 @@ inline int pick_conv_tiling(int M, int64_t B, int ntiles_n, int Wv, int Wp, int 
   return nmb;
 }
 
-template <int MODE, int KS, int NMB>
+template <int MODE, int KS, int NMB, bool SRC32 = false>
 static int launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs,
                        int ldo, int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const ConvTiling &tl,
                        const uint32_t *amax_x, const uint32_t *amax_w, hipStream_t stream) {
@@ -258,7 +280,7 @@ static int launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stri
   const unsigned lds = (unsigned)(F::NS * tmh * F::PITCH);
   const int64_t wgs = (int64_t)tl.per_ntile * ceil_div(n_valid, kFcTN);
   if (wgs > 0x7fffffffLL) return GFLA_ERR_UNSUPPORTED;
-  auto kern = fc_conv_kernel<MODE, KS, NMB>;
+  auto kern = fc_conv_kernel<MODE, KS, NMB, SRC32>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<dim3((unsigned)wgs), 256, lds, stream>>>(X, static_cast<const unsigned char *>(wk), w_split_stride, out, out_bs,
@@ -266,13 +288,13 @@ static int launch_conv(const PackedDesc &X, const void *wk, int64_t w_split_stri
   return launch_status();
 }
 
-template <int MODE, int KS>
+template <int MODE, int KS, bool SRC32 = false>
 static int dispatch_conv(int nmb, const PackedDesc &X, const void *wk, int64_t wss, float *out, int64_t out_bs, int ldo,
                          int n_valid, int64_t B, int nch, int M, int Wv, int Wp, const ConvTiling &tl, const uint32_t *ax,
                          const uint32_t *aw, hipStream_t s) {
   switch (nmb) {
 #define GFLA_CASE(N_) \
-  case N_: return launch_conv<MODE, KS, N_>(X, wk, wss, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, tl, ax, aw, s)
+  case N_: return launch_conv<MODE, KS, N_, SRC32>(X, wk, wss, out, out_bs, ldo, n_valid, B, nch, M, Wv, Wp, tl, ax, aw, s)
     GFLA_CASE(2);
     GFLA_CASE(3);
     GFLA_CASE(4);

@@ -83,6 +83,22 @@ __device__ __forceinline__ float fc_inv_scale(const uint32_t *amax) {
   return amax ? __uint_as_float((uint32_t)(254 - fc_scale_exp(*amax)) << 23) : 1.f;
 }
 
+// (hi0, hi1) and (lo0, lo1) f16 words of two float values, hi = RN16(v), lo = RN16(v - hi), in four instructions:
+// v_cvt_pk_f16_f32 (both hi), two v_fma_mix_f32 (v * 1 - hi with hi read as f16 from either half: the exact remainders),
+// v_cvt_pk_f16_f32 (both lo).  The values are made opaque first: with the arithmetic that produced them in sight hipcc fuses
+// it into the convert (v_fma_mixlo_f16 of the unrounded result) and hi is no longer the half the remainder was taken from.
+typedef _Float16 fc_f16x2 __attribute__((ext_vector_type(2)));
+typedef float fc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fc_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo) {
+  asm("" : "+v"(v0));
+  asm("" : "+v"(v1));
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(fc_f32x2{v0, v1}, fc_f16x2));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(hi));
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(fc_f32x2{r0, r1}, fc_f16x2));
+}
+
 // ---- geometry of one half (source or target) of the layer, shared by host code ------------------
 struct FcHalf {
   int Hp, Wp;      // replicate-padded input (Wp = the row pitch of the linearised input and gradient maps of this half)
@@ -147,6 +163,11 @@ int fc_pack_weights(const float *w0, const uint32_t *amax, void *wf_t, void *wf_
 int fc_conv(const PackedDesc &X, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
             int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k, int mode, const uint32_t *amax_x,
             const uint32_t *amax_w, hipStream_t stream);
+// mode 2's arithmetic (two f16 terms per operand, three cross products) on a FLOAT32 input map (packed records or the
+// (B, S, C) gradient map in place): the split happens when a chunk's pixels are written to LDS; weights = mode 2's pack
+int fc_conv_f32src(const PackedDesc &X32, const void *wk, int64_t w_split_stride, float *out, int64_t out_bs, int ldo,
+                   int n_valid, int64_t B, int nch, int M, int Wv, int Wp, int k, const uint32_t *amax_x,
+                   const uint32_t *amax_w, hipStream_t stream);
 bool fc_conv_fits(int Wv, int Wp, int k, int mode);
 int fc_wgrad(const PackedDesc &X, const PackedDesc &Y, int64_t y_lead, float *dwacc, int cpad, int64_t B, int Mk,
              int Wp, int k, int mode, hipStream_t stream);

@@ -960,16 +960,8 @@ __device__ __forceinline__ void wn16_split_halves(float v, _Float16 &h, _Float16
   asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(rem) : "v"(v), "v"(h));
   l = (_Float16)rem;
 }
-// (hi0, hi1) and (lo0, lo1) words of two values
-__device__ __forceinline__ void wn16_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo) {
-  asm("" : "+v"(v0));
-  asm("" : "+v"(v1));
-  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{v0, v1}, f16x2w));
-  float r0, r1;
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v0), "v"(hi));
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v1), "v"(hi));
-  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{r0, r1}, f16x2w));
-}
+// (hi0, hi1) and (lo0, lo1) words of two values (fc_gemm.h)
+__device__ __forceinline__ void wn16_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo) { fc_split_pair(v0, v1, hi, lo); }
 // row `A6` of A (6 x 2) applied to (a, b): the lift of one output-gradient pair to a point
 template <int A6>
 __device__ __forceinline__ float ww_lift2(float a, float b) {
