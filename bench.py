@@ -589,6 +589,13 @@ def fc_kernel_probes(hp, iters=10):
             stream = torch.cuda.current_stream(s.device)
             flops = 2.0 * B * H * W * C * k * k * 128
             layer_rows = []
+            # mode 5 (csrc/fc_block.hip: fc_hyb): the k = 5 convolutions and every data gradient run on the DIRECT kernels with
+            # two f16 terms per operand and three cross products, reading the float32 maps in place; tuning key 52 = 1: Winograd
+            import global_flow_local_attention_amd as _g
+            _old52 = _g.set_tuning(52, 0)
+            _g.set_tuning(52, _old52)
+            hyb = mode == 5 and _old52 != 1
+            geo = {True: fc_mfma.geometry(H, W, k, True), False: fc_mfma.geometry(H, W, k, False)}
             for which, nm in enumerate(names):
                 if which > 5 and mode not in (4, 5):
                     continue
@@ -602,7 +609,27 @@ def fc_kernel_probes(hp, iters=10):
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / iters * 1e3
                 row = {"dims": [B, C, H, W, k], "avg_us": round(us, 1)}
-                if which > 5:   # two jobs in one launch: the sums of the two halves' rows above
+                direct16 = hyb and ((which in (0, 1, 6) and k == 5) or which in (2, 3, 7))
+                if direct16 and which < 4:
+                    # direct convolution: the kernel executes k*k multiplies per (output row, c, n) over the rows of ITS domain --
+                    # the convolved map (Ho x Wo) forward, the padded domain (Hp x Wp) for the data gradient
+                    g = geo[which % 2 == 0]
+                    rows_out = g["Ho"] * g["Wo"] if which < 2 else g["Hp"] * g["Wp"]
+                    done = 2.0 * B * rows_out * C * k * k * 128
+                    row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "useful_GFLOP": round(flops / 1e9, 2), "effective_GFLOP": round(flops / 1e9, 2),
+                                "effective_TFLOPs": round(flops / (us * 1e-6) / 1e12, 1), "in_step": True, "launches": 1})
+                    kern = "fc_conv_kernel<f16x2 from f32>"
+                elif direct16:   # which 6 / 7: the two launches above, back to back (the direct kernels take one half each)
+                    halves = layer_rows[0:2] if which == 6 else layer_rows[2:4]
+                    done = sum(r["alg_GFLOP"] for r in halves) * 1e9
+                    eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
+                    row.update({"alg_GFLOP": round(done / 1e9, 2), "TFLOPs": round(done / (us * 1e-6) / 1e12, 1),
+                                "useful_GFLOP": round(sum(r["useful_GFLOP"] for r in halves), 2),
+                                "effective_GFLOP": round(eff / 1e9, 2), "effective_TFLOPs": round(eff / (us * 1e-6) / 1e12, 1),
+                                "launches": 2, "note": "the two launches of the rows above, back to back"})
+                    kern = "fc_conv_kernel<f16x2 from f32>"
+                elif which > 5:   # two jobs in one launch: the sums of the two halves' rows above
                     halves = layer_rows[0:2] if which == 6 else (layer_rows[2:4] if which == 7 else layer_rows[4:6])
                     done = sum(r["alg_GFLOP"] for r in halves) * 1e9
                     eff = sum(r["effective_GFLOP"] for r in halves) * 1e9
@@ -633,16 +660,19 @@ def fc_kernel_probes(hp, iters=10):
                     row.update({"alg_GFLOP": round(flops / 1e9, 2), "TFLOPs": round(flops / (us * 1e-6) / 1e12, 1)})
                 # mode 5: which convolutions run on the two-term f16 kernel (csrc/fc_block.hip: fc_w16_dgrad)
                 # ... and the weight gradient of the k = 5 layer (both halves in one launch: csrc/fc_block.hip: fc_w16_wgrad)
-                w16 = mode == 5 and (which in (0, 1, 6) or (which in (2, 3, 7) and k == 5) or (which == 8 and k == 5))
+                w16 = mode == 5 and (which in (0, 1, 6) or (which in (2, 3, 7) and k == 5) or (which == 8 and k == 5)) and not direct16
                 if mode == 5 and not w16 and kern == "fc_wino16_conv_kernel":
                     kern = "fc_wino_conv_kernel"
+                if mode == 5 and hyb and not direct16 and which < 4:
+                    row["in_step"] = False   # (not what the step issues in this configuration: a reference row)
                 row["kernel"] = "%s<mode %d, k %d>: %s" % (kern, mode, k, nm)
                 row["frac_mfma_f32_peak"] = round(row["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
-                if w16:
-                    # every Winograd-domain multiply is formed from two f16 terms per operand, all four cross products: the
-                    # matrix cores execute 4 f16 MACs per f32-equivalent one (two v_mfma_f32_32x32x16_f16 per 8 channels)
+                if w16 or direct16:
+                    # Winograd-domain kernels: every multiply is formed from two f16 terms per operand, all four cross products --
+                    # 4 f16 MACs per f32-equivalent one (two v_mfma_f32_32x32x16_f16 per 8 channels); direct kernels: three
                     row["pipe"] = "f16"
-                    row["f16_pipe_TFLOPs"] = round(4.0 * row["alg_GFLOP"] * 1e9 / (us * 1e-6) / 1e12, 1)
+                    row["f16_macs_per_mac"] = 3 if direct16 else 4
+                    row["f16_pipe_TFLOPs"] = round(row["f16_macs_per_mac"] * row["alg_GFLOP"] * 1e9 / (us * 1e-6) / 1e12, 1)
                     row["frac_mfma_f16_peak"] = round(row["f16_pipe_TFLOPs"] / MFMA_F16_PEAK_TFLOPS, 4)
                     row["frac_mfma_f32_peak_note"] = "f32-EQUIVALENT Winograd-domain flops / time / f32 peak: not a pipe fraction in this mode"
                 rows.append(row)
@@ -1237,41 +1267,51 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         line["value"] = round(images * world * args.steps / elapsed, 2)
         line["unit"] = "frames/s" if face else "images/s"
     if probes:
-        # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the one
-        # with the longest launch
-        dom = max(probes, key=lambda r: r["avg_us"])
-        step_rows = [r for r in probes if r.get("in_step") and r["dims"] == dom["dims"]
-                     and r["kernel"].split("<")[0] == dom["kernel"].split("<")[0]]
-        if dom.get("in_step") and len(step_rows) > 1:
-            # the step launches this kernel twice per layer (forward of both halves, data gradient of both halves): the
-            # object describes the kernel over both launches, so its average duration is the one a kernel trace shows
+        # the dominant kernels of the step are the MFMA kernels of the FC path; the roofline object describes the kernel the step
+        # spends the most time in (all of its launches in the step: the direct convolutions of the k = 5 layer are four launches,
+        # the Winograd-domain ones two, a weight gradient one)
+        groups = {}
+        for r in probes:
+            if r.get("in_step"):
+                groups.setdefault((r["kernel"].split(":")[0], tuple(r["dims"])), []).append(r)
+        if groups:
+            step_rows = max(groups.values(), key=lambda rs: sum(r["avg_us"] for r in rs))
+        else:
+            step_rows = [max(probes, key=lambda r: r["avg_us"])]
+        dom = dict(max(step_rows, key=lambda r: r["avg_us"]))
+        nl = sum(r.get("launches", 1) for r in step_rows)
+        if len(step_rows) > 1 or nl > 1:
             tus = sum(r["avg_us"] for r in step_rows)
             alg, eff = sum(r["alg_GFLOP"] for r in step_rows), sum(r["effective_GFLOP"] for r in step_rows)
             if all("useful_GFLOP" in r for r in step_rows):
-                dom = dict(dom, useful_GFLOP=round(sum(r["useful_GFLOP"] for r in step_rows) / len(step_rows), 2))
-            dom = dict(dom, kernel=dom["kernel"].split(":")[0] + ": both launches of the step (forward and data gradient, "
-                                   "source + target halves in one launch each)",
-                       avg_us=round(tus / len(step_rows), 1), alg_GFLOP=round(alg / len(step_rows), 2),
+                dom["useful_GFLOP"] = round(sum(r["useful_GFLOP"] for r in step_rows) / nl, 2)
+            dom.update(kernel=dom["kernel"].split(":")[0] + ": all %d launches of the step (forward and data gradient, source and target "
+                                                          "halves)" % nl,
+                       avg_us=round(tus / nl, 1), alg_GFLOP=round(alg / nl, 2),
                        TFLOPs=round(alg * 1e9 / (tus * 1e-6) / 1e12, 1), effective_TFLOPs=round(eff * 1e9 / (tus * 1e-6) / 1e12, 1))
             dom["frac_mfma_f32_peak"] = round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)
             if dom.get("pipe") == "f16":
-                dom["f16_pipe_TFLOPs"] = round(4.0 * alg * 1e9 / (tus * 1e-6) / 1e12, 1)
+                dom["f16_pipe_TFLOPs"] = round(dom.get("f16_macs_per_mac", 4) * alg * 1e9 / (tus * 1e-6) / 1e12, 1)
                 dom["frac_mfma_f16_peak"] = round(dom["f16_pipe_TFLOPs"] / MFMA_F16_PEAK_TFLOPS, 4)
         f16pipe = dom.get("pipe") == "f16"
         line["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "dims": dom["dims"],
                             "achieved": dom["f16_pipe_TFLOPs"] if f16pipe else dom["TFLOPs"],
                             "peak": MFMA_F16_PEAK_TFLOPS if f16pipe else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": dom["frac_mfma_f16_peak"] if f16pipe else dom["frac_mfma_f32_peak"], "avg_us": dom["avg_us"],
-                            **({"pipe": "f16 matrix cores, two f16 terms per operand: executed f16 MACs = 4 x the Winograd-domain "
-                                        "multiplies; the kernel is bound by its LDS / vector work (transforms, f16 split), not by "
-                                        "the matrix cores (DESIGN.md 4)",
+                            **({"pipe": ("f16 matrix cores, two f16 terms per operand, three cross products: executed f16 MACs = 3 x the "
+                                         "direct convolution's multiplies over the kernel's own output domain (DESIGN.md 4)"
+                                         if dom.get("f16_macs_per_mac") == 3 else
+                                         "f16 matrix cores, two f16 terms per operand: executed f16 MACs = 4 x the Winograd-domain "
+                                         "multiplies; the kernel is bound by its LDS / vector work (transforms, f16 split), not by "
+                                         "the matrix cores (DESIGN.md 4)"),
                                 "f32_equivalent_TFLOPs": dom["TFLOPs"],
-                                # round 5's yardstick for this kernel (executed Winograd-domain flops / time / f32 MFMA peak:
-                                # 0.58 on the f32 pipe then): NOT a pipe fraction in this mode, the same work per second
-                                "f32_equivalent_frac_of_f32_peak": round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)} if f16pipe else {}),
+                                # (Winograd-domain kernels only) round 5's yardstick for the convolution kernel -- executed
+                                # Winograd-domain flops / time / f32 MFMA peak, 0.58 on the f32 pipe then: NOT a pipe fraction
+                                **({"f32_equivalent_frac_of_f32_peak": round(dom["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 4)}
+                                   if dom.get("f16_macs_per_mac") == 4 else {})} if f16pipe else {}),
                             "alg_GFLOP_per_launch": dom["alg_GFLOP"],
                             **({"effective_TFLOPs": dom["effective_TFLOPs"]} if "effective_TFLOPs" in dom else {}),
-                            **({"useful_frac": round((4.0 if f16pipe else 1.0) * dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12
+                            **({"useful_frac": round((float(dom.get("f16_macs_per_mac", 4)) if f16pipe else 1.0) * dom["useful_GFLOP"] * 1e9 / (dom["avg_us"] * 1e-6) / 1e12
                                                      / (MFMA_F16_PEAK_TFLOPS if f16pipe else MFMA_F32_PEAK_TFLOPS), 4),
                                 "useful_frac_note": "executed Winograd-domain flops over the UN-extended output domain only (the "
                                                     "tiles whose outputs the caller keeps) / time / peak"}
@@ -1280,7 +1320,10 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                             "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                               "passes) of this bench, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; table: "
                                               + pmc_table_provenance(),
-                            "flops": ("Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "
+                            "flops": ("direct convolution: achieved = 2*B*rows*C*k*k*128 over the rows the kernel computes (the convolved "
+                                      "map forward, the padded domain for the data gradient) x 3 f16 MACs each / time; useful = "
+                                      "the reference formulation's 2*B*H*W*C*k*k*128" if dom.get("f16_macs_per_mac") == 3 else
+                                      "Winograd domain: achieved = the 36 multiplies per (tile, c, n) the kernel executes "
                                       "(2*36*tiles*C*128; tiles = ceil(rows/m)*ceil(cols/m) of the output domain, m = 2 for "
                                       "F(2x2,5x5), 4 for F(4x4,3x3)) / time; effective_TFLOPs = the reference formulation's "
                                       "2*B*H*W*C*k*k*128 / time" if args.fc_mode in (4, 5) else
