@@ -57,7 +57,7 @@ typedef void *gfla_stream_t; /* hipStream_t */
  *   7: round 5 (path ids 13-17, tuning keys 30-41: the big-plane kernels of csrc/tile_map.h; gfla_big_plane_geometry,
  *      gfla_xcd_swizzle)
  *   8: round 6 (arithmetic mode 5 of gfla_fc_*: Winograd domain with two-term f16 operands on the f16 matrix cores,
- *      csrc/fc_wino16.hip; path ids 18 / 19; tuning keys 43, 46, 49) */
+ *      csrc/fc_wino16.hip; path ids 18 / 19; tuning keys 43, 46, 49, 52) */
 #define GFLA_ABI_VERSION 8
 int gfla_abi_version(void);
 const char *gfla_status_string(int status);
@@ -99,6 +99,9 @@ const char *gfla_status_string(int status);
  *           instead of the owner-computes kernel of round 6 (csrc/fc_sample.hip: fc_scatter_own_kernel)
  *   key 49: arithmetic mode 5: 1 = the k = 5 weight gradient on the float32 Winograd kernel (rounds 3-5) instead of the
  *           two-term f16 kernel (csrc/fc_wino.hip: fc_wino16_wgrad_kernel)
+ *   key 52: arithmetic mode 5: 1 = Winograd-domain kernels for every convolution (the first half of round 6) instead of the
+ *           hybrid dispatch (direct f16x2 kernels fed from the float32 maps for the k = 5 convolutions and all data gradients:
+ *           csrc/fc_block.hip: fc_hyb, csrc/fc_conv_impl.h: SRC32)
  *   key 38: 1 = the first version of the gathers (taps read from global memory, no LDS window); key 33 = its channels per wave
  * (the other keys select experiments of individual kernels; see the tuning(...) calls in csrc/)                  */
 int gfla_set_tuning(int key, int value);
