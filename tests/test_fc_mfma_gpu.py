@@ -443,3 +443,27 @@ def test_two_term_f16_weight_gradient_equals_float32(lib, gfla, C, H, W):
     assert torch.isfinite(f16[4]).all() and e <= 1e-5, e
     for a, b_ in zip(f16[:4] + f16[5:], f32[:4] + f32[5:]):
         assert torch.equal(a, b_)   # nothing else changes
+
+
+@pytest.mark.parametrize("k,C,H,W", [(5, 16, 40, 28), (3, 24, 33, 17), (5, 128, 64, 44)])
+def test_mode5_hybrid_dispatch_equals_the_winograd_form(lib, gfla, k, C, H, W):
+    """Mode 5's default dispatch (direct f16x2 kernels reading the float32 maps in place for the k = 5 convolutions and every data
+    gradient: fc_conv_kernel<..., SRC32>) against the all-Winograd form of the first half of round 6 (tuning key 52 = 1) through
+    the whole layer: two float32-grade evaluations of the same sums, a few 1e-6 of the largest entry apart."""
+    B = 2
+    s, t = randn((B, C, H, W), seed=91).to(DEV), randn((B, C, H, W), seed=92).to(DEV)
+    f = make_flow("smooth", B, H, W, seed=93).to(DEV)
+    w0 = (randn((128, 2 * C, k, k), seed=94) / (2 * C * k * k) ** 0.5).to(DEV)
+    b0, b1 = (randn((128,), seed=95) * 0.1).to(DEV), (randn((k * k,), seed=97) * 0.1).to(DEV)
+    w1 = (randn((k * k, 128, 1, 1), seed=96) / 128 ** 0.5).to(DEV)
+    up = randn((B, k * k, H, W), seed=98).to(DEV)
+    hyb = _fc_backward_raw(lib, 5, s, t, f, w0, b0, w1, b1, up, k)
+    old = gfla.set_tuning(52, 1)
+    try:
+        wino = _fc_backward_raw(lib, 5, s, t, f, w0, b0, w1, b1, up, k)
+    finally:
+        gfla.set_tuning(52, old)
+    names = ("logits", "source", "target", "flow", "w0", "b0", "w1", "b1")
+    for n_, a, b_ in zip(names, hyb, wino):
+        e = rel_err(a.cpu(), b_.cpu())
+        assert torch.isfinite(a).all() and e <= 1.5e-5, "%s: %.2e" % (n_, e)

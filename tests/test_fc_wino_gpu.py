@@ -57,20 +57,23 @@ SWEEP = [  # (k, B, C, H, W): ragged / tiny / odd / wide
 
 @pytest.mark.parametrize("k,B,C,H,W", SWEEP)
 @pytest.mark.parametrize("is_source", [0, 1])
-@pytest.mark.parametrize("wmode", [4, 5, 50])
+@pytest.mark.parametrize("wmode", [4, 5, 52, 50])
 def test_winograd_half_on_ragged_shapes(gfla, k, B, C, H, W, is_source, wmode):
-    """wmode 50 = mode 5 with the two-term f16 kernel forced for EVERY convolution (tuning key 43 = 1: by default mode 5 keeps
-    the k = 3 data gradient on the float32 Winograd kernel, where that is faster)."""
+    """wmode 5 = the default dispatch of mode 5 (later in round 6: the direct f16x2 kernels fed from the float32 maps for the
+    k = 5 convolutions and every data gradient, Winograd domain for the k = 3 forward and the weight gradients); 52 = mode 5
+    with Winograd-domain kernels for every convolution (tuning key 52 = 1: the first half of round 6); 50 = that with the
+    two-term f16 kernel forced for the k = 3 data gradient as well (key 43 = 1; the float32 Winograd kernel otherwise)."""
     from global_flow_local_attention_amd import fc_mfma
-    force16 = wmode == 50
-    wmode = 5 if force16 else wmode
+    force16, all_wino = wmode == 50, wmode in (50, 52)
+    wmode = 5 if all_wino else wmode
     if force16 and k != 3:
         pytest.skip("key 43 only changes k = 3")
-    old43 = gfla.set_tuning(43, 1 if force16 else 0)
+    old43, old52 = gfla.set_tuning(43, 1 if force16 else 0), gfla.set_tuning(52, 1 if all_wino else 0)
     try:
         _ragged(gfla, k, B, C, H, W, is_source, wmode)
     finally:
         gfla.set_tuning(43, old43)
+        gfla.set_tuning(52, old52)
 
 
 def _ragged(gfla, k, B, C, H, W, is_source, wmode):
