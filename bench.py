@@ -1205,7 +1205,7 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
         notes = {0: "float32, DIRECT convolution kernels (a k-ordered fma chain per output): the same step without the "
                     "Winograd-domain formulation",
                  4: "float32 operands on f32 MFMA, Winograd-domain convolutions and weight gradient (the default of rounds 3-5)",
-                 5: "Winograd domain, two-term f16 operands with all four cross products on f16 MFMA (the product default)"}
+                 5: "two f16 terms per operand on f16 MFMA, f32 accumulate (the product default)"}
         # the same step with the loss-side warps on a side stream (HotPath.step)
         hv = make_hotpath(args.fc_mode)
         hv.two_streams = not getattr(hp, "two_streams", False)
@@ -1256,8 +1256,9 @@ def run(args, make_hotpath, make_resample, rank, world, device, on_gpu=True, dat
                                   "from autograd hooks, overlapping backward)" % world,
                    "fc_layers": ("this library's MFMA kernels, arithmetic mode %d (%s); no vendor GEMM / convolution in the step"
                                  % (args.fc_mode, {0: "exact f32, direct convolution", 4: "f32, Winograd-domain convolutions F(2x2,5x5) / "
-                                                   "F(4x4,3x3)", 5: "Winograd domain, f32 transforms, two-term f16 operands with all "
-                                                   "four cross products on f16 MFMA, f32 accumulate"}.get(args.fc_mode, "f16-split operands, f32 accumulate")))
+                                                   "F(4x4,3x3)", 5: "two f16 terms per operand (exact to 2^-24) on f16 MFMA, f32 "
+                                                   "accumulate: direct kernels for the k5 convolutions and the data gradients, "
+                                                   "Winograd domain for the k3 forward and the k5 weight gradient"}.get(args.fc_mode, "f16-split operands, f32 accumulate")))
                    if args.fc_impl == "mfma" else "round 1's vendor-library path (torch.mm / F.conv2d)"},
         "kernels": rows,
         "fc_kernels": probes,
@@ -1500,10 +1501,10 @@ def parse_args(argv=None):
     ap.add_argument("--face-one-stream", action="store_true",
                     help="face_bf16: evaluate attn_p and attn_r of a layer one after the other on one stream (default: two streams)")
     ap.add_argument("--fc-mode", type=int, choices=(0, 1, 2, 3, 4, 5), default=5,
-                    help="arithmetic of the FC contraction: 5 = Winograd domain, float32 transforms, every transformed operand as "
-                         "two f16 terms (exact to 2^-24) with all four cross products on the f16 matrix cores, f32 accumulation "
-                         "(the product default and the headline, round 6); 4 = the same domain on f32 MFMA (the default of rounds "
-                         "3-5); 0 = float32, direct convolution; 3 / 2 = three / two f16 terms per operand in the direct "
+                    help="arithmetic of the FC contraction: 5 = float32 tensors, every operand of a product as two f16 terms "
+                         "(exact to 2^-24) on the f16 matrix cores, f32 accumulation -- direct kernels and Winograd-domain kernels, "
+                         "chosen per convolution (the product default and the headline, round 6); 4 = Winograd domain on f32 MFMA "
+                         "(the default of rounds 3-5); 0 = float32, direct convolution; 3 / 2 = three / two f16 terms per operand in the direct "
                          "convolution (labelled experiments)")
     ap.add_argument("--with-losses", action="store_true",
                     help="replace the bare Resample2d sites by the losses that contain them in training (BASELINE "

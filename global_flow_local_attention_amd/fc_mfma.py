@@ -9,10 +9,12 @@ convolution.  `mode` picks the arithmetic of the contraction (include/gfla_hip.h
      2.78x / 4x fewer multiplies); errors against float64 at the bench shapes 1e-6 .. 9e-6, held to the same test bars as
      mode 0;
   0  float32, direct convolution: a k-ordered fma chain per output (what mode 4 falls back to for maps its tiles do not fit);
-  5  float32 tensors and transforms, Winograd domain as in 4, the 36 point-wise GEMMs on the f16 matrix cores with every
-     transformed value split into two f16 terms (hi + lo = the value to 2^-24) and all four cross products accumulated in f32
-     (csrc/fc_wino16.hip): 4x less matrix-core time than 4, the same measured error, the same test bars -- THE DEFAULT
-     (round 6); the weight gradient and the k = 3 data gradient are mode 4's kernels;
+  5  float32 tensors; every operand of a product as TWO f16 terms (hi + lo = the value to 2^-24 after a power-of-two scaling
+     from the tensor's max |x|) on the f16 matrix cores, f32 accumulation -- THE DEFAULT (round 6).  Which kernel runs what is
+     decided per convolution by measurement (csrc/fc_block.hip: fc_hyb): the k = 5 convolutions and every data gradient on the
+     direct kernels (three cross products, mode 2's arithmetic) reading the float32 maps in place; the k = 3 forward and the
+     k = 5 weight gradient in the Winograd domain (all four cross products: csrc/fc_wino16.hip, fc_wino.hip); the k = 3 weight
+     gradient is mode 4's kernel.  Same measured error as mode 4, same test bars;
   3 / 2  operands split into three / two f16 terms, f32 accumulation (labelled experiments);  1  one f16 term (bf16 path).
 """
 import ctypes
@@ -24,15 +26,16 @@ from . import _lib
 
 MODES = (0, 1, 2, 3, 4, 5)
 # float32 is what the reference computes this layer in (base_function.py:799-810): a module without an explicit `fc_mode`
-# gets float32-grade arithmetic -- the Winograd-domain kernels with two-term f16 operands (5: every operand represented to
-# 2^-24, all four cross products, f32 accumulation; measured error = mode 4's), the float32 Winograd kernels (4) or the
+# gets float32-grade arithmetic -- two f16 terms per operand on the f16 matrix cores (5: every operand represented to
+# 2^-24, f32 accumulation; measured error = mode 4's), the float32 Winograd kernels (4) or the
 # float32 direct kernels (0) where the shape does not fit the faster one; 2 / 3 are labelled experiments (lower / other
 # precision trade-offs), 1 belongs to the bf16-feature path
 DEFAULT_MODE = 5
 MODE_NAMES = {0: "f32 MFMA, direct convolution", 1: "one f16 term per operand (exact for bf16 values), f32 accumulate",
               2: "two f16 terms per operand, f32 accumulate", 3: "three f16 terms per operand, f32 accumulate",
               4: "f32 MFMA, Winograd-domain convolutions F(2x2,5x5) / F(4x4,3x3)",
-              5: "Winograd domain F(2x2,5x5) / F(4x4,3x3), two-term f16 operands (4 cross products) on f16 MFMA, f32 accumulate"}
+              5: "two f16 terms per operand on f16 MFMA, f32 accumulate: direct kernels (k5 convolutions, data gradients) + "
+                 "Winograd domain F(2x2,5x5) / F(4x4,3x3) (k3 forward, k5 weight gradient)"}
 
 
 def supported(C, H, W, k, mode=DEFAULT_MODE):
