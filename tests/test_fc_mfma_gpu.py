@@ -398,7 +398,9 @@ def test_owner_computes_scatter_equals_the_atomics(lib, gfla, mode, k, C, H, W, 
     for n_, a, b_, c_ in zip(names, own, atom, again):
         assert torch.isfinite(a).all(), n_
         e = rel_err(a.cpu(), b_.cpu())
-        assert e <= 2e-6, "%s: owner-computes vs atomics %.2e" % (n_, e)
+        # (the atomics add in arrival order: on the collapsing flow a cell collects > 1 000 float contributions and the
+        # ATOMICS' own result moves by ~2e-6 from run to run; the owner-computes sums are exact integers, bit-equal below)
+        assert e <= 1e-5, "%s: owner-computes vs atomics %.2e" % (n_, e)
         if n_ in ("source", "target", "flow", "b0", "w1", "b1", "logits"):   # (w0: the weight gradient's split sums are fixed order too)
             assert torch.equal(a, c_), "%s differs from run to run" % n_
     assert torch.equal(own[4], again[4]), "w0 differs from run to run"
