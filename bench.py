@@ -488,6 +488,8 @@ def pmc_traffic_kernel(kernel_label, in_step=False):
         # fc_conv_kernel<MODE, KS, NMB>, fc_wgrad_f32_kernel<KS>, fc_wgrad_kernel<MODE, KS, NB>,
         # fc_wino_conv_kernel<KS, DBG, DB>, fc_wino_wgrad_kernel<KS>
         ks = args[0] if (len(args) == 1 or name.startswith("fc_wino")) else args[1]
+        if name == "fc_wino16_wgrad_kernel":   # <multi-row, DBG>: the k = 5 layer only
+            ks = "5"
         if k is None or ks == k:
             rows += rs
     if not rows:
